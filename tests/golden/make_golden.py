@@ -1,0 +1,594 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  Everything written here is data: integers, input tensors, weights, and the
+outputs the unmodified reference modules produced for them.  Re-run with
+
+    python -B tests/golden/make_golden.py
+
+Shims applied to make the reference importable/runnable:
+  1. empty stub modules for tensorboard / tensorboardX / librosa / fire
+  2. util.gather_md_scriptable = util.gather_md_jit          (C-7)
+  3. vq_bn.StopGrad / ReplaceGrad injected from vqema_bn     (C-8)
+  4. ConvReLURes.forward residual add made out-of-place      (C-9, forward bit-identical)
+  5. autoencoder wiring: the reference AutoEncoder class cannot be constructed at HEAD
+     (C-5), so its forward/run (autoencoder_model.py:206-259) and _init_geometry
+     (:95-146) are driven here on the reference's own Encoder / bottleneck / WaveNet
+     module instances; decoder.wav_cond_offset := trim_dec_in (C-10).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+from collections import Counter
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("AEW_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+import numpy as np
+import torch
+
+for name in ("tensorboard", "torch.utils.tensorboard", "tensorboardX", "librosa", "fire"):
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.SummaryWriter = object
+        sys.modules[name] = m
+sys.path.insert(0, REF)
+
+import vconv            # noqa: E402
+import util             # noqa: E402
+import hparams          # noqa: E402
+import wavenet          # noqa: E402
+import wave_encoder     # noqa: E402
+import vqema_bn         # noqa: E402
+import vq_bn            # noqa: E402
+import vae_bn           # noqa: E402
+import ae_bn            # noqa: E402
+import mfcc_inverter    # noqa: E402
+
+util.gather_md_scriptable = util.gather_md_jit
+vq_bn.StopGrad = vqema_bn.StopGrad
+vq_bn.ReplaceGrad = vqema_bn.ReplaceGrad
+
+
+def _crr_forward(self, x):
+    pre = self.conv(x)
+    act = self.relu(pre)
+    if self.do_res:
+        act = act + x[:, :, self.residual_offsets[0]:self.residual_offsets[1] or None]
+    self.frac_zero_act = (act == 0.0).sum().double() / act.nelement()
+    return act
+
+
+wave_encoder.ConvReLURes.forward = _crr_forward
+
+
+class _MfccStub:
+    def __init__(self, **kw):
+        pass
+
+
+mfcc_inverter.mfcc.ProcessWav = _MfccStub
+
+
+# ------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------
+def np_weights(shapes, seed, scale=None):
+    """Deterministic weights from numpy's legacy RandomState (stable across versions):
+    uniform(-a, a) with Xavier bound per tensor unless `scale` given; 1-D tensors get
+    small non-zero values so bias paths are exercised."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        if len(shp) >= 2:
+            rf = int(np.prod(shp[2:])) if len(shp) > 2 else 1
+            bound = scale if scale is not None else float(np.sqrt(6.0 / ((shp[0] + shp[1]) * rf)))
+        else:
+            bound = 0.1
+        out[k] = rs.uniform(-bound, bound, size=shp).astype(np.float32)
+    return out
+
+
+def load_np_weights(module, seed, skip=()):
+    """Overwrite every floating-point parameter of `module` with np_weights()."""
+    shapes = {k: tuple(v.shape) for k, v in module.named_parameters()}
+    w = np_weights(shapes, seed)
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            if k in skip:
+                continue
+            p.copy_(torch.from_numpy(w[k]))
+    return w
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def make_hps(**kw):
+    h = hparams.setup_hparams("mfcc_inverter,mfcc,train", {})
+    h.update(kw)
+    return h
+
+
+TINY = dict(n_res=24, n_dil=16, n_skp=20, n_post=12, n_quant=256, n_lc_out=8,
+            n_global_embed=4, n_speakers=5, n_blocks=2, n_block_layers=3, n_win_batch=7)
+
+
+# ------------------------------------------------------------------------------------
+# A. geometry
+# ------------------------------------------------------------------------------------
+def gr2l(g):
+    return [g.full[0], g.full[1], g.sub[0], g.sub[1], g.gs]
+
+
+def build_ae_modules(hps, enc_n_out, n_mel=39):
+    """Reference modules wired like autoencoder_model.py:52-89 (with the live WaveNet
+    signature)."""
+    mfcc_vc = vconv.VirtualConv(filter_info=hps.mfcc_win_sz, stride=hps.mfcc_hop_sz,
+                                parent=None, name="MFCC")
+    enc = wave_encoder.Encoder(n_in=n_mel, n_out=enc_n_out, parent_vc=None)
+    enc.set_parent_vc(mfcc_vc)
+    dec = wavenet.WaveNet(hps, parent_vc=enc.vc["end"])
+    return mfcc_vc, enc, dec
+
+
+def ae_geometry(mfcc_vc, enc, dec, w):
+    """autoencoder_model.py:95-146, verbatim semantics, via the reference vconv."""
+    end_enc_vc = enc.vc["end"]
+    end_ups_vc = dec.vc["last_upsample"]
+    beg_grcc_vc = dec.vc["beg_grcc"]
+    end_grcc_vc = dec.vc["end_grcc"]
+    do = vconv.GridRange((0, 100000), (0, w), 1)
+    di = vconv.input_range(beg_grcc_vc, end_grcc_vc, do)
+    ei = vconv.input_range(mfcc_vc, end_grcc_vc, do)
+    mi = vconv.input_range(mfcc_vc.child, end_grcc_vc, do)
+    eo = vconv.output_range(mfcc_vc, end_enc_vc, ei)
+    uo = vconv.output_range(mfcc_vc, end_ups_vc, ei)
+    return dict(
+        enc_in_len=ei.sub_length(), mel_len=mi.sub_length(), embed_len=eo.sub_length(),
+        dec_in_len=di.sub_length(),
+        trim_dec_in=[di.sub[0] - ei.sub[0], di.sub[1] - ei.sub[0]],
+        trim_ups_out=[di.sub[0] - uo.sub[0], di.sub[1] - uo.sub[0]],
+        trim_dec_out=[do.sub[0] - di.sub[0], do.sub[1] - di.sub[0]],
+    )
+
+
+def gen_geometry():
+    out = {}
+    # --- model geometry, autoencoder --------------------------------------------
+    for tag, kw, ws in (
+        ("vqvae-ema", dict(lc_upsample_strides=[5, 4, 4, 4], n_lc_in=32),
+         [1, 2, 7, 100, 101, 319, 320, 321, 1000, 5000, 8192, 16384, 65536]),
+        ("deep", dict(lc_upsample_strides=[5, 4, 4, 4], n_lc_in=32, n_blocks=3, n_res=512),
+         [100, 5000, 65536]),
+    ):
+        cases = []
+        for w in ws:
+            hps = make_hps(**kw, n_win_batch=w)
+            mfcc_vc, enc, dec = build_ae_modules(hps, 768)
+            g = ae_geometry(mfcc_vc, enc, dec, w)
+            dec.post_init(w)
+            g["leads"] = [layer.leads.tolist() for layer in dec.conv_layers]
+            # WaveNet.get_input_size returns vc['beg'].parent.in_len(), which in the AE wiring is
+            # the encoder's last stage (C-10); the wav length is the chain root's in_len after
+            # the same two-pass solve, so record that.
+            dec.get_input_size(w)
+            g["input_size"] = mfcc_vc.in_len()
+            g["n_win"] = w
+            cases.append(g)
+        out[tag] = cases
+    # --- model geometry, mfcc inverter (runs at HEAD) -----------------------------
+    cases = []
+    for w in [1, 7, 100, 159, 160, 161, 1000, 5000]:
+        hps = make_hps(n_win_batch=w)
+        m = mfcc_inverter.MfccInverter(hps)
+        g = dict(n_win=w, enc_in_len=m.enc_in_len, mel_len=m.enc_in_mel_len,
+                 embed_len=m.embed_len, dec_in_len=m.dec_in_len,
+                 trim_dec_in=m.trim_dec_in.tolist(), trim_dec_out=m.trim_dec_out.tolist(),
+                 trim_ups_out=m.wavenet.trim_ups_out.tolist(),
+                 wav_cond_offset=list(m.wavenet.wav_cond_offset),
+                 leads=[layer.leads.tolist() for layer in m.wavenet.conv_layers])
+        g["input_size"] = m.get_input_size(w)
+        cases.append(g)
+    out["mi"] = cases
+
+    # --- known answers of the reference's own test_vconv.py (keyword fix) --
+    hps = make_hps(lc_upsample_strides=[5, 4, 4, 4], n_lc_in=32)
+    mfcc_vc, enc, dec = build_ae_modules(hps, 768)
+    vcs = {}
+    vc = mfcc_vc
+    while vc is not None:
+        vcs[vc.name.split("(")[0]] = vc
+        vc = vc.child
+    last = "GRCC_1,9"
+    x = vconv.GridRange((0, 250000), (0, 250000), 1)
+    y = vconv.output_range(vcs["MFCC"], vcs[last], x)
+    xi = vconv.input_range(vcs["MFCC"], vcs[last], y)
+    ka = {"full_chain_250000": {"y": gr2l(y), "xi": gr2l(xi)}}
+
+    def phase(src, dst, n_sub, win):
+        c = Counter()
+        for b in range(n_sub):
+            o = vconv.GridRange((0, 90000), (b, b + win), 1)
+            c[vconv.input_range(vcs[src], vcs[dst], o).sub_length()] += 1
+        return {str(k): v for k, v in c.items()}
+
+    ka["phase_upsample"] = phase("Upsampling_0", "Upsampling_3", 20, 2146)
+    ka["phase_half_upsample"] = phase("Upsampling_2", "Upsampling_3", 20, 2146)
+    ka["phase_encclip_upsample"] = phase("CRR_0", "Upsampling_3", 6000, 2146)
+    ka["phase_decoder"] = phase("GRCC_0,0", last, 6000, 100)
+    c = Counter()
+    for b in range(10000):
+        o = vconv.GridRange((0, 100000), (b, b + 1), 1)
+        i = vconv.input_range(vcs["Upsampling_0"], vcs[last], o)
+        c[str(list(vconv.tensor_slice(i, i.sub)))] += 1
+    ka["usage_10000"] = dict(c)
+    # autoenc_test(vcs, 100000, 56730) (test_vconv.py:207-253)
+    full_in = vconv.GridRange((0, 100000), (0, 100000), 1)
+    full_out = vconv.output_range(vcs["MFCC"], vcs[last], full_in)
+    out_req = vconv.GridRange(full_out.full, (56730, 56830), 1)
+    mid_req = vconv.input_range(vcs["GRCC_0,0"], vcs[last], out_req)
+    in_req = vconv.input_range(vcs["MFCC"], vcs["Upsampling_3"], mid_req)
+    mfcc_act = vconv.output_range(vcs["MFCC"], vcs["MFCC"], in_req)
+    mid_act = vconv.output_range(vcs["MFCC"], vcs["Upsampling_3"], in_req)
+    ka["autoenc_100000_56730"] = dict(
+        in_req=gr2l(in_req), mfcc_req=gr2l(mfcc_act), mid_req=gr2l(mid_req),
+        mid_act=gr2l(mid_act), full_out=gr2l(full_out),
+        wav_mid_sl=list(vconv.tensor_slice(in_req, mid_req.sub)),
+        lcond_sl=list(vconv.tensor_slice(mid_act, mid_req.sub)),
+        wav_out_sl=list(vconv.tensor_slice(in_req, out_req.sub)))
+    out["known_answers"] = ka
+
+    # --- randomized single-stage sweep (pins _forward/_backward incl. empty cases) ---
+    rs = np.random.RandomState(7)
+    sweep = []
+    while len(sweep) < 3000:
+        lw, rw = int(rs.randint(0, 6)), int(rs.randint(0, 6))
+        lp, rp = int(rs.randint(0, lw + 1)), int(rs.randint(0, rw + 1))
+        st = int(rs.randint(1, 6))
+        down = bool(rs.randint(0, 2))
+        vc = vconv.VirtualConv((lw, rw), (lp, rp), st, down, name="s")
+        gs = int(rs.choice([1, 2, 3, 4, 6, 8])) * (1 if down else st)
+        fb = int(rs.randint(-20, 20))
+        l1, l2, l3 = int(rs.randint(0, 8)), int(rs.randint(0, 40)), int(rs.randint(0, 8))
+        sb = fb + l1 * gs
+        se = sb + l2 * gs + 1
+        fe = se + l3 * gs
+        gin = vconv.GridRange((fb, fe), (sb, se), gs)
+        rec = dict(stage=[lw, rw, st, down, lp, rp], span=gr2l(gin))
+        try:
+            rec["fwd"] = gr2l(vconv.output_range(vc, vc, gin))
+        except RuntimeError:
+            rec["fwd"] = None
+        if down and gs % st:
+            rec["bwd"] = "skip"
+        else:
+            try:
+                rec["bwd"] = gr2l(vconv.input_range(vc, vc, gin))
+            except RuntimeError:
+                rec["bwd"] = None
+            except AssertionError:
+                rec["bwd"] = "assert"
+        sweep.append(rec)
+    out["stage_sweep"] = sweep
+    with open(os.path.join(HERE, "geometry.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+    print("wrote geometry.json", os.path.getsize(os.path.join(HERE, "geometry.json")) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------------------------
+# B. MfccInverter end-to-end (the model that runs unmodified at HEAD)
+# ------------------------------------------------------------------------------------
+def run_mi(hps, seed, B, jitter_kind):
+    torch.manual_seed(0)
+    m = mfcc_inverter.MfccInverter(hps)
+    m.train()
+    w = load_np_weights(m, seed)
+    g = torch.Generator().manual_seed(seed)
+    n_mel = m.embed_len
+    wav = torch.randint(0, hps.n_quant, (B, m.enc_in_len), generator=g).float()
+    mel = torch.randn(B, hps.n_lc_in, n_mel, generator=g)
+    voice = torch.randint(0, hps.n_speakers, (B,), generator=g)
+    if jitter_kind == "identity":
+        jitter = torch.arange(n_mel).repeat(B, 1)
+    else:
+        rs = np.random.RandomState(seed)
+        j = np.arange(n_mel)[None, :] + rs.randint(-1, 2, size=(B, n_mel))
+        jitter = torch.from_numpy(np.clip(j, 0, n_mel - 1)).long()
+    pred, target, loss = m.run(wav, mel, voice, jitter)
+    loss.backward()
+    grads = {"grad." + k: t2n(p.grad) for k, p in m.named_parameters()}
+    mel_grad = torch.autograd.grad(
+        m.objective(*(lambda q: (q[..., :-1], target))(m.forward(wav, mel, voice, jitter))), mel)[0]
+    res = dict(wav=t2n(wav), mel=t2n(mel), voice=t2n(voice), jitter=t2n(jitter),
+               pred=t2n(pred), target=t2n(target), loss=t2n(loss), mel_grad=t2n(mel_grad),
+               mel_grad_sd=t2n(m.objective.metrics["mel_grad_sd"]),
+               mel_grad_mean=t2n(m.objective.metrics["mel_grad_mean"]))
+    res.update({"w." + k: v for k, v in w.items()})
+    res.update(grads)
+    return res, m
+
+
+def gen_mi():
+    for tag, jk in (("identity", "identity"), ("jitter", "random")):
+        hps = make_hps(**TINY, n_lc_in=7)
+        res, _ = run_mi(hps, 11, 2, jk)
+        res["hps_json"] = np.array(json.dumps({k: hps[k] for k in list(TINY) + ["n_lc_in",
+                                   "lc_upsample_strides", "lc_upsample_filt_sizes", "filter_sz",
+                                   "mfcc_win_sz", "mfcc_hop_sz", "bias"]}))
+        save(f"mi_tiny_{tag}.npz", **res)
+    # full width: keep only outputs (weights are regenerated from the seed by the tests)
+    hps = make_hps(n_win_batch=100)
+    res, m = run_mi(hps, 5, 2, "identity")
+    keep = dict(wav=res["wav"], mel=res["mel"], voice=res["voice"], jitter=res["jitter"],
+                loss=res["loss"], target=res["target"], pred_sub=res["pred"][:, :, ::9],
+                mel_grad=res["mel_grad"], seed=np.array(5))
+    # a few representative gradients (full tensors for small ones, slices for large)
+    for k in ("wavenet.post2.bias", "wavenet.post1.bias", "wavenet.base_layer.bias",
+              "wavenet.cond.speaker_embedding.weight", "wavenet.lc_conv.bias",
+              "wavenet.conv_layers.0.conv_signal.bias", "wavenet.conv_layers.19.conv_gate.bias",
+              "wavenet.lc_upsample.0.tconv.bias"):
+        keep["grad." + k] = res["grad." + k]
+    for k in ("wavenet.conv_layers.7.conv_signal.weight", "wavenet.conv_layers.12.dil_res.weight",
+              "wavenet.conv_layers.3.proj_gate.weight", "wavenet.conv_layers.19.dil_skp.weight",
+              "wavenet.lc_upsample.3.tconv.weight", "wavenet.base_layer.weight"):
+        keep["gradslice." + k] = res["grad." + k][:8, :8]
+    keep["param_names"] = np.array(json.dumps(
+        {k: list(v.shape) for k, v in m.named_parameters()}))
+    save("mi_full.npz", **keep)
+
+
+# ------------------------------------------------------------------------------------
+# C. autoencoder wiring on reference component modules
+# ------------------------------------------------------------------------------------
+def run_ae(hps, bn_type, enc_n_out, bn_n_out, n_embed, seed, B, jitter_kind, n_mel_ch=39,
+           anneal=0.3, free_nats=0.5):
+    torch.manual_seed(0)
+    mfcc_vc, enc, dec = build_ae_modules(hps, enc_n_out, n_mel_ch)
+    w = hps.n_win_batch
+    geo = ae_geometry(mfcc_vc, enc, dec, w)
+    if bn_type == "vqvae-ema":
+        bn = vqema_bn.VQEMA(n_in=enc_n_out, n_out=bn_n_out, vq_gamma=0.25, vq_ema_gamma=0.99,
+                            vq_n_embed=n_embed, training=True)
+        obj = vqema_bn.VQEMALoss(bn)
+    elif bn_type == "vqvae":
+        bn = vq_bn.VQ(n_in=enc_n_out, n_out=bn_n_out, vq_gamma=0.25, vq_n_embed=n_embed)
+        obj = None       # VQLoss references an undefined L2Error (C-8): terms captured below
+    elif bn_type == "vae":
+        bn = vae_bn.VAE(n_in=enc_n_out, n_out=bn_n_out)
+        obj = vae_bn.SGVBLoss(bn, free_nats=free_nats)
+        obj.update_anneal_weight(anneal)
+    elif bn_type == "ae":
+        bn = ae_bn.AE(n_in=enc_n_out, n_out=bn_n_out)
+        obj = ae_bn.AELoss(bn, 0.001)
+    dec.post_init(w)
+    dec.wav_cond_offset = geo["trim_dec_in"]                      # C-10
+    dec.trim_ups_out = torch.tensor(geo["trim_ups_out"])
+    mods = torch.nn.ModuleDict(dict(encoder=enc, bottleneck=bn, decoder=dec))
+    mods.train()
+    wts = load_np_weights(mods, seed)
+    bufs = {}
+    if bn_type in ("vqvae-ema",):
+        rs = np.random.RandomState(seed + 1)
+        emb = rs.uniform(-1, 1, size=(n_embed, bn_n_out)).astype(np.float32)
+        with torch.no_grad():
+            bn.emb.copy_(torch.from_numpy(emb))
+            bn.ema_numer = bn.emb * bn.ema_gamma_comp
+            bn.ema_denom = bn.n_sum_ones * bn.ema_gamma_comp
+        bufs["emb0"] = emb
+    g = torch.Generator().manual_seed(seed)
+    wav = torch.randint(0, hps.n_quant, (B, geo["enc_in_len"]), generator=g).float()
+    mel = torch.randn(B, n_mel_ch, geo["mel_len"], generator=g).requires_grad_(True)
+    voice = torch.randint(0, hps.n_speakers, (B,), generator=g)
+    ne = geo["embed_len"]
+    if jitter_kind == "identity":
+        jitter = torch.arange(ne).repeat(B, 1)
+    else:
+        rs = np.random.RandomState(seed)
+        j = np.arange(ne)[None, :] + rs.randint(-1, 2, size=(B, ne))
+        jitter = torch.from_numpy(np.clip(j, 0, ne - 1)).long()
+
+    eps = {}
+    if bn_type == "vae":
+        orig = torch.randn_like
+
+        def cap(x):
+            e = orig(x)
+            eps["eps"] = t2n(e)
+            return e
+        torch.randn_like = cap
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        encoding = enc(mel)
+        encoding_bn = bn(encoding)
+        quant = dec(wav, encoding_bn, voice, jitter)
+    if bn_type == "vae":
+        torch.randn_like = orig
+    wav_dec = wav[:, geo["trim_dec_in"][0]:geo["trim_dec_in"][1]]
+    wav_out = wav_dec[:, geo["trim_dec_out"][0]:geo["trim_dec_out"][1]]
+    pred, target = quant[..., :-1], wav_out[..., 1:]
+    res = dict(wav=t2n(wav), mel=t2n(mel), voice=t2n(voice), jitter=t2n(jitter),
+               encoding=t2n(encoding), encoding_bn=t2n(encoding_bn), pred=t2n(pred),
+               target=t2n(target), geo_json=np.array(json.dumps(geo)))
+    res.update(eps)
+    res.update(bufs)
+    res.update({"w." + k: v for k, v in wts.items()})
+    res["enc_frac_zero"] = np.array([float(enc.metrics[f"enc_az_{i}"]) for i in range(9)])
+
+    params = dict(mods.named_parameters())
+
+    def grads_of(loss, tag):
+        names = list(params)
+        gs = torch.autograd.grad(loss, [params[k] for k in names] + [mel, encoding_bn],
+                                 retain_graph=True, allow_unused=True)
+        for k, gr in zip(names + ["@mel", "@encoding_bn"], gs):
+            res[f"{tag}.{k}"] = t2n(gr) if gr is not None else np.zeros((0,), np.float32)
+
+    if bn_type == "vqvae-ema":
+        head = obj(pred, target)                                   # HEAD: commitment only (C-3)
+        res["loss_head"] = t2n(head)
+        rec_ts_n = pred.shape[0] * pred.shape[2]
+        com_n = bn.min_dist.numel()
+        intended = obj.metrics["rec"] * rec_ts_n + obj.metrics["com"] * com_n   # vqema_bn.py:244
+        res["loss_intended"] = t2n(intended)
+        grads_of(head, "ghead")
+        grads_of(intended, "gint")
+        for k in ("rec", "com", "min_ze", "max_ze", "min_emb", "max_emb", "hst_ent"):
+            res["metric." + k] = t2n(obj.metrics[k])
+        res["metric.nunq"] = np.array(obj.metrics["nunq"])
+        res.update(ze=t2n(bn.ze), min_ind=t2n(bn.min_ind), min_dist=t2n(bn.min_dist),
+                   z_sum=t2n(bn.z_sum), n_sum=t2n(bn.n_sum), ema_numer=t2n(bn.ema_numer),
+                   ema_denom=t2n(bn.ema_denom), ind_hist=t2n(bn.ind_hist))
+        bn.update_codebook()
+        res["emb1"] = t2n(bn.emb)
+    elif bn_type == "vqvae":
+        # the three documented terms (vq_bn.py:72-115, doc/loss_terms.txt); L2Error restated
+        # as the per-element squared error between sg(ze) and the selected code (README:45-46)
+        logp = torch.log_softmax(pred, 1)
+        rec = -torch.gather(logp, 1, target.long().unsqueeze(1))
+        com = bn.min_dist * bn.gamma
+        sel = bn.emb[bn_min_ind(bn)]                                # (B, N, d)
+        l2 = ((bn.ze.detach().permute(0, 2, 1) - sel) ** 2)
+        total = rec.sum() + l2.sum() + com.sum()
+        res["loss_intended"] = t2n(total)
+        res["emb0"] = t2n(bn.emb)
+        grads_of(total, "gint")
+        res.update(ze=t2n(bn.ze), min_ind=t2n(bn_min_ind(bn)), min_dist=t2n(bn.min_dist))
+    else:
+        loss = obj(pred, target)
+        res["loss"] = t2n(loss)
+        grads_of(loss, "g")
+        for k, v in obj.metrics.items():
+            res["metric." + k] = t2n(v)
+        if bn_type == "vae":
+            res.update(mu=t2n(bn.mu), sigma_sq=t2n(bn.sigma_sq), anneal=np.array(anneal),
+                       free_nats=np.array(free_nats))
+        else:
+            res["ze"] = t2n(bn.ze)
+    return res
+
+
+def bn_min_ind(bn):
+    # VQ does not keep min_ind; recover it the way VQ.forward does (vq_bn.py:39-40)
+    l2 = ((bn.ze.unsqueeze(1) - bn.emb.detach().unsqueeze(2)) ** 2).sum(dim=2)
+    return l2.min(dim=1)[1]
+
+
+def gen_ae():
+    base = dict(TINY, lc_upsample_strides=[5, 4, 4, 4])
+    for bn_type, jk in (("vqvae-ema", "random"), ("vqvae-ema", "identity"), ("vae", "random"),
+                        ("ae", "identity"), ("vqvae", "identity")):
+        hps = make_hps(**base, n_lc_in=6)
+        res = run_ae(hps, bn_type, enc_n_out=16, bn_n_out=6, n_embed=10, seed=23, B=2,
+                     jitter_kind=jk, n_mel_ch=9)
+        res["hps_json"] = np.array(json.dumps(dict(base, n_lc_in=6, enc_n_out=16, bn_type=bn_type,
+                                   bn_n_out=6, bn_vq_n_embed=10, n_mel_ch=9)))
+        save(f"ae_tiny_{bn_type}_{jk}.npz", **res)
+
+
+# ------------------------------------------------------------------------------------
+# D. full-width single modules (weights regenerated from seeds by the tests)
+# ------------------------------------------------------------------------------------
+def gen_full_modules():
+    # gated layer, full width, dil=4 (not final) and dil=2 (final)
+    hps = make_hps()
+    for tag, dil, final in (("mid", 4, False), ("final", 2, True)):
+        torch.manual_seed(0)
+        dummy_vc = {"beg_grcc": None, "end_grcc": None}
+        layer = wavenet.GatedResidualCondConv(dummy_vc, hps, n_cond=138, stride=1, dil=dil,
+                                              final_layer=final, parent_vc=None, name="g")
+        load_np_weights(layer, 31 + dil)
+        layer.register_buffer("leads", torch.tensor([5, 9, dil, 0]))
+        layer.set_full()
+        rs = np.random.RandomState(100 + dil)
+        T = 40
+        x = torch.from_numpy(rs.uniform(-1, 1, (2, 368, T)).astype(np.float32))
+        cond = torch.from_numpy(rs.uniform(-1, 1, (2, 138, T + 5)).astype(np.float32))
+        sig, skp = layer(x, cond)
+        save(f"gated_full_{tag}.npz", sig=t2n(sig), skp=t2n(skp), dil=np.array(dil),
+             seed=np.array(31 + dil), in_seed=np.array(100 + dil), leads=np.array([5, 9, dil, 0]))
+
+    # VQEMA full width
+    bn = vqema_bn.VQEMA(n_in=768, n_out=32, vq_gamma=0.25, vq_ema_gamma=0.99, vq_n_embed=4096,
+                        training=True)
+    load_np_weights(bn, 41)
+    rs = np.random.RandomState(42)
+    emb = (rs.standard_normal((4096, 32)) * 0.7).astype(np.float32)
+    with torch.no_grad():
+        bn.emb.copy_(torch.from_numpy(emb))
+        bn.ema_numer = bn.emb * bn.ema_gamma_comp
+        bn.ema_denom = bn.n_sum_ones * bn.ema_gamma_comp
+    z = torch.from_numpy((rs.standard_normal((2, 768, 29)) * 2.0).astype(np.float32))
+    with contextlib.redirect_stdout(io.StringIO()):
+        zq = bn(z)
+    snorm = vqema_bn.scaled_l2_norm(bn.ze.unsqueeze(1), bn.emb.unsqueeze(2).unsqueeze(0))
+    top2 = snorm.topk(2, dim=1, largest=False)[0]
+    res = dict(ze=t2n(bn.ze), min_ind=t2n(bn.min_ind), min_dist=t2n(bn.min_dist), zq=t2n(zq),
+               margin=t2n(top2[:, 1] - top2[:, 0]), z_sum_rows=t2n(bn.z_sum[bn.min_ind.flatten()]),
+               n_sum=t2n(bn.n_sum), ema_denom=t2n(bn.ema_denom),
+               ema_numer_rows=t2n(bn.ema_numer[bn.min_ind.flatten()]))
+    bn.update_codebook()
+    res["emb1_rows"] = t2n(bn.emb[bn.min_ind.flatten()])
+    # plain squared-L2 indices on the same data (vq_bn.py:39-40)
+    l2 = ((bn.ze.unsqueeze(1) - torch.from_numpy(emb).unsqueeze(2)) ** 2).sum(dim=2)
+    md, mi = l2.min(dim=1)
+    res.update(l2_min_ind=t2n(mi), l2_min_dist=t2n(md), w_seed=np.array(41), in_seed=np.array(42))
+    save("vqema_full.npz", **res)
+
+    # encoder full width
+    enc = wave_encoder.Encoder(n_in=39, n_out=768, parent_vc=None)
+    load_np_weights(enc, 51)
+    rs = np.random.RandomState(52)
+    mel = torch.from_numpy(rs.standard_normal((2, 39, 30)).astype(np.float32))
+    out = enc(mel)
+    save("encoder_full.npz", out=t2n(out), w_seed=np.array(51), in_seed=np.array(52),
+         frac_zero=np.array([float(enc.metrics[f"enc_az_{i}"]) for i in range(9)]))
+
+    # upsampler + LC conv full width
+    hps = make_hps(lc_upsample_strides=[5, 4, 4, 4], n_lc_in=32)
+    torch.manual_seed(0)
+    wn = wavenet.WaveNet(hps, parent_vc=None)
+    load_np_weights(wn, 61)
+    rs = np.random.RandomState(62)
+    lc = torch.from_numpy(rs.standard_normal((2, 32, 7)).astype(np.float32))
+    y = wn.lc_upsample(wn.lc_conv(lc))
+    save("lc_upsample_full.npz", out_sub=t2n(y)[:, ::5, :], out_len=np.array(y.shape[2]),
+         w_seed=np.array(61), in_seed=np.array(62))
+
+    # losses
+    rs = np.random.RandomState(71)
+    pred = torch.from_numpy((rs.standard_normal((3, 256, 50)) * 2).astype(np.float32)).requires_grad_(True)
+    tgt = torch.from_numpy(rs.randint(0, 256, (3, 50)).astype(np.float32))
+    rl = wavenet.RecLoss()
+    loss = rl(pred, tgt)
+    gp, = torch.autograd.grad(loss, pred)
+    save("recloss.npz", pred=t2n(pred), target=t2n(tgt), loss=t2n(loss), grad=t2n(gp))
+
+
+def main():
+    which = sys.argv[1:] or ["geometry", "mi", "ae", "full"]
+    if "geometry" in which:
+        gen_geometry()
+    if "mi" in which:
+        gen_mi()
+    if "ae" in which:
+        gen_ae()
+    if "full" in which:
+        gen_full_modules()
+
+
+if __name__ == "__main__":
+    main()
