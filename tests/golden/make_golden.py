@@ -78,21 +78,8 @@ mfcc_inverter.mfcc.ProcessWav = _MfccStub
 # ------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------
-def np_weights(shapes, seed, scale=None):
-    """Deterministic weights from numpy's legacy RandomState (stable across versions):
-    uniform(-a, a) with Xavier bound per tensor unless `scale` given; 1-D tensors get
-    small non-zero values so bias paths are exercised."""
-    rs = np.random.RandomState(seed)
-    out = {}
-    for k in sorted(shapes):
-        shp = tuple(shapes[k])
-        if len(shp) >= 2:
-            rf = int(np.prod(shp[2:])) if len(shp) > 2 else 1
-            bound = scale if scale is not None else float(np.sqrt(6.0 / ((shp[0] + shp[1]) * rf)))
-        else:
-            bound = 0.1
-        out[k] = rs.uniform(-bound, bound, size=shp).astype(np.float32)
-    return out
+sys.path.insert(0, HERE)
+from weights import np_weights    # noqa: E402
 
 
 def load_np_weights(module, seed, skip=()):
@@ -309,14 +296,12 @@ def run_mi(hps, seed, B, jitter_kind):
         j = np.arange(n_mel)[None, :] + rs.randint(-1, 2, size=(B, n_mel))
         jitter = torch.from_numpy(np.clip(j, 0, n_mel - 1)).long()
     pred, target, loss = m.run(wav, mel, voice, jitter)
+    sd, mean = t2n(m.objective.metrics["mel_grad_sd"]), t2n(m.objective.metrics["mel_grad_mean"])
     loss.backward()
     grads = {"grad." + k: t2n(p.grad) for k, p in m.named_parameters()}
-    mel_grad = torch.autograd.grad(
-        m.objective(*(lambda q: (q[..., :-1], target))(m.forward(wav, mel, voice, jitter))), mel)[0]
     res = dict(wav=t2n(wav), mel=t2n(mel), voice=t2n(voice), jitter=t2n(jitter),
-               pred=t2n(pred), target=t2n(target), loss=t2n(loss), mel_grad=t2n(mel_grad),
-               mel_grad_sd=t2n(m.objective.metrics["mel_grad_sd"]),
-               mel_grad_mean=t2n(m.objective.metrics["mel_grad_mean"]))
+               pred=t2n(pred), target=t2n(target), loss=t2n(loss), mel_grad=t2n(mel.grad),
+               mel_grad_sd=sd, mel_grad_mean=mean)
     res.update({"w." + k: v for k, v in w.items()})
     res.update(grads)
     return res, m
@@ -407,7 +392,7 @@ def run_ae(hps, bn_type, enc_n_out, bn_n_out, n_embed, seed, B, jitter_kind, n_m
 
         def cap(x):
             e = orig(x)
-            eps["eps"] = t2n(e)
+            eps["eps"] = t2n(e).copy()      # the reference mutates it in place (vae_bn.py:52-53)
             return e
         torch.randn_like = cap
     sink = io.StringIO()
@@ -516,7 +501,7 @@ def gen_full_modules():
         rs = np.random.RandomState(100 + dil)
         T = 40
         x = torch.from_numpy(rs.uniform(-1, 1, (2, 368, T)).astype(np.float32))
-        cond = torch.from_numpy(rs.uniform(-1, 1, (2, 138, T + 5)).astype(np.float32))
+        cond = torch.from_numpy(rs.uniform(-1, 1, (2, 138, T - dil + 5)).astype(np.float32))
         sig, skp = layer(x, cond)
         save(f"gated_full_{tag}.npz", sig=t2n(sig), skp=t2n(skp), dil=np.array(dil),
              seed=np.array(31 + dil), in_seed=np.array(100 + dil), leads=np.array([5, 9, dil, 0]))
