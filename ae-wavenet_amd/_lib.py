@@ -1,0 +1,224 @@
+"""ctypes binding of the C ABI in include/aewavenet.h.
+
+The structures below mirror the header field-for-field; `load()` checks their sizes against
+`aew_sizeof()` so a drifted mirror fails loudly.  There is no CPU fallback: if the shared
+library is missing, `load()` raises and nothing in the product path can run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_SEGS = 32
+BF16, F32 = 0, 1
+
+E_ARG, E_UNSUP, E_ALIGN = -1, -2, -3
+
+EPI_STORE, EPI_GATED, EPI_RES_SKIP, EPI_DFG = 0, 1, 2, 3
+EF_BIAS, EF_RELU, EF_OUT1_PRE, EF_ADD_AUX0 = 1 << 0, 1 << 1, 1 << 2, 1 << 3
+EF_MUL_POS1, EF_OUT1_POS1, EF_ACCUM, EF_OUT2_RELU, EF_COUNT_ZERO = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
+
+(OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
+ OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM) = range(1, 20)
+
+vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", vp), ("batch_stride", i64), ("row_pitch", i32), ("row_step", i32),
+                ("row_off", i32), ("row_lo", i32), ("row_hi", i32), ("k_len", i32)]
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", vp), ("batch_stride", i64), ("row_pitch", i32), ("row_step", i32),
+                ("row_off", i32), ("row_lo", i32), ("row_hi", i32), ("dtype", i32)]
+
+
+class GemmNT(C.Structure):
+    _fields_ = [("dtype", i32), ("impl", i32), ("M", i32), ("N", i32), ("N_pad", i32),
+                ("batch", i32), ("n_segs", i32), ("K_total", i32), ("seg", Seg * MAX_SEGS),
+                ("W", vp), ("epi", i32), ("flags", u32), ("out0", View), ("out1", View),
+                ("out2", View), ("aux0", View), ("aux1", View), ("bias", vp), ("bias_bs", i64),
+                ("n_split", i32), ("reserved", i32), ("counter", vp)]
+
+
+class GemmTN(C.Structure):
+    _fields_ = [("dtype", i32), ("impl", i32), ("Mc", i32), ("batch", i32), ("N", i32),
+                ("N_pad", i32), ("g", Seg), ("n_segs", i32), ("K_total", i32),
+                ("seg", Seg * MAX_SEGS), ("out", vp), ("out_batch_stride", i64)]
+
+
+class CopyRec(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("dims", i32 * 4), ("ss", i64 * 4), ("ds", i64 * 4),
+                ("src_dtype", i32), ("dst_dtype", i32), ("red_n", i32), ("accumulate", i32),
+                ("red_stride", i64), ("scale", f32), ("first_block", i32)]
+
+
+class CopyTable(C.Structure):
+    _fields_ = [("recs", vp), ("block_rec", vp), ("n_blocks", i32), ("n_recs", i32)]
+
+
+class VqNearest(C.Structure):
+    _fields_ = [("ze", vp), ("emb", vp), ("Q", i32), ("K", i32), ("d", i32), ("d_pitch", i32),
+                ("metric", i32), ("ind", vp), ("dist", vp), ("zq", vp)]
+
+
+class VqStats(C.Structure):
+    _fields_ = [("ze", vp), ("ind", vp), ("Q", i32), ("K", i32), ("d", i32), ("d_pitch", i32),
+                ("z_sum", vp), ("n_sum", vp), ("hist", vp)]
+
+
+class VqEma(C.Structure):
+    _fields_ = [("numer", vp), ("denom", vp), ("z_sum", vp), ("n_sum", vp), ("emb", vp),
+                ("K", i32), ("d", i32), ("update_codebook", i32), ("gamma", f32),
+                ("gamma_comp", f32)]
+
+
+class VqBwd(C.Structure):
+    _fields_ = [("ze", vp), ("emb", vp), ("ind", vp), ("dzq", vp), ("Q", i32), ("d", i32),
+                ("d_pitch", i32), ("metric", i32), ("coef", f32), ("demb_coef", f32),
+                ("dze", vp), ("demb", vp)]
+
+
+class LcGather(C.Structure):
+    _fields_ = [("src", vp), ("src_bs", i64), ("src_pitch", i32), ("jitter", vp),
+                ("jit_pitch", i32), ("dst", vp), ("dst_bs", i64), ("dst_pitch", i32),
+                ("B", i32), ("N", i32), ("C", i32), ("C_pad", i32), ("take_compat", i32)]
+
+
+class LcScatter(C.Structure):
+    _fields_ = [("d", vp), ("d_bs", i64), ("d_pitch", i32), ("jitter", vp), ("jit_pitch", i32),
+                ("dsrc", vp), ("dsrc_bs", i64), ("dsrc_pitch", i32), ("B", i32), ("N", i32),
+                ("C", i32), ("take_compat", i32)]
+
+
+class SpkBias(C.Structure):
+    _fields_ = [("params", vp), ("voice", vp), ("off_bias_sig", vp), ("off_bias_gate", vp),
+                ("off_proj_sig", vp), ("off_proj_gate", vp), ("off_spk_w", i64),
+                ("off_spk_b", i64), ("B", i32), ("L", i32), ("D", i32), ("D_pad", i32),
+                ("C_lc", i32), ("G", i32), ("n_speakers", i32), ("bias", vp), ("gc", vp)]
+
+
+class SpkBwd(C.Structure):
+    _fields_ = [("params", vp), ("voice", vp), ("off_bias_sig", vp), ("off_bias_gate", vp),
+                ("off_proj_sig", vp), ("off_proj_gate", vp), ("off_spk_w", i64),
+                ("off_spk_b", i64), ("B", i32), ("L", i32), ("D", i32), ("D_pad", i32),
+                ("C_lc", i32), ("G", i32), ("n_speakers", i32), ("colsum", vp), ("gc", vp),
+                ("grads", vp)]
+
+
+class BaseGather(C.Structure):
+    _fields_ = [("wav", vp), ("wav_pitch", i32), ("wav_off", i32), ("W", vp), ("bias", vp),
+                ("B", i32), ("T", i32), ("R", i32), ("R_pad", i32), ("Q", i32), ("x", vp),
+                ("x_bs", i64), ("x_pitch", i32), ("onehot", vp), ("oh_bs", i64),
+                ("oh_pitch", i32), ("Q_pad", i32)]
+
+
+class SoftmaxNll(C.Structure):
+    _fields_ = [("logits", vp), ("bs", i64), ("pitch", i32), ("wav", vp), ("wav_pitch", i32),
+                ("tgt_off", i32), ("B", i32), ("w", i32), ("Q", i32), ("Q_pad", i32),
+                ("nll", vp), ("ptgt", vp), ("dlogits", vp), ("dl_bs", i64), ("dl_pitch", i32),
+                ("scale", f32), ("backward", i32)]
+
+
+class Colsum(C.Structure):
+    _fields_ = [("x", Seg), ("dtype", i32), ("M", i32), ("N", i32), ("batch", i32),
+                ("out", vp), ("out_bs", i64), ("accumulate", i32)]
+
+
+class Reduce(C.Structure):
+    _fields_ = [("x", vp * 4), ("n", i32 * 4), ("scale", f32 * 4), ("clamp", i32 * 4),
+                ("clamp_min", f32 * 4), ("post_scale", f32 * 4), ("n_terms", i32), ("out", vp)]
+
+
+class Adam(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("lr", f32),
+                ("beta1", f32), ("beta2", f32), ("eps", f32), ("bc1", f32), ("bc2", f32),
+                ("grad_scale", f32)]
+
+
+class Zero(C.Structure):
+    _fields_ = [("ptr", vp), ("bytes", i64)]
+
+
+class Vae(C.Structure):
+    _fields_ = [("lin", vp), ("lin_pitch", i32), ("eps", vp), ("Q", i32), ("d", i32),
+                ("d_pitch", i32), ("sample", vp), ("kl_terms", vp), ("dsample", vp),
+                ("kl_coef", f32), ("kl_value", vp), ("free_nats", f32), ("dlin", vp),
+                ("backward", i32)]
+
+
+class AeNorm(C.Structure):
+    _fields_ = [("ze", vp), ("Q", i32), ("d", i32), ("d_pitch", i32), ("term", vp),
+                ("dze_in", vp), ("coef", f32), ("dze", vp), ("backward", i32)]
+
+
+class _OpU(C.Union):
+    _fields_ = [("nt", GemmNT), ("tn", GemmTN), ("copy", CopyTable), ("vqn", VqNearest),
+                ("vqs", VqStats), ("vqe", VqEma), ("vqb", VqBwd), ("lcg", LcGather),
+                ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
+                ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
+                ("zero", Zero), ("vae", Vae), ("aen", AeNorm)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("tag", i32), ("u", _OpU)]
+
+
+OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEAREST: "vqn",
+            OP_VQ_STATS: "vqs", OP_VQ_EMA: "vqe", OP_VQ_BWD: "vqb", OP_LC_GATHER: "lcg",
+            OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
+            OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
+            OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen"}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaewavenet_hip.so")
+_lib = None
+
+
+class AewError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libaewavenet_hip.so (built by __graft_entry__.build()).  Raises if it is missing
+    or if the struct mirrors above have drifted from the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AewError(f"HIP extension not built: {LIB_PATH} is missing "
+                       "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                       "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.aew_strerror.restype = C.c_char_p
+    lib.aew_run_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    lib.aew_timing_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.aew_selftest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.aew_tn_slabs.argtypes = [C.c_void_p]
+    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec)):
+        want = lib.aew_sizeof(which)
+        if want != C.sizeof(cls):
+            raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
+                           f"{want} in the library")
+    if lib.aew_abi_version() != 1:
+        raise AewError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what="aew call", fail_index=None):
+    if rc != 0:
+        msg = load().aew_strerror(rc).decode()
+        at = f" at op {fail_index}" if fail_index is not None else ""
+        raise AewError(f"{what} failed{at}: rc={rc} ({msg})")
+
+
+def tn_slabs(tn: GemmTN) -> int:
+    """Number of fp32 partial slabs a TN op writes (host-side mirror is the library itself so
+    the split heuristic has a single definition)."""
+    return load().aew_tn_slabs(C.byref(tn))
+
+
+EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
+           "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe")

@@ -1,0 +1,725 @@
+// aew_gemm.hip — multi-segment row-affine GEMMs on CDNA4 matrix cores (gfx950).
+//
+//   NT:  C[b][m][n]        = sum_s sum_k A_s[b][m*step_s+off_s][k] * W[n][K_s+k]    (fwd, dgrad)
+//   TN:  dW[slab][n][K_s+k] = sum_m G[b][m*gs+go][n] * A_s[b][m*step_s+off_s][k]     (wgrad)
+//
+// Replaces every conv1d / conv_transpose1d / linear call on the reference's training path
+// (wavenet.py:100-109,154,337,351,359-360; wave_encoder.py:39; vqema_bn.py:131) and their
+// autograd backward.  Operand tiles are staged global->LDS with 16-byte LDS-DMA, swizzled on
+// the source address; bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses v_mfma_f32_16x16x4_f32
+// (an exact k-ordered fmaf chain, which is what makes the encoder->VQ path bit-exact against
+// oracle/exact_chain.c).  MFMA operands are issued "swapped" (weights as the A operand) so a
+// lane's 4 accumulator registers are 4 consecutive CHANNELS of one row: channels-last stores
+// are then 8/16-byte vectors.
+#include "aew_common.h"
+
+// =============================================================================================
+// epilogues (operate on 4 consecutive channels n..n+3 of row m; shared by MFMA and check kernels)
+// =============================================================================================
+__device__ __forceinline__ void epi_store4(const aew_gemm_nt_t& g, int b, int m, int n, float v[4],
+                                           unsigned& zero_count) {
+    const unsigned fl = g.flags;
+    if (fl & AEW_EF_BIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.bias + (int64_t)b * g.bias_bs + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (fl & AEW_EF_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    if (fl & AEW_EF_OUT1_PRE) view_store4(g.out1, b, m, n, v);
+    if (fl & AEW_EF_ADD_AUX0) {
+        float a[4];
+        view_load4(g.aux0, b, m, n, a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] + a[r];
+    }
+    if (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)) {
+        float a[4], w[4];
+        view_load4(g.aux1, b, m, n, a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = a[r] > 0.f ? v[r] : 0.f;
+        if (fl & AEW_EF_OUT1_POS1) view_store4(g.out1, b, m, n, w);
+        if (fl & AEW_EF_MUL_POS1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = w[r];
+        }
+    }
+    if (fl & AEW_EF_COUNT_ZERO) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zero_count += (n + r < g.N && v[r] == 0.f) ? 1u : 0u;
+    }
+    view_store4(g.out0, b, m, n, v);
+}
+
+// filt/gate quads of the same 4 channels `ch`
+__device__ __forceinline__ void epi_gated4(const aew_gemm_nt_t& g, int b, int m, int np_f, int ch,
+                                           float f[4], float gt[4]) {
+    const float* bias = g.bias + (int64_t)b * g.bias_bs;
+    const float4 bf = *reinterpret_cast<const float4*>(bias + np_f);
+    const float4 bg = *reinterpret_cast<const float4*>(bias + np_f + 16);
+    float a[4], s[4], z[4], pf[4], pg[4];
+    a[0] = tanh_f(f[0] + bf.x); a[1] = tanh_f(f[1] + bf.y); a[2] = tanh_f(f[2] + bf.z); a[3] = tanh_f(f[3] + bf.w);
+    s[0] = sigmoid_f(gt[0] + bg.x); s[1] = sigmoid_f(gt[1] + bg.y);
+    s[2] = sigmoid_f(gt[2] + bg.z); s[3] = sigmoid_f(gt[3] + bg.w);
+    // store z and the two local derivatives dz/dfilt, dz/dgate (computed in fp32, so the
+    // saturated-tanh factor 1-a^2 does not suffer bf16 cancellation in backward)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        z[r] = a[r] * s[r];
+        pf[r] = s[r] * (1.0f - a[r] * a[r]);
+        pg[r] = z[r] * (1.0f - s[r]);
+    }
+    view_store4(g.out0, b, m, ch, z);
+    view_store4(g.out1, b, m, ch, pf);
+    view_store4(g.out2, b, m, ch, pg);
+}
+
+__device__ __forceinline__ void epi_res_skip4(const aew_gemm_nt_t& g, int b, int m, int n, float v[4]) {
+    if (n < g.n_split) {
+        float a[4];
+        view_load4(g.aux0, b, m, n, a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += a[r];
+        view_store4(g.out0, b, m, n, v);
+    } else {
+        const int c = n - g.n_split;
+        int64_t row;
+        if (!view_row(g.out1, m, row)) return;
+        if (g.flags & AEW_EF_ACCUM) {
+            float a[4];
+            view_load4(g.out1, b, m, c, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += a[r];
+        }
+        view_store4(g.out1, b, m, c, v);
+        if (g.flags & AEW_EF_OUT2_RELU) {
+            float w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = v[r] > 0.f ? v[r] : 0.f;
+            view_store4(g.out2, b, m, c, w);
+        }
+    }
+}
+
+__device__ __forceinline__ void epi_dfg4(const aew_gemm_nt_t& g, int b, int m, int n, const float dz[4]) {
+    float pf[4], pg[4], df[4], dg[4];
+    view_load4(g.aux0, b, m, n, pf);
+    view_load4(g.aux1, b, m, n, pg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        df[r] = dz[r] * pf[r];
+        dg[r] = dz[r] * pg[r];
+    }
+    const int np = (n >> 4) * 32 + (n & 15);
+    view_store4(g.out0, b, m, np, df);
+    view_store4(g.out0, b, m, np + 16, dg);
+}
+
+// =============================================================================================
+// segment iterator: walks K tiles across the segment table in order
+// =============================================================================================
+struct KIter {
+    int seg, kin, kglob;
+    __device__ __forceinline__ void init() { seg = 0; kin = 0; kglob = 0; }
+    __device__ __forceinline__ void advance(const aew_seg_t* segs, int bk) {
+        kin += bk; kglob += bk;
+        if (kin >= segs[seg].k_len) { ++seg; kin = 0; }
+    }
+};
+
+// =============================================================================================
+// NT kernel, bf16:  block tile 128 (rows m) x 128 (channels n), BK = 64, 4 waves as 2(n) x 2(m)
+// =============================================================================================
+#define NT_BM 128
+#define NT_BN 128
+#define NT_BK 64
+#define NT_ROWB 128                                 // bytes per staged row (64 bf16)
+#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 32 KiB
+
+__device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, int m, int esize) {
+    const int64_t row = (int64_t)m * s.row_step + s.row_off;
+    if (row < s.row_lo || row >= s.row_hi) return nullptr;
+    return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
+}
+
+// issue one K tile (X rows then W rows) into LDS stage `stage`
+__device__ __forceinline__ void nt_issue_bf16(const aew_gemm_nt_t& g, char* stage, int b, int m0, int n0,
+                                              const KIter& it, int wave, int lane) {
+    const aew_seg_t& s = g.seg[it.seg];
+    const int lr = lane >> 3, pc = lane & 7;
+    // X: 128 rows = 16 pieces of 8 rows; wave w takes pieces w*4 .. w*4+3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + lr;
+        const int c = nt_swz(r, pc);
+        const char* src = seg_row_ptr(s, b, m0 + r, 2);
+        src = src ? src + (it.kin + c * 8) * 2 : reinterpret_cast<const char*>(aew_zero_page);
+        glds16(src, stage + (wave * 4 + j) * 1024);
+    }
+    const char* wbase = reinterpret_cast<const char*>(g.W);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + lr;
+        const int c = nt_swz(r, pc);
+        const char* src = wbase + ((int64_t)(n0 + r) * g.K_total + it.kglob + c * 8) * 2;
+        glds16(src, stage + NT_BM * NT_ROWB + (wave * 4 + j) * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int m0 = blockIdx.x * NT_BM, n0 = blockIdx.y * NT_BN, b = blockIdx.z;
+    // RES_SKIP: skip-part tiles that lie entirely before the skip window do nothing
+    if (g.epi == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
+        const int64_t last = (int64_t)(min(m0 + NT_BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
+        if (last < g.out1.row_lo) return;
+    }
+    const int nkt = g.K_total / NT_BK;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    KIter it; it.init();
+    nt_issue_bf16(g, smem, b, m0, n0, it, wave, lane);
+    const int fi = lane & 15, fg = lane >> 4;
+    for (int t = 0; t < nkt; ++t) {
+        wait_vm0();
+        __syncthreads();
+        if (t + 1 < nkt) {
+            it.advance(g.seg, NT_BK);
+            nt_issue_bf16(g, smem + ((t + 1) & 1) * NT_STAGE_BYTES, b, m0, n0, it, wave, lane);
+        }
+        const char* xs = smem + (t & 1) * NT_STAGE_BYTES;
+        const char* ws = xs + NT_BM * NT_ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wn * 64 + i * 16 + fi;
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(ws + r * NT_ROWB + (nt_swz(r, kk * 4 + fg) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wm * 64 + j * 16 + fi;
+                xf[j] = *reinterpret_cast<const bf16x8_t*>(xs + r * NT_ROWB + (nt_swz(r, kk * 4 + fg) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: acc[i][j][r] = C[m = m0+wm*64+j*16+fi][n = n0+wn*64+i*16+4*fg+r]
+    unsigned zc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fi;
+        if (m >= g.M) continue;
+        if (g.epi == AEW_EPI_GATED) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int np_f = n0 + wn * 64 + p * 32 + 4 * fg;          // packed column of the filt quad
+                const int ch = (np_f >> 5) * 16 + 4 * fg;
+                if (ch >= g.N) continue;
+                float f[4] = {acc[2 * p][j][0], acc[2 * p][j][1], acc[2 * p][j][2], acc[2 * p][j][3]};
+                float q[4] = {acc[2 * p + 1][j][0], acc[2 * p + 1][j][1], acc[2 * p + 1][j][2], acc[2 * p + 1][j][3]};
+                epi_gated4(g, b, m, np_f, ch, f, q);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + i * 16 + 4 * fg;
+                if (n >= g.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (g.epi == AEW_EPI_STORE) epi_store4(g, b, m, n, v, zc);
+                else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip4(g, b, m, n, v);
+                else epi_dfg4(g, b, m, n, v);
+            }
+        }
+    }
+    if ((g.flags & AEW_EF_COUNT_ZERO) && g.epi == AEW_EPI_STORE) {
+        zc = (unsigned)wave_sum((float)zc);
+        if (lane == 0 && zc) atomicAdd(g.counter, (unsigned long long)zc);
+    }
+}
+
+// =============================================================================================
+// NT kernel, fp32 (exact fmaf chain): block tile 32 (rows m) x 64 (channels n), BK = 32 floats,
+// 4 waves each 16 channels x 32 rows.  One accumulator per output, K strictly ascending.
+// =============================================================================================
+#define NF_BM 32
+#define NF_BN 64
+#define NF_BK 32
+#define NF_STAGE_BYTES ((NF_BM + NF_BN) * 128)      // 12 KiB
+
+__device__ __forceinline__ void nt_issue_f32(const aew_gemm_nt_t& g, char* stage, int b, int m0, int n0,
+                                             const KIter& it, int wave, int lane) {
+    const aew_seg_t& s = g.seg[it.seg];
+    const int lr = lane >> 3, pc = lane & 7;
+    // 96 rows = 12 pieces of 8 rows: pieces 0..3 = X, 4..11 = W; wave w takes pieces w, w+4, w+8
+    {
+        const int r = wave * 8 + lr;
+        const int c = nt_swz(r, pc);
+        const char* src = seg_row_ptr(s, b, m0 + r, 4);
+        src = src ? src + (it.kin + c * 4) * 4 : reinterpret_cast<const char*>(aew_zero_page);
+        glds16(src, stage + wave * 1024);
+    }
+    const char* wbase = reinterpret_cast<const char*>(g.W);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 4 * j) * 8 + lr;
+        const int c = nt_swz(r, pc);
+        const char* src = wbase + ((int64_t)(n0 + r) * g.K_total + it.kglob + c * 4) * 4;
+        glds16(src, stage + NF_BM * 128 + (wave + 4 * j) * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * NF_BM, n0 = blockIdx.y * NF_BN, b = blockIdx.z;
+    const int nkt = g.K_total / NF_BK;
+    f32x4_t acc[2];
+    acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    KIter it; it.init();
+    nt_issue_f32(g, smem, b, m0, n0, it, wave, lane);
+    const int fi = lane & 15, kq = lane >> 4;
+    for (int t = 0; t < nkt; ++t) {
+        wait_vm0();
+        __syncthreads();
+        if (t + 1 < nkt) {
+            it.advance(g.seg, NF_BK);
+            nt_issue_f32(g, smem + ((t + 1) & 1) * NF_STAGE_BYTES, b, m0, n0, it, wave, lane);
+        }
+        const char* xs = smem + (t & 1) * NF_STAGE_BYTES;
+        const char* ws = xs + NF_BM * 128;
+        const int rw = wave * 16 + fi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float wv = *reinterpret_cast<const float*>(ws + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rx = j * 16 + fi;
+                const float xv = *reinterpret_cast<const float*>(xs + rx * 128 + (nt_swz(rx, ks) << 4) + kq * 4);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    unsigned zc = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + j * 16 + fi;
+        const int n = n0 + wave * 16 + 4 * kq;
+        if (m >= g.M || n >= g.N) continue;
+        float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        epi_store4(g, b, m, n, v, zc);
+    }
+    if (g.flags & AEW_EF_COUNT_ZERO) {
+        zc = (unsigned)wave_sum((float)zc);
+        if (lane == 0 && zc) atomicAdd(g.counter, (unsigned long long)zc);
+    }
+}
+
+// =============================================================================================
+// NT check kernel (impl = 1): one thread per (m, channel quad); same operands, same epilogues,
+// plain fp32 fmaf chain in ascending k.  Used by the tests to isolate MFMA-path bugs.
+// =============================================================================================
+template <typename T>
+__device__ __forceinline__ float ld_elem(const T* p);
+template <> __device__ __forceinline__ float ld_elem<uint16_t>(const uint16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ld_elem<float>(const float* p) { return *p; }
+
+template <typename T>
+__global__ void k_gemm_nt_check(const aew_gemm_nt_t g) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;        // quad index along N_pad
+    const int m = blockIdx.y, b = blockIdx.z;
+    const int nq_total = (g.epi == AEW_EPI_GATED) ? g.N_pad / 8 : g.N_pad / 4;
+    if (q >= nq_total) return;
+    const T* W = reinterpret_cast<const T*>(g.W);
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    int n_f, n_g = 0, ch = 0;
+    if (g.epi == AEW_EPI_GATED) {
+        // quad q of channels -> packed filt columns and gate columns
+        ch = q * 4;
+        n_f = (ch >> 4) * 32 + (ch & 15);
+        n_g = n_f + 16;
+    } else {
+        n_f = q * 4;
+    }
+    int kglob = 0;
+    for (int s = 0; s < g.n_segs; ++s) {
+        const aew_seg_t& sg = g.seg[s];
+        const int64_t row = (int64_t)m * sg.row_step + sg.row_off;
+        const bool ok = row >= sg.row_lo && row < sg.row_hi;
+        const T* xr = reinterpret_cast<const T*>(sg.ptr) + (int64_t)b * sg.batch_stride + row * sg.row_pitch;
+        for (int k = 0; k < sg.k_len; ++k) {
+            const float xv = ok ? ld_elem<T>(xr + k) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a0[r] = fmaf(ld_elem<T>(W + (int64_t)(n_f + r) * g.K_total + kglob + k), xv, a0[r]);
+                if (g.epi == AEW_EPI_GATED)
+                    a1[r] = fmaf(ld_elem<T>(W + (int64_t)(n_g + r) * g.K_total + kglob + k), xv, a1[r]);
+            }
+        }
+        kglob += sg.k_len;
+    }
+    unsigned zc = 0;
+    if (g.epi == AEW_EPI_GATED) { if (ch < g.N) epi_gated4(g, b, m, n_f, ch, a0, a1); }
+    else if (n_f < g.N) {
+        if (g.epi == AEW_EPI_STORE) epi_store4(g, b, m, n_f, a0, zc);
+        else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip4(g, b, m, n_f, a0);
+        else epi_dfg4(g, b, m, n_f, a0);
+    }
+    if ((g.flags & AEW_EF_COUNT_ZERO) && zc) atomicAdd(g.counter, (unsigned long long)zc);
+}
+
+// =============================================================================================
+// TN kernel, bf16: out tile 128 (k cols of A-seg) x 128 (n cols of G); contraction staged 64
+// rows at a time; fragments via ds_read_b64_tr_b16 (hardware 4x4 transpose).
+// acc[ki][ni][r] = dW[n = n0+wn*64+ni*16+q][k = k0+wk*64+ki*16+4g+r]
+// =============================================================================================
+#define TN_BT 128
+#define TN_RC 64                                    // contraction rows per stage
+#define TN_STAGE_BYTES (2 * TN_RC * 256)            // 32 KiB
+
+struct TnTile { int seg, kin, koff; };              // which segment / column offset this block owns
+
+__device__ __forceinline__ TnTile tn_locate(const aew_gemm_tn_t& g, int kt, int tile) {
+    // kt-th tile of `tile` columns along the concatenated K axis
+    TnTile t; t.seg = 0; t.koff = kt * tile; t.kin = t.koff;
+    while (t.kin >= g.seg[t.seg].k_len) { t.kin -= g.seg[t.seg].k_len; ++t.seg; }
+    return t;
+}
+
+template <int ESIZE>
+__device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, char* stage, int b, int r0, int r_end,
+                                         int n0, const TnTile& tt, int wave, int lane) {
+    // stage layout: G rows [0,TN_RC) then A rows [0,TN_RC), 256-byte rows (16 chunks)
+    const int lr = lane >> 4, pc = lane & 15;
+    const aew_seg_t& sa = g.seg[tt.seg];
+    constexpr int EPC = 16 / ESIZE;                 // elements per chunk
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 4 + lr;      // 16 pieces of 4 rows per operand
+        const int c = ESIZE == 2 ? tn_swz_bf16(r, pc) : tn_swz_f32(r, pc);
+        const int m = r0 + r;
+        const char* sg = (m < r_end) ? seg_row_ptr(g.g, b, m, ESIZE) : nullptr;
+        sg = sg ? sg + (n0 + c * EPC) * ESIZE : reinterpret_cast<const char*>(aew_zero_page);
+        glds16(sg, stage + (wave * 4 + j) * 1024);
+        const char* sp = (m < r_end) ? seg_row_ptr(sa, b, m, ESIZE) : nullptr;
+        sp = sp ? sp + (tt.kin + c * EPC) * ESIZE : reinterpret_cast<const char*>(aew_zero_page);
+        glds16(sp, stage + TN_RC * 256 + (wave * 4 + j) * 1024);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c0, int lane, int safe) {
+    // operand fragment for columns c0..c0+15, contraction rows r0..r0+31 of a [rows][128] bf16 tile
+    const int q = lane & 15, gq = lane >> 4;
+    s16x8_t out;
+    if (!safe) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = r0 + 8 * gq + 4 * h + (q >> 2);
+            const int col = c0 + 4 * (q & 3);
+            const int chunk = tn_swz_bf16(row, col >> 3);
+            const char* p = tile + row * 256 + (chunk << 4) + ((col & 7) << 1);
+            const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4_t __attribute__((address_space(3)))*)AEW_LDS_PTR(p));
+            out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
+        }
+    } else {
+        // scalar gather with the same result layout (fallback if the transpose read misbehaves)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = r0 + 8 * gq + e;
+            const int col = c0 + q;
+            const int chunk = tn_swz_bf16(row, col >> 3);
+            out[e] = *reinterpret_cast<const short*>(tile + row * 256 + (chunk << 4) + ((col & 7) << 1));
+        }
+    }
+    return __builtin_bit_cast(bf16x8_t, out);
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits, int rows_per_split,
+                                                         int fold_batch, int safe) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    const int nkt = g.K_total / TN_BT;
+    const int kt = blockIdx.x % nkt, nt = blockIdx.x / nkt;
+    const int n0 = nt * TN_BT;
+    const int sp = blockIdx.y;
+    const TnTile tt = tn_locate(g, kt, TN_BT);
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int b_lo = fold_batch ? 0 : blockIdx.z, b_hi = fold_batch ? g.batch : blockIdx.z + 1;
+    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
+    const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
+    const int total = nst * (b_hi - b_lo);
+    if (total > 0) tn_issue<2>(g, smem, b_lo, r_lo, r_hi, n0, tt, wave, lane);
+    for (int t = 0; t < total; ++t) {
+        wait_vm0();
+        __syncthreads();
+        if (t + 1 < total) {
+            const int bb = b_lo + (t + 1) / nst, st = (t + 1) % nst;
+            tn_issue<2>(g, smem + ((t + 1) & 1) * TN_STAGE_BYTES, bb, r_lo + st * TN_RC, r_hi, n0, tt, wave, lane);
+        }
+        const char* gs = smem + (t & 1) * TN_STAGE_BYTES;
+        const char* as = gs + TN_RC * 256;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], gf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tn_frag_bf16(as, kk * 32, wk * 64 + i * 16, lane, safe);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16(gs, kk * 32, wn * 64 + j * 16, lane, safe);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int slab = fold_batch ? sp : (blockIdx.z * splits + sp);
+    float* out = g.out + (int64_t)slab * g.out_batch_stride;
+    const int q = lane & 15, gq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tt.koff + wk * 64 + i * 16 + 4 * gq;
+            *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// =============================================================================================
+// TN kernel, fp32: out tile 64 (k) x 64 (n), contraction staged 32 rows at a time, operands by
+// ds_read_b32 (v_mfma_f32_16x16x4_f32 takes one row of the contraction per 16-lane group).
+// =============================================================================================
+#define TF_BT 64
+#define TF_RC 32
+#define TF_STAGE_BYTES (2 * TF_RC * 256)            // 16 KiB
+
+__device__ __forceinline__ void tnf_issue(const aew_gemm_tn_t& g, char* stage, int b, int r0, int r_end,
+                                          int n0, const TnTile& tt, int wave, int lane) {
+    const int lr = lane >> 4, pc = lane & 15;
+    const aew_seg_t& sa = g.seg[tt.seg];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 4 + lr;      // 8 pieces of 4 rows per operand
+        const int c = tn_swz_f32(r, pc);
+        const int m = r0 + r;
+        const char* sg = (m < r_end) ? seg_row_ptr(g.g, b, m, 4) : nullptr;
+        sg = sg ? sg + (n0 + c * 4) * 4 : reinterpret_cast<const char*>(aew_zero_page);
+        glds16(sg, stage + (wave * 2 + j) * 1024);
+        const char* sp = (m < r_end) ? seg_row_ptr(sa, b, m, 4) : nullptr;
+        sp = sp ? sp + (tt.kin + c * 4) * 4 : reinterpret_cast<const char*>(aew_zero_page);
+        glds16(sp, stage + TF_RC * 256 + (wave * 2 + j) * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_f32(const aew_gemm_tn_t g, int splits, int rows_per_split,
+                                                     int fold_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    const int nkt = g.K_total / TF_BT;
+    const int kt = blockIdx.x % nkt, nt = blockIdx.x / nkt;
+    const int n0 = nt * TF_BT;
+    const int sp = blockIdx.y;
+    const TnTile tt = tn_locate(g, kt, TF_BT);
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int b_lo = fold_batch ? 0 : blockIdx.z, b_hi = fold_batch ? g.batch : blockIdx.z + 1;
+    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
+    const int nst = (r_hi - r_lo + TF_RC - 1) / TF_RC;
+    const int total = nst * (b_hi - b_lo);
+    if (total > 0) tnf_issue(g, smem, b_lo, r_lo, r_hi, n0, tt, wave, lane);
+    const int q = lane & 15, kq = lane >> 4;
+    for (int t = 0; t < total; ++t) {
+        wait_vm0();
+        __syncthreads();
+        if (t + 1 < total) {
+            const int bb = b_lo + (t + 1) / nst, st = (t + 1) % nst;
+            tnf_issue(g, smem + ((t + 1) & 1) * TF_STAGE_BYTES, bb, r_lo + st * TF_RC, r_hi, n0, tt, wave, lane);
+        }
+        const char* gs = smem + (t & 1) * TF_STAGE_BYTES;
+        const char* as = gs + TF_RC * 256;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int row = ks * 4 + kq;
+            float af[2], gf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int col = wk * 32 + i * 16 + q;
+                af[i] = *reinterpret_cast<const float*>(as + row * 256 + (tn_swz_f32(row, col >> 2) << 4) + ((col & 3) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 32 + j * 16 + q;
+                gf[j] = *reinterpret_cast<const float*>(gs + row * 256 + (tn_swz_f32(row, col >> 2) << 4) + ((col & 3) << 2));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], gf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int slab = fold_batch ? sp : (blockIdx.z * splits + sp);
+    float* out = g.out + (int64_t)slab * g.out_batch_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = tt.koff + wk * 32 + i * 16 + 4 * kq;
+            *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// TN check kernel: one thread per output element, ascending (b, m) order.
+template <typename T>
+__global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_split, int fold_batch) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    const int nslab_b = fold_batch ? 1 : g.batch;
+    const int slab = blockIdx.z;                      // (b, sp) or sp
+    const int sp = fold_batch ? slab : slab % splits;
+    const int bz = fold_batch ? 0 : slab / splits;
+    (void)nslab_b;
+    if (k >= g.K_total) return;
+    int s = 0, kin = k;
+    while (kin >= g.seg[s].k_len) { kin -= g.seg[s].k_len; ++s; }
+    const aew_seg_t& sa = g.seg[s];
+    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
+    float acc = 0.f;
+    const int b_lo = fold_batch ? 0 : bz, b_hi = fold_batch ? g.batch : bz + 1;
+    for (int b = b_lo; b < b_hi; ++b)
+        for (int m = r_lo; m < r_hi; ++m) {
+            const int64_t rg = (int64_t)m * g.g.row_step + g.g.row_off;
+            const int64_t ra = (int64_t)m * sa.row_step + sa.row_off;
+            if (rg < g.g.row_lo || rg >= g.g.row_hi || ra < sa.row_lo || ra >= sa.row_hi) continue;
+            const float gv = ld_elem<T>(reinterpret_cast<const T*>(g.g.ptr) + (int64_t)b * g.g.batch_stride + rg * g.g.row_pitch + n);
+            const float av = ld_elem<T>(reinterpret_cast<const T*>(sa.ptr) + (int64_t)b * sa.batch_stride + ra * sa.row_pitch + kin);
+            acc = fmaf(gv, av, acc);
+        }
+    g.out[(int64_t)slab * g.out_batch_stride + (int64_t)n * g.K_total + k] = acc;
+}
+
+// =============================================================================================
+// host-side launchers
+// =============================================================================================
+static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
+
+static int check_seg(const aew_seg_t& s, int esize, int ktile) {
+    if (!s.ptr) return AEW_E_ARG;
+    if (s.k_len <= 0 || s.k_len % ktile) return AEW_E_ARG;
+    if (((uintptr_t)s.ptr & 15) || ((int64_t)s.row_pitch * esize) % 16 || ((int64_t)s.batch_stride * esize) % 16)
+        return AEW_E_ALIGN;
+    return 0;
+}
+
+static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
+    if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.M <= 0 || g.batch <= 0 || !g.W) return AEW_E_ARG;
+    const int es = g.dtype == AEW_BF16 ? 2 : 4;
+    const int kt = g.dtype == AEW_BF16 ? NT_BK : NF_BK;
+    const int ntile = g.dtype == AEW_BF16 ? NT_BN : NF_BN;
+    int ksum = 0;
+    for (int s = 0; s < g.n_segs; ++s) {
+        const int rc = check_seg(g.seg[s], es, kt);
+        if (rc) return rc;
+        ksum += g.seg[s].k_len;
+    }
+    if (ksum != g.K_total || g.N_pad % ntile || g.N > g.N_pad || (g.N & 3)) return AEW_E_ARG;
+    if (g.epi == AEW_EPI_RES_SKIP && (g.n_split % ntile)) return AEW_E_ARG;
+    if (g.epi != AEW_EPI_STORE && g.dtype != AEW_BF16) return AEW_E_UNSUP;
+    if (g.impl == 1) {
+        const int nq = (g.epi == AEW_EPI_GATED) ? g.N_pad / 8 : g.N_pad / 4;
+        dim3 grid((nq + 63) / 64, g.M, g.batch);
+        if (g.dtype == AEW_BF16) hipLaunchKernelGGL(k_gemm_nt_check<uint16_t>, grid, dim3(64), 0, st, g);
+        else hipLaunchKernelGGL(k_gemm_nt_check<float>, grid, dim3(64), 0, st, g);
+    } else if (g.dtype == AEW_BF16) {
+        dim3 grid((g.M + NT_BM - 1) / NT_BM, g.N_pad / NT_BN, g.batch);
+        hipLaunchKernelGGL(k_gemm_nt_bf16, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g);
+    } else {
+        dim3 grid((g.M + NF_BM - 1) / NF_BM, g.N_pad / NF_BN, g.batch);
+        hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), 2 * NF_STAGE_BYTES, st, g);
+    }
+    return (int)hipGetLastError();
+}
+
+// split heuristic: aim for >= ~2 blocks per CU
+static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* rps, int* fold) {
+    const int tiles = (g.N_pad / tile) * (g.K_total / tile);
+    int f = (g.Mc * g.batch <= 4096) ? 1 : 0;           // short contractions: fold the batch loop
+    int slabs_b = f ? 1 : g.batch;
+    int want = (512 + tiles * slabs_b - 1) / (tiles * slabs_b);
+    int max_sp = (g.Mc + 4 * rc - 1) / (4 * rc);        // keep >= 4 stages per block
+    if (max_sp < 1) max_sp = 1;
+    int sp = want < 1 ? 1 : (want > max_sp ? max_sp : want);
+    if (f) sp = 1;
+    int r = (g.Mc + sp - 1) / sp;
+    r = ((r + rc - 1) / rc) * rc;
+    sp = (g.Mc + r - 1) / r;
+    *splits = sp; *rps = r; *fold = f;
+}
+
+extern "C" int aew_tn_slabs(const aew_gemm_tn_t* g) {
+    // number of fp32 partial slabs the TN op writes (the unpack step sums them)
+    int sp, rps, fold;
+    const int tile = g->dtype == AEW_BF16 ? TN_BT : TF_BT;
+    const int rc = g->dtype == AEW_BF16 ? TN_RC : TF_RC;
+    tn_plan(*g, tile, rc, &sp, &rps, &fold);
+    return fold ? sp : g->batch * sp;
+}
+
+static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
+    if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.Mc <= 0 || g.batch <= 0 || !g.out) return AEW_E_ARG;
+    const int es = g.dtype == AEW_BF16 ? 2 : 4;
+    const int tile = g.dtype == AEW_BF16 ? TN_BT : TF_BT;
+    const int rc = g.dtype == AEW_BF16 ? TN_RC : TF_RC;
+    int ksum = 0;
+    for (int s = 0; s < g.n_segs; ++s) {
+        const int rcode = check_seg(g.seg[s], es, tile);
+        if (rcode) return rcode;
+        ksum += g.seg[s].k_len;
+    }
+    aew_seg_t gg = g.g; gg.k_len = tile;
+    const int rcode = check_seg(gg, es, tile);
+    if (rcode) return rcode;
+    if (ksum != g.K_total || g.N_pad % tile) return AEW_E_ARG;
+    int sp, rps, fold;
+    tn_plan(g, tile, rc, &sp, &rps, &fold);
+    if (g.impl == 1) {
+        dim3 grid((g.K_total + 63) / 64, g.N_pad, fold ? sp : g.batch * sp);
+        if (g.dtype == AEW_BF16) hipLaunchKernelGGL(k_gemm_tn_check<uint16_t>, grid, dim3(64), 0, st, g, sp, rps, fold);
+        else hipLaunchKernelGGL(k_gemm_tn_check<float>, grid, dim3(64), 0, st, g, sp, rps, fold);
+    } else if (g.dtype == AEW_BF16) {
+        dim3 grid((g.N_pad / TN_BT) * (g.K_total / TN_BT), sp, fold ? 1 : g.batch);
+        hipLaunchKernelGGL(k_gemm_tn_bf16, grid, dim3(256), 2 * TN_STAGE_BYTES, st, g, sp, rps, fold, g_tn_safe);
+    } else {
+        dim3 grid((g.N_pad / TF_BT) * (g.K_total / TF_BT), sp, fold ? 1 : g.batch);
+        hipLaunchKernelGGL(k_gemm_tn_f32, grid, dim3(256), 2 * TF_STAGE_BYTES, st, g, sp, rps, fold);
+    }
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,531 @@
+// aew_ops.hip — the HBM-bound ops of the hot path (everything that is not a GEMM).
+#include "aew_common.h"
+
+// =============================================================================================
+// table-driven strided copy / convert / reduce   (weight pack, gradient unpack, NCL <-> NLC)
+// =============================================================================================
+__global__ void k_copy_table(const aew_copy_table_t t) {
+    const int rec_i = t.block_rec[blockIdx.x];
+    const aew_copy_rec_t r = t.recs[rec_i];
+    const int64_t total = (int64_t)r.dims[0] * r.dims[1] * r.dims[2] * r.dims[3];
+    const int64_t base = (int64_t)(blockIdx.x - r.first_block) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int64_t e = base + u * 256 + threadIdx.x;
+        if (e >= total) return;
+        const int i3 = (int)(e % r.dims[3]); e /= r.dims[3];
+        const int i2 = (int)(e % r.dims[2]); e /= r.dims[2];
+        const int i1 = (int)(e % r.dims[1]); e /= r.dims[1];
+        const int i0 = (int)e;
+        const int64_t so = i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3];
+        const int64_t dof = i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
+        float acc = 0.f;
+        for (int q = 0; q < r.red_n; ++q) {
+            const int64_t si = so + q * r.red_stride;
+            acc += (r.src_dtype == AEW_BF16) ? bf2f(reinterpret_cast<const uint16_t*>(r.src)[si])
+                                             : reinterpret_cast<const float*>(r.src)[si];
+        }
+        acc *= r.scale;
+        if (r.dst_dtype == AEW_BF16) reinterpret_cast<uint16_t*>(r.dst)[dof] = f2bf(acc);
+        else if (r.accumulate) reinterpret_cast<float*>(r.dst)[dof] += acc;
+        else reinterpret_cast<float*>(r.dst)[dof] = acc;
+    }
+}
+
+// =============================================================================================
+// VQ: nearest code.  One wave per query; lane scans codes lane, lane+64, ...; the arithmetic is
+// the exact order of oracle/exact_chain.c (fma chains, IEEE sqrt and divide, strict '<',
+// lowest index wins).   vqema_bn.py:135-142, vq_bn.py:39-41
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.Q) return;
+    const float* z = p.ze + (int64_t)q * p.d_pitch;
+    float zz = 0.f;
+    for (int j = 0; j < p.d; ++j) zz = __fmaf_rn(z[j], z[j], zz);
+    const float zn = __fsqrt_rn(zz);
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < p.K; k += 64) {
+        const float* c = p.emb + (int64_t)k * p.d;
+        float dd = 0.f, qq = 0.f;
+        for (int j = 0; j < p.d; ++j) {
+            const float cj = c[j];
+            const float t = __fsub_rn(z[j], cj);
+            dd = __fmaf_rn(t, t, dd);
+            qq = __fmaf_rn(cj, cj, qq);
+        }
+        float v;
+        if (p.metric == 0) v = __fdiv_rn(__fsqrt_rn(dd), __fadd_rn(zn, __fsqrt_rn(qq)));
+        else v = dd;
+        if (v < best) { best = v; bi = k; }          // ascending k within the lane: first min wins
+    }
+    // wave argmin with lowest-index tie-break
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;                    // all-NaN row: torch.min would return NaN; pick 0
+    if (lane == 0) { p.ind[q] = bi; p.dist[q] = best; }
+    float* zq = p.zq + (int64_t)q * p.d_pitch;
+    for (int j = lane; j < p.d_pitch; j += 64) zq[j] = j < p.d ? p.emb[(int64_t)bi * p.d + j] : 0.f;
+}
+
+// z_sum / n_sum: one thread per (code, channel), queries in ascending order (deterministic and
+// bit-identical to the oracle).  vqema_bn.py:172-188
+__global__ void k_vq_stats(const aew_vq_stats_t p) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)p.K * p.d) return;
+    const int k = (int)(e / p.d), j = (int)(e % p.d);
+    float s = 0.f, n = 0.f;
+    for (int q = 0; q < p.Q; ++q)
+        if (p.ind[q] == k) { s = __fadd_rn(s, p.ze[(int64_t)q * p.d_pitch + j]); n = __fadd_rn(n, 1.0f); }
+    p.z_sum[e] = s;
+    if (j == 0) {
+        p.n_sum[k] = n;
+        if (p.hist) p.hist[k] += n;
+    }
+}
+
+__global__ void k_vq_ema(const aew_vq_ema_t p) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)p.K * p.d) return;
+    const int k = (int)(e / p.d), j = (int)(e % p.d);
+    const float nu = __fadd_rn(__fmul_rn(p.gamma, p.numer[e]), __fmul_rn(p.gamma_comp, p.z_sum[e]));
+    const float de = __fadd_rn(__fmul_rn(p.gamma, p.denom[k]), __fmul_rn(p.gamma_comp, p.n_sum[k]));
+    p.numer[e] = nu;
+    if (p.update_codebook) p.emb[e] = __fdiv_rn(nu, de);
+    // every thread of row k computes the same `de`; the write is deferred to a second kernel so
+    // no thread reads denom[k] after another thread of the row has overwritten it
+    (void)j;
+}
+__global__ void k_vq_ema_denom(const aew_vq_ema_t p) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.K) return;
+    p.denom[k] = __fadd_rn(__fmul_rn(p.gamma, p.denom[k]), __fmul_rn(p.gamma_comp, p.n_sum[k]));
+}
+
+// d(ze) = d(zq) [straight-through, vqema_bn.py:44-45] + coef * d(dist_min)/d(ze)
+//   scaled_l2: dist = u/v, u = ||z-q||, v = ||z|| + ||q||
+//       d dist/dz = (z-q)/(u v) - u z / (v^2 ||z||)
+//   sq_l2:     d dist/dz = 2 (z-q);  VQ also gets d/d(emb) of the l2 term (vq_bn.py:78)
+__global__ __launch_bounds__(256) void k_vq_bwd(const aew_vq_bwd_t p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.Q) return;
+    const float* z = p.ze + (int64_t)q * p.d_pitch;
+    const int64_t k = p.ind[q];
+    const float* c = p.emb + k * p.d;
+    float dd = 0.f, zz = 0.f, qq = 0.f;
+    for (int j = lane; j < p.d; j += 64) {
+        const float t = z[j] - c[j];
+        dd += t * t; zz += z[j] * z[j]; qq += c[j] * c[j];
+    }
+    dd = wave_sum(dd); zz = wave_sum(zz); qq = wave_sum(qq);
+    const float u = sqrtf(dd), zn = sqrtf(zz), v = zn + sqrtf(qq);
+    for (int j = lane; j < p.d_pitch; j += 64) {
+        float gr = 0.f;
+        if (j < p.d) {
+            const float t = z[j] - c[j];
+            float dj;
+            if (p.metric == 0) dj = (u > 0.f ? t / (u * v) : 0.f) - (zn > 0.f ? u * z[j] / (v * v * zn) : 0.f);
+            else dj = 2.0f * t;
+            gr = p.dzq[(int64_t)q * p.d_pitch + j] + p.coef * dj;
+            if (p.demb) atomicAdd(p.demb + k * p.d + j, p.demb_coef * (-2.0f * t));
+        }
+        p.dze[(int64_t)q * p.d_pitch + j] = gr;
+    }
+}
+
+// =============================================================================================
+// jitter gather / scatter   (wavenet.py:330-336)
+// =============================================================================================
+__global__ void k_lc_gather(const aew_lc_gather_t p) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.N * p.C_pad;
+    if (e >= total) return;
+    const int c = (int)(e % p.C_pad);
+    const int t = (int)((e / p.C_pad) % p.N);
+    const int b = (int)(e / ((int64_t)p.C_pad * p.N));
+    float v = 0.f;
+    if (c < p.C) {
+        const int64_t j = p.jitter[(int64_t)b * p.jit_pitch + t];
+        if (p.take_compat) {
+            // torch.take on the flattened (B, C, N) tensor with index b*N + j, expanded over c:
+            // flat index -> (b', c', n') of the NCL tensor
+            const int64_t flat = (int64_t)b * p.N + j;
+            const int64_t bb = flat / ((int64_t)p.C * p.N), cc = (flat / p.N) % p.C, nn = flat % p.N;
+            v = p.src[bb * p.src_bs + nn * p.src_pitch + cc];
+        } else {
+            v = p.src[(int64_t)b * p.src_bs + j * p.src_pitch + c];
+        }
+    }
+    p.dst[(int64_t)b * p.dst_bs + (int64_t)t * p.dst_pitch + c] = f2bf(v);
+}
+
+__global__ void k_lc_scatter(const aew_lc_scatter_t p) {
+    // dsrc must be zeroed by the caller; atomics because several t may hit the same source row
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.N * p.C;
+    if (e >= total) return;
+    const int c = (int)(e % p.C);
+    const int t = (int)((e / p.C) % p.N);
+    const int b = (int)(e / ((int64_t)p.C * p.N));
+    const float g = p.d[(int64_t)b * p.d_bs + (int64_t)t * p.d_pitch + c];
+    const int64_t j = p.jitter[(int64_t)b * p.jit_pitch + t];
+    if (p.take_compat) {
+        const int64_t flat = (int64_t)b * p.N + j;
+        const int64_t bb = flat / ((int64_t)p.C * p.N), cc = (flat / p.N) % p.C, nn = flat % p.N;
+        atomicAdd(p.dsrc + bb * p.dsrc_bs + nn * p.dsrc_pitch + cc, g);
+    } else {
+        atomicAdd(p.dsrc + (int64_t)b * p.dsrc_bs + j * p.dsrc_pitch + c, g);
+    }
+}
+
+// =============================================================================================
+// speaker-conditioned gated bias  (wavenet.py:135-139 folded into a per-(batch,layer) bias)
+// =============================================================================================
+__global__ void k_spk_bias(const aew_spk_bias_t p) {
+    // grid: (ceil(2*D_pad/256), L, B)
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y, b = blockIdx.z;
+    if (n >= 2 * p.D_pad) return;
+    const int gate = (n >> 4) & 1;
+    const int co = (n >> 5) * 16 + (n & 15);
+    float v = 0.f;
+    if (co < p.D) {
+        const int64_t ob = gate ? p.off_bias_gate[l] : p.off_bias_sig[l];
+        if (ob >= 0) v = p.params[ob + co];
+        const int64_t ov = (gate ? p.off_proj_gate[l] : p.off_proj_sig[l]) + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
+        const int64_t vb = p.voice[b];
+        for (int j = 0; j < p.G; ++j) {
+            float gc = p.params[p.off_spk_w + (int64_t)j * p.n_speakers + vb];
+            if (p.off_spk_b >= 0) gc += p.params[p.off_spk_b + j];
+            v += p.params[ov + j] * gc;
+            if (l == 0 && n == 0) p.gc[b * p.G + j] = gc;
+        }
+    }
+    p.bias[((int64_t)b * p.L + l) * 2 * p.D_pad + n] = v;
+}
+
+__global__ void k_spk_bwd(const aew_spk_bwd_t p) {
+    // one block per layer; thread per output channel `co` for both filt and gate
+    const int l = blockIdx.x;
+    const int tid = threadIdx.x;
+    extern __shared__ float sh[];                    // [B][G] partial dgc for this layer
+    for (int i = tid; i < p.B * p.G; i += blockDim.x) sh[i] = 0.f;
+    __syncthreads();
+    for (int half = 0; half < 2; ++half)
+        for (int co = tid; co < p.D; co += blockDim.x) {
+            const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
+            const int64_t ob = half ? p.off_bias_gate[l] : p.off_bias_sig[l];
+            const int64_t ov = (half ? p.off_proj_gate[l] : p.off_proj_sig[l]) + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
+            float bsum = 0.f;
+            for (int b = 0; b < p.B; ++b) bsum += p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
+            if (ob >= 0) p.grads[ob + co] = bsum;
+            for (int j = 0; j < p.G; ++j) {
+                float gv = 0.f;
+                const float vj = p.params[ov + j];
+                for (int b = 0; b < p.B; ++b) {
+                    const float cs = p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
+                    gv += cs * p.gc[b * p.G + j];
+                    atomicAdd(&sh[b * p.G + j], cs * vj);
+                }
+                p.grads[ov + j] = gv;
+            }
+        }
+    __syncthreads();
+    // speaker embedding grads accumulate over layers -> global atomics (caller zeroes them)
+    for (int i = tid; i < p.B * p.G; i += blockDim.x) {
+        const int b = i / p.G, j = i % p.G;
+        atomicAdd(p.grads + p.off_spk_w + (int64_t)j * p.n_speakers + p.voice[b], sh[i]);
+        if (p.off_spk_b >= 0) atomicAdd(p.grads + p.off_spk_b + j, sh[i]);
+    }
+}
+
+// =============================================================================================
+// base layer: one-hot x 1x1 conv == column gather   (wavenet.py:348-351)
+// =============================================================================================
+__global__ void k_base_gather(const aew_base_gather_t p) {
+    // grid: (ceil(R_pad/4/64), T, B); thread handles 4 channels
+    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int t = blockIdx.y, b = blockIdx.z;
+    const int q = (int)p.wav[(int64_t)b * p.wav_pitch + p.wav_off + t];
+    if (c4 < p.R_pad) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = c4 + r;
+            v[r] = c < p.R ? p.W[(int64_t)c * p.Q + q] + (p.bias ? p.bias[c] : 0.f) : 0.f;
+        }
+        *reinterpret_cast<uint2*>(p.x + (int64_t)b * p.x_bs + (int64_t)t * p.x_pitch + c4) = pack4_bf16(v);
+    }
+    if (p.onehot && c4 < p.Q_pad) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (c4 + r == q) ? 1.f : 0.f;
+        *reinterpret_cast<uint2*>(p.onehot + (int64_t)b * p.oh_bs + (int64_t)t * p.oh_pitch + c4) = pack4_bf16(v);
+    }
+}
+
+// =============================================================================================
+// fused log-softmax + NLL and its gradient; one wave per position   (wavenet.py:543-547)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_softmax_nll(const aew_softmax_nll_t p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= (int64_t)p.B * p.w) return;
+    const int b = (int)(pos / p.w), u = (int)(pos % p.w);
+    const float* lg = p.logits + (int64_t)b * p.bs + (int64_t)u * p.pitch;
+    const bool live = u < p.w - 1;
+    float mx = -INFINITY;
+    for (int c = lane; c < p.Q; c += 64) mx = fmaxf(mx, lg[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < p.Q; c += 64) se += __expf(lg[c] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    const int tgt = live ? (int)p.wav[(int64_t)b * p.wav_pitch + p.tgt_off + u + 1] : 0;
+    if (!p.backward) {
+        if (lane == 0) {
+            const float lp = lg[tgt] - lse;
+            p.nll[pos] = live ? -lp : 0.f;
+            if (p.ptgt) p.ptgt[pos] = live ? __expf(lp) : 0.f;
+        }
+    } else {
+        uint16_t* dl = p.dlogits + (int64_t)b * p.dl_bs + (int64_t)u * p.dl_pitch;
+        for (int c = lane; c < p.Q_pad; c += 64) {
+            float g = 0.f;
+            if (live && c < p.Q) g = (__expf(lg[c] - lse) - (c == tgt ? 1.f : 0.f)) * p.scale;
+            dl[c] = f2bf(g);
+        }
+    }
+}
+
+// =============================================================================================
+// column sums (bias gradients).  grid: (ceil(N/64), batch, chunks); block 256 = 4 row-lanes x 64
+// columns; chunked over rows with atomics into a pre-zeroed (or accumulating) output.
+// =============================================================================================
+__global__ void k_colsum(const aew_colsum_t p, int rows_per_chunk) {
+    __shared__ float sh[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.z * rows_per_chunk, r1 = min(p.M, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (col < p.N)
+        for (int m = r0 + rl; m < r1; m += 4) {
+            const int64_t row = (int64_t)m * p.x.row_step + p.x.row_off;
+            if (row < p.x.row_lo || row >= p.x.row_hi) continue;
+            const int64_t idx = (int64_t)b * p.x.batch_stride + row * p.x.row_pitch + col;
+            s += p.dtype == AEW_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.x.ptr)[idx])
+                                     : reinterpret_cast<const float*>(p.x.ptr)[idx];
+        }
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < p.N) {
+        s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        atomicAdd(p.out + (int64_t)b * p.out_bs + col, s);
+    }
+}
+
+// =============================================================================================
+// scalar reduction (loss):  out[0] = sum_i scale_i * sum(x_i)     single block, deterministic
+// =============================================================================================
+__global__ void k_reduce(const aew_reduce_t p) {
+    __shared__ float sh[256];
+    float tot = 0.f;
+    for (int i = 0; i < p.n_terms; ++i) {
+        float s = 0.f;
+        for (int e = threadIdx.x; e < p.n[i]; e += 256) s += p.x[i][e];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float v = sh[0] * p.scale[i];
+        if (threadIdx.x == 0) p.out[1 + i] = v;
+        tot += p.clamp[i] ? p.post_scale[i] * fmaxf(v, p.clamp_min[i]) : v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.out[0] = tot;
+}
+
+// =============================================================================================
+// Adam (torch.optim.Adam defaults; checkpoint.py:49-50), flat buffer, float4 vectorised
+// =============================================================================================
+__global__ void k_adam(const aew_adam_t a) {
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= a.n) return;
+    const float inv_sqrt_bc2 = rsqrtf(a.bc2);
+    const float step = a.lr / a.bc1;
+    if (i4 + 4 <= a.n) {
+        float4 p = *reinterpret_cast<float4*>(a.p + i4);
+        float4 g = *reinterpret_cast<const float4*>(a.g + i4);
+        float4 m = *reinterpret_cast<float4*>(a.m + i4);
+        float4 v = *reinterpret_cast<float4*>(a.v + i4);
+        float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gr = gp[r] * a.grad_scale;
+            mp[r] = a.beta1 * mp[r] + (1.f - a.beta1) * gr;
+            vp[r] = a.beta2 * vp[r] + (1.f - a.beta2) * gr * gr;
+            pp[r] -= step * mp[r] / (sqrtf(vp[r]) * inv_sqrt_bc2 + a.eps);
+        }
+        *reinterpret_cast<float4*>(a.p + i4) = p;
+        *reinterpret_cast<float4*>(a.m + i4) = m;
+        *reinterpret_cast<float4*>(a.v + i4) = v;
+    } else {
+        for (int64_t i = i4; i < a.n; ++i) {
+            const float gr = a.g[i] * a.grad_scale;
+            const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * gr;
+            const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * gr * gr;
+            a.m[i] = m; a.v[i] = v;
+            a.p[i] -= step * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+        }
+    }
+}
+
+// =============================================================================================
+// VAE reparameterisation + KL terms (vae_bn.py:44-53, 90-98) and AE norm term (ae_bn.py:36-38)
+// =============================================================================================
+__global__ void k_vae(const aew_vae_t p) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;                     // 64 threads
+    const float* lin = p.lin + (int64_t)q * p.lin_pitch;
+    float kl = 0.f;
+    float klc = p.kl_coef;
+    if (p.backward && p.kl_value) klc = (p.kl_value[0] >= p.free_nats) ? p.kl_coef : 0.f;
+    for (int j = lane; j < p.d_pitch; j += 64) {
+        if (j < p.d) {
+            const float mu = lin[j], ls = lin[p.d + j];
+            const float sigma = __expf(0.5f * ls);
+            const float e = p.eps[(int64_t)q * p.d + j];
+            if (!p.backward) {
+                p.sample[(int64_t)q * p.d_pitch + j] = mu + sigma * e;
+                const float s2 = sigma * sigma;
+                kl += 1.0f + __logf(s2) - mu * mu - s2;
+            } else {
+                // loss = ... + kl_coef * KL,  KL = -0.5*sum(1 + ls - mu^2 - exp(ls))
+                const float ds = p.dsample[(int64_t)q * p.d_pitch + j];
+                p.dlin[(int64_t)q * p.lin_pitch + j] = ds + klc * mu;
+                p.dlin[(int64_t)q * p.lin_pitch + p.d + j] =
+                    ds * e * 0.5f * sigma + klc * (-0.5f) * (1.0f - sigma * sigma);
+            }
+        } else if (!p.backward) {
+            p.sample[(int64_t)q * p.d_pitch + j] = 0.f;
+        }
+    }
+    if (!p.backward) {
+        kl = wave_sum(kl);
+        if (lane == 0) p.kl_terms[q] = kl;
+    }
+}
+
+__global__ void k_ae_norm(const aew_ae_norm_t p) {
+    const int q = blockIdx.x, lane = threadIdx.x;     // 64 threads
+    const float* z = p.ze + (int64_t)q * p.d_pitch;
+    float ss = 0.f;
+    for (int j = lane; j < p.d; j += 64) ss += z[j] * z[j];
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    if (!p.backward) {
+        if (lane == 0) p.term[q] = fabsf(nrm - 1.0f);
+    } else {
+        const float sgn = nrm > 1.0f ? 1.f : (nrm < 1.0f ? -1.f : 0.f);
+        for (int j = lane; j < p.d_pitch; j += 64) {
+            float g = 0.f;
+            if (j < p.d) g = p.dze_in[(int64_t)q * p.d_pitch + j] + (nrm > 0.f ? p.coef * sgn * z[j] / nrm : 0.f);
+            p.dze[(int64_t)q * p.d_pitch + j] = g;
+        }
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+static int launch_copy(const aew_copy_table_t& t, hipStream_t st) {
+    if (t.n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_copy_table, dim3(t.n_blocks), dim3(256), 0, st, t);
+    return (int)hipGetLastError();
+}
+static int launch_vq_nearest(const aew_vq_nearest_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_vq_nearest, dim3(cdiv64(p.Q, 4)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_vq_stats(const aew_vq_stats_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_vq_stats, dim3(cdiv64((int64_t)p.K * p.d, 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_vq_ema(const aew_vq_ema_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_vq_ema, dim3(cdiv64((int64_t)p.K * p.d, 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_vq_ema_denom, dim3(cdiv64(p.K, 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_vq_bwd(const aew_vq_bwd_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_vq_bwd, dim3(cdiv64(p.Q, 4)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_lc_gather(const aew_lc_gather_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_lc_gather, dim3(cdiv64((int64_t)p.B * p.N * p.C_pad, 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_lc_scatter(const aew_lc_scatter_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_lc_scatter, dim3(cdiv64((int64_t)p.B * p.N * p.C, 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_spk_bias(const aew_spk_bias_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_bias, dim3(cdiv64(2 * p.D_pad, 256), p.L, p.B), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L), dim3(256), p.B * p.G * sizeof(float), st, p);
+    return (int)hipGetLastError();
+}
+static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {
+    const int cmax = p.onehot && p.Q_pad > p.R_pad ? p.Q_pad : p.R_pad;
+    hipLaunchKernelGGL(k_base_gather, dim3(cdiv64(cmax / 4, 64), p.T, p.B), dim3(64), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_softmax(const aew_softmax_nll_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_softmax_nll, dim3(cdiv64((int64_t)p.B * p.w, 4)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
+    if (!p.accumulate) {
+        for (int b = 0; b < p.batch; ++b) {
+            hipError_t e = hipMemsetAsync(p.out + (int64_t)b * p.out_bs, 0, (size_t)p.N * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    int chunks = (p.M + 511) / 512;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    const int rpc = (p.M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv64(p.N, 64), p.batch, chunks), dim3(256), 0, st, p, rpc);
+    return (int)hipGetLastError();
+}
+static int launch_reduce(const aew_reduce_t& p, hipStream_t st) {
+    if (p.n_terms < 1 || p.n_terms > 4) return AEW_E_ARG;
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_adam(const aew_adam_t& p, hipStream_t st) {
+    if (((uintptr_t)p.p | (uintptr_t)p.g | (uintptr_t)p.m | (uintptr_t)p.v) & 15) return AEW_E_ALIGN;
+    hipLaunchKernelGGL(k_adam, dim3(cdiv64((p.n + 3) / 4, 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_vae(const aew_vae_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_vae, dim3(p.Q), dim3(64), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_ae_norm(const aew_ae_norm_t& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_ae_norm, dim3(p.Q), dim3(64), 0, st, p);
+    return (int)hipGetLastError();
+}

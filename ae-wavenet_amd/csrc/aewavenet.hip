@@ -1,0 +1,244 @@
+// aewavenet.hip — single translation unit of libaewavenet_hip.so: kernels + the C ABI
+// declared in include/aewavenet.h.   Build: see __graft_entry__.build()
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC aewavenet.hip -o libaewavenet_hip.so
+#include "aew_gemm.hip"
+#include "aew_ops.hip"
+
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// timing (HIP events on the plan's stream; used by bench.py for the roofline numbers)
+// ---------------------------------------------------------------------------------------------
+static int g_timing = 0;
+static std::vector<hipEvent_t> g_ev;       // pairs (start, stop)
+static std::vector<int32_t> g_ev_tag;
+static size_t g_ev_used = 0;
+
+static hipEvent_t ev_get(size_t i) {
+    while (g_ev.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_ev.push_back(e);
+    }
+    return g_ev[i];
+}
+
+static int dispatch(const aew_op_t& op, hipStream_t st) {
+    switch (op.kind) {
+        case AEW_OP_GEMM_NT: return launch_gemm_nt(op.u.nt, st);
+        case AEW_OP_GEMM_TN: return launch_gemm_tn(op.u.tn, st);
+        case AEW_OP_COPY_TABLE: return launch_copy(op.u.copy, st);
+        case AEW_OP_VQ_NEAREST: return launch_vq_nearest(op.u.vqn, st);
+        case AEW_OP_VQ_STATS: return launch_vq_stats(op.u.vqs, st);
+        case AEW_OP_VQ_EMA: return launch_vq_ema(op.u.vqe, st);
+        case AEW_OP_VQ_BWD: return launch_vq_bwd(op.u.vqb, st);
+        case AEW_OP_LC_GATHER: return launch_lc_gather(op.u.lcg, st);
+        case AEW_OP_LC_SCATTER: return launch_lc_scatter(op.u.lcs, st);
+        case AEW_OP_SPK_BIAS: return launch_spk_bias(op.u.spk, st);
+        case AEW_OP_SPK_BWD: return launch_spk_bwd(op.u.spkb, st);
+        case AEW_OP_BASE_GATHER: return launch_base_gather(op.u.base, st);
+        case AEW_OP_SOFTMAX_NLL: return launch_softmax(op.u.sm, st);
+        case AEW_OP_COLSUM: return launch_colsum(op.u.cs, st);
+        case AEW_OP_REDUCE: return launch_reduce(op.u.red, st);
+        case AEW_OP_ADAM: return launch_adam(op.u.adam, st);
+        case AEW_OP_ZERO:
+            if (op.u.zero.bytes <= 0) return 0;
+            return (int)hipMemsetAsync(op.u.zero.ptr, 0, (size_t)op.u.zero.bytes, st);
+        case AEW_OP_VAE: return launch_vae(op.u.vae, st);
+        case AEW_OP_AE_NORM: return launch_ae_norm(op.u.aen, st);
+        default: return AEW_E_UNSUP;
+    }
+}
+
+extern "C" int aew_abi_version(void) { return AEW_ABI_VERSION; }
+
+extern "C" int aew_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(aew_op_t);
+        case 1: return (int)sizeof(aew_gemm_nt_t);
+        case 2: return (int)sizeof(aew_gemm_tn_t);
+        case 3: return (int)sizeof(aew_seg_t);
+        case 4: return (int)sizeof(aew_view_t);
+        case 5: return (int)sizeof(aew_copy_rec_t);
+        default: return -1;
+    }
+}
+
+extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index) {
+    if (!ops || n < 0) return AEW_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_timing) {
+            e0 = ev_get(2 * g_ev_used);
+            e1 = ev_get(2 * g_ev_used + 1);
+            if (!e0 || !e1) return (int)hipErrorOutOfMemory;
+            hipEventRecord(e0, st);
+        }
+        const int rc = dispatch(ops[i], st);
+        if (g_timing) {
+            hipEventRecord(e1, st);
+            if (g_ev_tag.size() <= g_ev_used) g_ev_tag.resize(g_ev_used + 1);
+            g_ev_tag[g_ev_used] = ops[i].tag;
+            ++g_ev_used;
+        }
+        if (rc != 0) {
+            if (fail_index) *fail_index = i;
+            return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" int aew_timing_enable(int on) {
+    g_timing = on ? 1 : 0;
+    g_ev_used = 0;
+    return 0;
+}
+
+extern "C" int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count) {
+    if (!count) return AEW_E_ARG;
+    *count = (int)g_ev_used;
+    if (g_ev_used == 0) return 0;
+    hipError_t e = hipEventSynchronize(g_ev[2 * g_ev_used - 1]);
+    if (e != hipSuccess) return (int)e;
+    for (size_t i = 0; i < g_ev_used && (int)i < capacity; ++i) {
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        if (ms) ms[i] = t;
+        if (tags) tags[i] = g_ev_tag[i];
+    }
+    g_ev_used = 0;
+    return 0;
+}
+
+extern "C" int aew_set_tn_safe(int on) { g_tn_safe = on ? 1 : 0; return 0; }
+
+extern "C" const char* aew_strerror(int code) {
+    if (code == 0) return "ok";
+    if (code == AEW_E_ARG) return "aewavenet: malformed descriptor";
+    if (code == AEW_E_UNSUP) return "aewavenet: unsupported op/dtype/flag combination";
+    if (code == AEW_E_ALIGN) return "aewavenet: pointer/pitch alignment violated";
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "aewavenet: unknown error";
+}
+
+// ---------------------------------------------------------------------------------------------
+// device self-test of the lane mappings the kernels rely on
+//   detail[0] bf16 MFMA 16x16x32 C/D map + operand map        (0 ok)
+//   detail[1] f32  MFMA 16x16x4  C/D map                       (0 ok)
+//   detail[2] f32  MFMA is a k-ascending fmaf chain (bitwise)  (0 ok)
+//   detail[3] ds_read_b64_tr_b16 lane semantics                (0 ok)
+//   detail[4] global_load_lds_dwordx4 lands lane-linear        (0 ok)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_selftest(int32_t* detail, float* scratch) {
+    __shared__ __attribute__((aligned(16))) char lds[8192];
+    const int lane = threadIdx.x;
+    const int fi = lane & 15, fg = lane >> 4;
+    int bad;
+    // ---- [0] bf16 MFMA: A[i][k] = small ints asymmetric, B[k][j]
+    {
+        bf16x8_t a, bq;
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * fg + e;
+            a[e] = (__bf16)(float)((fi * 3 + k) % 7 - 3);            // A[fi][k]
+            bq[e] = (__bf16)(float)((fi * 5 + 2 * k) % 5 - 2);       // B[k][fi]
+        }
+        f32x4_t c = {0, 0, 0, 0};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, c, 0, 0, 0);
+        bad = 0;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * fg + r, col = fi;
+            float ref = 0.f;
+            for (int k = 0; k < 32; ++k)
+                ref += (float)((row * 3 + k) % 7 - 3) * (float)((col * 5 + 2 * k) % 5 - 2);
+            if (c[r] != ref) bad = 1;
+        }
+        if (__any(bad) && lane == 0) detail[0] = 1;
+    }
+    // ---- [1]/[2] f32 MFMA
+    {
+        f32x4_t c = {0, 0, 0, 0};
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + fg;
+            const float a = (float)((fi * 3 + k) % 7 - 3), bq = (float)((fi * 5 + 2 * k) % 5 - 2);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, c, 0, 0, 0);
+        }
+        bad = 0;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * fg + r, col = fi;
+            float ref = 0.f;
+            for (int k = 0; k < 16; ++k)
+                ref += (float)((row * 3 + k) % 7 - 3) * (float)((col * 5 + 2 * k) % 5 - 2);
+            if (c[r] != ref) bad = 1;
+        }
+        if (__any(bad) && lane == 0) detail[1] = 1;
+        // order sensitivity: values with wide dynamic range, compare bitwise with fmaf chain
+        f32x4_t d = {0.25f, 0.25f, 0.25f, 0.25f};
+        auto av = [](int i, int k) { return (1.0f + 0.37f * i) * (k % 3 == 0 ? 1.0e4f : (k % 3 == 1 ? 3.3e-3f : -7.1f)) + 0.001f * k; };
+        auto bv = [](int k, int j) { return (0.9f - 0.11f * j) * (k % 2 ? -1.7e2f : 2.9e-2f) + 0.003f * k; };
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k = 4 * ks + fg;
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av(fi, k), bv(k, fi), d, 0, 0, 0);
+        }
+        bad = 0;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * fg + r, col = fi;
+            float ref = 0.25f;
+            for (int k = 0; k < 32; ++k) ref = __fmaf_rn(av(row, k), bv(k, col), ref);
+            if (__float_as_uint(d[r]) != __float_as_uint(ref)) bad = 1;
+        }
+        if (__any(bad) && lane == 0) detail[2] = 1;
+    }
+    // ---- [3] ds_read_b64_tr_b16: fill 4 rows x 64 cols of shorts with value row*64+col
+    {
+        short* t = reinterpret_cast<short*>(lds);
+        for (int e = lane; e < 4 * 64 * 4; e += 64) t[e] = (short)e;      // 16 rows x 64 cols
+        __syncthreads();
+        // lane (q, g): read rows 4g..4g+3, column group: address row (4g + (q>>2)), cols 4*(q&3)
+        const int q = lane & 15;
+        const char* p = lds + ((4 * fg + (q >> 2)) * 64 + 4 * (q & 3)) * 2;
+        const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)AEW_LDS_PTR(p));
+        bad = 0;
+        for (int e = 0; e < 4; ++e)
+            if (v[e] != (short)((4 * fg + e) * 64 + q)) bad = 1;          // rows 4g+e, column q
+        if (__any(bad) && lane == 0) detail[3] = 1;
+        __syncthreads();
+    }
+    // ---- [4] LDS-DMA placement
+    {
+        float* src = scratch;                                           // 256 floats prepared by host memset
+        for (int e = lane; e < 256; e += 64) src[e] = (float)e;
+        __threadfence();
+        __syncthreads();
+        // lane l fetches 16 B at element 4*(63-l)  -> LDS slot l
+        glds16(src + 4 * (63 - lane), lds);
+        wait_vm0();
+        __syncthreads();
+        const float* t = reinterpret_cast<const float*>(lds);
+        bad = 0;
+        for (int e = 0; e < 4; ++e)
+            if (t[4 * lane + e] != (float)(4 * (63 - lane) + e)) bad = 1;
+        if (__any(bad) && lane == 0) detail[4] = 1;
+    }
+}
+
+extern "C" int aew_selftest(void* scratch, int64_t scratch_bytes, void* stream, int32_t* detail) {
+    if (!scratch || scratch_bytes < (1 << 16) || !detail) return AEW_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* d_detail = reinterpret_cast<int32_t*>(scratch);
+    float* d_f = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 4096);
+    hipError_t e = hipMemsetAsync(d_detail, 0, 8 * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, st, d_detail, d_f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(detail, d_detail, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 5; ++i)
+        if (detail[i]) return AEW_E_UNSUP;
+    return 0;
+}

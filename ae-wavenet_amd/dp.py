@@ -1,0 +1,65 @@
+"""Data parallelism: one process per GPU, RCCL over xGMI via torch.distributed.
+
+The reference only distributes on TPU (xmp.spawn + xm.optimizer_step, train.py:58-60,
+chassis.py:168-169).  Here every rank holds a full replica and an independent shard of audio
+windows (sampler rule data.py:100-106); per step the ranks exchange
+  * the flat gradient buffer (one bucketed all-reduce, SUM; the optimizer applies 1/world for
+    mean-type losses — SURVEY §8e), and
+  * the VQ-EMA statistics z_sum / n_sum (SUM) before the EMA update, so that all replicas keep
+    an identical codebook (north-star requirement; the reference lets replicas drift).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n: int, rank: int, world: int, epoch: int) -> List[int]:
+    """Replica-sharded looping sampler order of the reference (data.py:100-106)."""
+    g = torch.Generator()
+    g.manual_seed(epoch * world + rank)
+    vals = list(range(rank, n, world))
+    perm = torch.randperm(len(vals), generator=g).tolist()
+    return [vals[i] for i in perm]
+
+
+class DataParallel:
+    def __init__(self, bucket_mb: float = 32.0, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+
+    def grad_scale(self, mean_loss: bool) -> float:
+        """Factor the optimizer applies to the summed gradient: 1/world reproduces the
+        single-process gradient of a mean-type loss over the global batch; sum-type losses
+        (VQ, KL) keep the sum."""
+        return 1.0 / self.world if mean_loss else 1.0
+
+    def allreduce_grads(self, eng):
+        flat = eng.ps.grads[:eng.ps.numel]
+        if self.world == 1:
+            return
+        n = flat.numel()
+        for s in range(0, n, self.bucket_elems):
+            dist.all_reduce(flat[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce_ema(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
+        if self.world == 1:
+            return
+        dist.all_reduce(z_sum, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(n_sum, op=dist.ReduceOp.SUM, group=self.group)
+
+    def broadcast_params(self, eng, src: int = 0):
+        dist.broadcast(eng.ps.params, src, group=self.group)
+        if eng.bn_type == "vqvae-ema":
+            for t in (eng.emb, eng.ema_numer, eng.ema_denom):
+                dist.broadcast(t, src, group=self.group)
+
+    def attach(self, model):
+        model._dp = self
+        model._ema_allreduce = self.allreduce_ema

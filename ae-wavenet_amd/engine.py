@@ -1,0 +1,684 @@
+"""Launch plans for the WaveNet-autoencoder training step.
+
+Builds, once per (model, batch, window), the forward and backward plans that
+`aew_run_plan` executes: weight packing, encoder (fp32 exact chain), bottleneck, the
+conditioning path, the gated dilated stack, the post network, the loss, and the complete
+hand-written backward including weight-gradient GEMMs and gradient unpacking.
+
+Reference arithmetic restated by these plans (citations into the reference checkout):
+  encoder            wave_encoder.py:34-50, 53-103
+  bottlenecks        vqema_bn.py:125-222, vq_bn.py:28-61, vae_bn.py:26-62, ae_bn.py:11-16
+  decoder            wavenet.py:91-111 (gated layer), :127-140 (conditioning), :142-165
+                     (upsampling), :323-364 (forward_train)
+  losses             wavenet.py:541-552, vqema_bn.py:231-266, vq_bn.py:72-115,
+                     vae_bn.py:76-125, ae_bn.py:29-46
+  wiring             autoencoder_model.py:206-259, mfcc_inverter.py:89-108
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import geometry as G
+from .plan import (CopyTableBuilder, ESIZE, Mat, Plan, Workspace, make_nt, make_tn, null_view, ru)
+
+BF, F3 = L.BF16, L.F32
+
+# timing tags (reported by aew_timing_read; bench.py groups kernel time by these)
+TAG_G1, TAG_G2, TAG_DZ, TAG_DX, TAG_WG_FG, TAG_WG_RS, TAG_DCOND, TAG_POST, TAG_UPS, TAG_ENC, \
+    TAG_VQ, TAG_LOSS, TAG_PACK, TAG_MISC, TAG_ADAM = range(1, 16)
+
+
+# ------------------------------------------------------------------------------------------
+# parameters
+# ------------------------------------------------------------------------------------------
+def decoder_param_specs(hps, n_lc_in: int, pre: str) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Names / shapes / registration order of the reference WaveNet module
+    (wavenet.py:184-259)."""
+    R, D, S, P, Q = hps.n_res, hps.n_dil, hps.n_skp, hps.n_post, hps.n_quant
+    Cc = hps.n_lc_out + hps.n_global_embed
+    sp: List[Tuple[str, Tuple[int, ...]]] = [(pre + "lc_conv.weight", (hps.n_lc_out, n_lc_in, 3))]
+    if hps.bias:
+        sp.append((pre + "lc_conv.bias", (hps.n_lc_out,)))
+    for i, f in enumerate(hps.lc_upsample_filt_sizes):
+        sp.append((pre + f"lc_upsample.{i}.tconv.weight", (hps.n_lc_out, hps.n_lc_out, f)))
+        sp.append((pre + f"lc_upsample.{i}.tconv.bias", (hps.n_lc_out,)))
+    sp.append((pre + "cond.speaker_embedding.weight", (hps.n_global_embed, hps.n_speakers)))
+    sp.append((pre + "cond.speaker_embedding.bias", (hps.n_global_embed,)))
+    sp.append((pre + "base_layer.weight", (R, Q, 1)))
+    if hps.bias:
+        sp.append((pre + "base_layer.bias", (R,)))
+    nl = hps.n_blocks * hps.n_block_layers
+    for i in range(nl):
+        p = pre + f"conv_layers.{i}."
+        for nm in ("conv_signal", "conv_gate"):
+            sp.append((p + nm + ".weight", (D, R, 2)))
+            if hps.bias:
+                sp.append((p + nm + ".bias", (D,)))
+        sp.append((p + "proj_signal.weight", (D, Cc, 1)))
+        sp.append((p + "proj_gate.weight", (D, Cc, 1)))
+        sp.append((p + "dil_skp.weight", (S, D, 1)))
+        if i != nl - 1:
+            sp.append((p + "dil_res.weight", (R, D, 1)))
+    for nm, shp in (("post1", (P, S, 1)), ("post2", (Q, P, 1))):
+        sp.append((pre + nm + ".weight", shp))
+        if hps.bias:
+            sp.append((pre + nm + ".bias", (shp[0],)))
+    return sp
+
+
+def encoder_param_specs(n_in: int, n_out: int, pre: str = "encoder."):
+    sp = []
+    cin = n_in
+    for i, f in enumerate(G.ENCODER_FILTERS):
+        sp.append((pre + f"net.{i}.conv.weight", (n_out, cin, f)))
+        sp.append((pre + f"net.{i}.conv.bias", (n_out,)))
+        cin = n_out
+    return sp
+
+
+def bottleneck_param_specs(hps, pre: str = "bottleneck."):
+    bn, E, d = hps.bn_type, hps.enc_n_out, hps.bn_n_out
+    if bn == "vae":
+        return [(pre + "linear.weight", (2 * d, E, 1))]
+    if bn == "ae":
+        return [(pre + "linear.weight", (d, E, 1)), (pre + "linear.bias", (d,))]
+    if bn == "vqvae":
+        # nn.Module registers direct Parameters before sub-module parameters (vq_bn.py:13,20)
+        return [(pre + "emb", (hps.bn_vq_n_embed, d)), (pre + "linear.weight", (d, E, 1))]
+    return [(pre + "linear.weight", (d, E, 1))]
+
+
+class ParamStore:
+    """All trainable parameters in one flat fp32 buffer (+ a same-shaped gradient buffer):
+    one all-reduce, one fused Adam launch, and the pack/unpack tables address it by offset."""
+
+    def __init__(self, ws: Workspace, specs: Sequence[Tuple[str, Tuple[int, ...]]]):
+        self.ws = ws
+        self.shape: Dict[str, Tuple[int, ...]] = {}
+        self.off: Dict[str, int] = {}
+        o = 0
+        for n, shp in specs:
+            self.shape[n], self.off[n] = tuple(shp), o
+            numel = 1
+            for s in shp:
+                numel *= s
+            o += ru(numel, 4)
+        self.numel = o
+        self.params = ws.alloc("params", o, torch.float32)
+        self.grads = ws.alloc("grads", o, torch.float32)
+
+    def names(self):
+        return list(self.shape)
+
+    def numel_of(self, n):
+        k = 1
+        for s in self.shape[n]:
+            k *= s
+        return k
+
+    def view(self, n, grad=False) -> torch.Tensor:
+        t = self.grads if grad else self.params
+        return t[self.off[n]:self.off[n] + self.numel_of(n)].view(self.shape[n])
+
+    def ptr(self, n, grad=False) -> int:
+        t = self.grads if grad else self.params
+        return t.data_ptr() + 4 * self.off[n]
+
+    def has(self, n):
+        return n in self.shape
+
+
+# ------------------------------------------------------------------------------------------
+# pack / unpack helpers
+# ------------------------------------------------------------------------------------------
+def _gate_groups(D: int):
+    """Output channel co -> packed row (co//16)*32 + co%16 (+16 for gate).  Yields
+    (co_start, n_groups, group_len) pieces covering [0, D)."""
+    full = D // 16
+    if full:
+        yield 0, full, 16
+    if D % 16:
+        yield full * 16, 1, D % 16
+
+
+class Packer:
+    """Emits strided-copy records in both directions for one packed matrix:
+    pack   params(fp32)        -> packed weights (bf16 / f32)
+    unpack wgrad slabs (fp32)  -> flat grads (fp32), summing `slabs` partials."""
+
+    def __init__(self, ps: ParamStore, pack_tbl: CopyTableBuilder, unpack_tbl: CopyTableBuilder):
+        self.ps, self.pack_tbl, self.unpack_tbl = ps, pack_tbl, unpack_tbl
+
+    def rec(self, pname: str, p_off: int, p_strides: Sequence[int], dims: Sequence[int],
+            w_mat: Optional[Mat], w_off: int, w_strides: Sequence[int],
+            g_ptr: int = 0, g_strides: Optional[Sequence[int]] = None, slabs: int = 0, slab_stride: int = 0,
+            g_off: Optional[int] = None):
+        """One rectangular piece.  p_* address the parameter tensor (elements, relative to the
+        parameter), w_* the packed forward matrix, g_* the wgrad slab (defaults to the same
+        layout as the packed matrix)."""
+        ps = self.ps
+        if w_mat is not None:
+            self.pack_tbl.add(ps.ptr(pname) + 4 * p_off, w_mat.ptr + w_off * ESIZE[w_mat.dtype],
+                              dims, p_strides, w_strides, F3, w_mat.dtype)
+        if g_ptr:
+            gs = list(g_strides if g_strides is not None else w_strides)
+            go = w_off if g_off is None else g_off
+            self.unpack_tbl.add(g_ptr + 4 * go, ps.ptr(pname, grad=True) + 4 * p_off, dims, gs,
+                                p_strides, F3, F3, red_n=slabs, red_stride=slab_stride)
+
+
+# ------------------------------------------------------------------------------------------
+# decoder
+# ------------------------------------------------------------------------------------------
+class DecoderPlan:
+    """Conditioning path + gated stack + post network + NLL, forward and backward."""
+
+    def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, pre: str,
+                 n_lc_in: int, lc_src: Mat, wav: torch.Tensor, voice: torch.Tensor,
+                 jitter: torch.Tensor, take_compat: bool, packer: Packer, impl: int = 0):
+        self.ws, self.ps, self.hps, self.g, self.B, self.pre = ws, ps, hps, geom, B, pre
+        self.impl = impl
+        self.n_lc_in = n_lc_in
+        self.lc_src, self.wav, self.voice, self.jitter = lc_src, wav, voice, jitter
+        self.take_compat = take_compat
+        self.pk = packer
+        h = hps
+        self.R, self.D, self.S, self.P, self.Q = h.n_res, h.n_dil, h.n_skp, h.n_post, h.n_quant
+        self.Clc, self.Gc = h.n_lc_out, h.n_global_embed
+        self.Rp, self.Dp, self.Sp, self.Pp, self.Qp = (ru(v, 128) for v in (self.R, self.D, self.S, self.P, self.Q))
+        self.Cp, self.Lp = ru(self.Clc, 128), ru(n_lc_in, 128)
+        self.NL = len(geom.layers)
+        self.T, self.w = geom.dec_in_len, geom.n_win
+        self.Ne = geom.embed_len
+        self._alloc()
+        self._pack_records()
+
+    # -- buffers --------------------------------------------------------------------------
+    def _alloc(self):
+        ws, B, g = self.ws, self.B, self.g
+        p = self.pre
+        M = lambda n, rows, pitch, dt, cols=None: Mat.new(ws, p + n, B, rows, pitch, dt, cols)
+        self.lcj = M("lcj", self.Ne, self.Lp, BF)
+        self.lc_lens = g.lc_lens                      # [Ne, Ne-2, after each upsampler]
+        self.ups_in: List[Mat] = [M("lc1", self.lc_lens[1], self.Cp, BF)]
+        n_ups = len(self.hps.lc_upsample_strides)
+        for i in range(n_ups - 1):
+            self.ups_in.append(M(f"ups{i}", self.lc_lens[2 + i], self.Cp, BF))
+        self.cond = M("cond", self.T, self.Cp, BF)
+        self.bias_bl = ws.alloc(p + "bias_bl", B * self.NL * 2 * self.Dp, torch.float32)
+        self.gc = ws.alloc(p + "gc", B * self.Gc, torch.float32)
+        self.x: List[Mat] = [M(f"x{l}", lg.in_len, self.Rp, BF) for l, lg in enumerate(g.layers)]
+        self.z = [M(f"z{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
+        # local derivatives dz/dfilt, dz/dgate saved by the gated epilogue for backward
+        self.pf = [M(f"pf{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
+        self.pg = [M(f"pg{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
+        self.skp = M("skp", self.w, self.Sp, F3)
+        self.h0 = M("h0", self.w, self.Sp, BF)
+        self.h1 = M("h1", self.w, self.Pp, BF)
+        self.logits = M("logits", self.w, self.Qp, F3)
+        self.nll = ws.alloc(p + "nll", B * self.w, torch.float32)
+        self.ptgt = ws.alloc(p + "ptgt", B * self.w, torch.float32)
+        # backward
+        self.onehot = M("onehot", self.T, self.Qp, BF)
+        self.dlogits = M("dlogits", self.w, self.Qp, BF)
+        self.dh1 = M("dh1", self.w, self.Pp, BF)
+        self.dskp = M("dskp", self.w, self.Sp, BF)
+        self.dxa = M("dxa", self.T, self.Rp, BF)
+        self.dxb = M("dxb", self.T, self.Rp, BF)
+        self.dfg = [M(f"dfg{l}", lg.out_len, 2 * self.Dp, BF) for l, lg in enumerate(g.layers)]
+        self.colsum_fg = ws.alloc(p + "colsum_fg", B * self.NL * 2 * self.Dp, torch.float32)
+        self.dcond = M("dcond", self.T, self.Cp, BF)
+        self.dups = [M(f"d{m.name[len(p):]}", m.rows, self.Cp, BF) for m in self.ups_in]
+        self.dlcj = M("dlcj", self.Ne, self.Lp, F3)
+        # gradient w.r.t. the LC source (fp32, same shape as lc_src)
+        self.dlc_src = Mat.new(ws, p + "dlc_src", B, self.lc_src.rows, self.lc_src.pitch, F3)
+        # offset tables for the speaker-bias ops
+        offs = {k: [] for k in ("bs", "bg", "ps", "pg")}
+        for l in range(self.NL):
+            q = p + f"conv_layers.{l}."
+            offs["bs"].append(self.ps.off.get(q + "conv_signal.bias", -1))
+            offs["bg"].append(self.ps.off.get(q + "conv_gate.bias", -1))
+            offs["ps"].append(self.ps.off[q + "proj_signal.weight"])
+            offs["pg"].append(self.ps.off[q + "proj_gate.weight"])
+        self.off_tbl = {}
+        for k, v in offs.items():
+            t = ws.alloc(p + "off_" + k, self.NL, torch.int64)
+            t[:self.NL].copy_(torch.tensor(v, dtype=torch.int64))
+            self.off_tbl[k] = t
+
+    def _wmat(self, name, rows, cols, dt=BF) -> Mat:
+        return Mat.new(self.ws, self.pre + "wp." + name, 1, rows, cols, dt)
+
+    def _gslab(self, name, rows, cols, slabs) -> Tuple[int, int]:
+        t = self.ws.alloc(self.pre + "wg." + name, slabs * rows * cols, torch.float32)
+        return t.data_ptr(), rows * cols
+
+    # -- packed weight matrices and their pack/unpack records ------------------------------
+    def _pack_records(self):
+        pk, p, ps = self.pk, self.pre, self.ps
+        R, D, S, P, Q, Clc = self.R, self.D, self.S, self.P, self.Q, self.Clc
+        Rp, Dp, Sp, Pp, Qp, Cp, Lp = self.Rp, self.Dp, self.Sp, self.Pp, self.Qp, self.Cp, self.Lp
+        Cc = Clc + self.Gc
+        NL = self.NL
+        self.Wfg, self.Wrs, self.WrsT, self.WfgT = [], [], [], []
+        self.tn: Dict[str, L.GemmTN] = {}         # wgrad ops by name (built in build_backward)
+        self.gbuf: Dict[str, Tuple[int, int, int]] = {}  # name -> (ptr, slab stride, slabs)
+        Kfg = 2 * Rp + Cp
+        self.VfgT = self._wmat("VfgT", Cp, NL * 2 * Dp)
+        for l in range(NL):
+            last = l == NL - 1
+            q = p + f"conv_layers.{l}."
+            Wfg = self._wmat(f"fg{l}", 2 * Dp, Kfg)
+            WfgT = self._wmat(f"fgT{l}", Rp, 4 * Dp)
+            self.Wfg.append(Wfg); self.WfgT.append(WfgT)
+            for gate, nm in ((0, "signal"), (1, "gate")):
+                for co0, ng, gl in _gate_groups(D):
+                    row0 = (co0 // 16) * 32 + 16 * gate
+                    # conv weight [D][R][2] -> Wfg rows, tap-major K; and WfgT (dgrad) layout
+                    pk.rec(q + f"conv_{nm}.weight", co0 * R * 2, [16 * R * 2, R * 2, 2, 1], [ng, gl, R, 2],
+                           Wfg, row0 * Kfg, [32 * Kfg, Kfg, 1, Rp])
+                    pk.rec(q + f"conv_{nm}.weight", co0 * R * 2, [16 * R * 2, R * 2, 2, 1], [ng, gl, R, 2],
+                           WfgT, row0, [32, 1, 4 * Dp, 2 * Dp])
+                    # conditioning projection [D][Cc][1], first Clc columns only
+                    pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
+                           Wfg, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1])
+                    pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
+                           self.VfgT, l * 2 * Dp + row0, [32, 1, NL * 2 * Dp])
+            Nrs = Sp if last else Rp + Sp
+            Wrs = self._wmat(f"rs{l}", Nrs, Dp)
+            WrsT = self._wmat(f"rsT{l}", Dp, Nrs)
+            self.Wrs.append(Wrs); self.WrsT.append(WrsT)
+            so = 0 if last else Rp
+            if not last:
+                pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], Wrs, 0, [Dp, 1])
+                pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], WrsT, 0, [1, Nrs])
+            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], Wrs, so * Dp, [Dp, 1])
+            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], WrsT, so, [1, Nrs])
+        # post network
+        self.Wp1, self.Wp1T = self._wmat("p1", Pp, Sp), self._wmat("p1T", Sp, Pp)
+        self.Wp2, self.Wp2T = self._wmat("p2", Qp, Pp), self._wmat("p2T", Pp, Qp)
+        pk.rec(p + "post1.weight", 0, [S, 1], [P, S], self.Wp1, 0, [Sp, 1])
+        pk.rec(p + "post1.weight", 0, [S, 1], [P, S], self.Wp1T, 0, [1, Pp])
+        pk.rec(p + "post2.weight", 0, [P, 1], [Q, P], self.Wp2, 0, [Pp, 1])
+        pk.rec(p + "post2.weight", 0, [P, 1], [Q, P], self.Wp2T, 0, [1, Qp])
+        # fp32 bias vectors padded to N_pad
+        self.bias_vec: Dict[str, int] = {}
+        for nm, n, npad in (("post1", P, Pp), ("post2", Q, Qp), ("lc_conv", Clc, Cp)):
+            t = self.ws.alloc(p + "wp.bias." + nm, npad, torch.float32)
+            self.bias_vec[nm] = t.data_ptr()
+            if ps.has(p + nm + ".bias"):
+                pk.pack_tbl.add(ps.ptr(p + nm + ".bias"), t.data_ptr(), [n], [1], [1], F3, F3)
+        # LC conv [Clc][n_lc_in][3]
+        nin = self.n_lc_in
+        self.Wlc, self.WlcT = self._wmat("lc", Cp, 3 * Lp), self._wmat("lcT", Lp, 3 * Cp)
+        pk.rec(p + "lc_conv.weight", 0, [nin * 3, 3, 1], [Clc, nin, 3], self.Wlc, 0, [3 * Lp, 1, Lp])
+        pk.rec(p + "lc_conv.weight", 0, [nin * 3, 3, 1], [Clc, nin, 3], self.WlcT, 0, [1, 3 * Cp, Cp])
+        # upsamplers: ConvTranspose1d weight [ci][co][k]
+        self.Wup: List[List[Mat]] = []
+        self.WupT: List[Mat] = []
+        for i, (f, s) in enumerate(zip(self.hps.lc_upsample_filt_sizes, self.hps.lc_upsample_strides)):
+            nm = p + f"lc_upsample.{i}.tconv.weight"
+            phases = []
+            for ph in range(s):
+                Wm = self._wmat(f"up{i}.{ph}", Cp, (f // s) * Cp)
+                # [co][j*Cp + ci] <- W[ci][co][ph + s*j]
+                pk.rec(nm, ph, [f, Clc * f, s], [Clc, Clc, f // s], Wm, 0, [(f // s) * Cp, 1, Cp])
+                phases.append(Wm)
+            self.Wup.append(phases)
+            WT = self._wmat(f"upT{i}", Cp, f * Cp)
+            # [ci][k*Cp + co] <- W[ci][co][k]
+            pk.rec(nm, 0, [Clc * f, f, 1], [Clc, Clc, f], WT, 0, [f * Cp, 1, Cp])
+            self.WupT.append(WT)
+            t = self.ws.alloc(p + f"wp.bias.up{i}", Cp, torch.float32)
+            self.bias_vec[f"up{i}"] = t.data_ptr()
+            pk.pack_tbl.add(ps.ptr(p + f"lc_upsample.{i}.tconv.bias"), t.data_ptr(), [Clc], [1], [1], F3, F3)
+
+    # -- forward ---------------------------------------------------------------------------
+    def build_forward(self, plan: Plan, need_onehot: bool = True):
+        B, g, hps, p = self.B, self.g, self.hps, self.pre
+        Rp, Dp, Sp, Pp, Qp, Cp, Lp = self.Rp, self.Dp, self.Sp, self.Pp, self.Qp, self.Cp, self.Lp
+        impl = self.impl
+        # 1. jitter gather (wavenet.py:330-336)
+        lg_ = L.LcGather()
+        lg_.src, lg_.src_bs, lg_.src_pitch = self.lc_src.ptr, self.lc_src.bs, self.lc_src.pitch
+        lg_.jitter, lg_.jit_pitch = self.jitter.data_ptr(), self.jitter.shape[1]
+        lg_.dst, lg_.dst_bs, lg_.dst_pitch = self.lcj.ptr, self.lcj.bs, self.lcj.pitch
+        lg_.B, lg_.N, lg_.C, lg_.C_pad = B, self.Ne, self.n_lc_in, Lp
+        lg_.take_compat = int(self.take_compat)
+        plan.add(L.OP_LC_GATHER, lg_, "lc_gather", TAG_UPS)
+        # 2. LC conv k=3 (wavenet.py:337)
+        lc1 = self.ups_in[0]
+        plan.add(L.OP_GEMM_NT, make_nt(
+            BF, lc1.rows, Cp, Cp, B, [self.lcj.seg(Lp, row_off=t) for t in range(3)], self.Wlc.ptr,
+            flags=L.EF_BIAS, out0=lc1.view(), bias_ptr=self.bias_vec["lc_conv"], impl=impl), "lc_conv", TAG_UPS)
+        # 3. transposed-conv upsamplers as polyphase GEMMs (wavenet.py:154,338)
+        n_ups = len(hps.lc_upsample_strides)
+        for i, (f, s) in enumerate(zip(hps.lc_upsample_filt_sizes, hps.lc_upsample_strides)):
+            X = self.ups_in[i]
+            Lin, Lout, pad = X.rows, self.lc_lens[2 + i], f - s
+            last = i == n_ups - 1
+            trim0 = g.trim_ups_out[0] if last else 0
+            Y = self.cond if last else self.ups_in[i + 1]
+            for ph in range(s):
+                q0 = -((ph - pad) // s)                 # ceil((pad - ph)/s): first q with o >= 0
+                o0 = s * q0 + ph - pad
+                if o0 >= Lout:
+                    continue
+                Mq = (Lout - 1 - o0) // s + 1
+                segs = [X.seg(Cp, row_off=q0 - j) for j in range(f // s)]
+                plan.add(L.OP_GEMM_NT, make_nt(
+                    BF, Mq, Cp, Cp, B, segs, self.Wup[i][ph].ptr, flags=L.EF_BIAS,
+                    out0=Y.view(row_off=o0 - trim0, row_step=s), bias_ptr=self.bias_vec[f"up{i}"],
+                    impl=impl), f"ups{i}.ph{ph}", TAG_UPS)
+        # 4. speaker-conditioned gated bias (wavenet.py:127-140 folded)
+        sb = L.SpkBias()
+        self._fill_spk(sb)
+        sb.bias, sb.gc = self.bias_bl.data_ptr(), self.gc.data_ptr()
+        plan.add(L.OP_SPK_BIAS, sb, "spk_bias", TAG_MISC)
+        # 5. base layer = column gather (wavenet.py:348-351)
+        bg = L.BaseGather()
+        bg.wav, bg.wav_pitch, bg.wav_off = self.wav.data_ptr(), self.wav.shape[1], g.trim_dec_in[0]
+        bg.W = self.ps.ptr(p + "base_layer.weight")
+        bg.bias = self.ps.ptr(p + "base_layer.bias") if self.ps.has(p + "base_layer.bias") else None
+        bg.B, bg.T, bg.R, bg.R_pad, bg.Q = B, self.T, self.R, Rp, self.Q
+        bg.x, bg.x_bs, bg.x_pitch = self.x[0].ptr, self.x[0].bs, self.x[0].pitch
+        if need_onehot:
+            bg.onehot, bg.oh_bs, bg.oh_pitch, bg.Q_pad = self.onehot.ptr, self.onehot.bs, self.onehot.pitch, Qp
+        plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
+        # 6. gated dilated stack (wavenet.py:91-111, 355-357)
+        NL = self.NL
+        for l, lg in enumerate(g.layers):
+            last = l == NL - 1
+            x = self.x[l]
+            P_l = lg.out_len
+            segs = [x.seg(Rp), x.seg(Rp, row_off=lg.dil), self.cond.seg(Cp, row_off=lg.cond_lead)]
+            plan.add(L.OP_GEMM_NT, make_nt(
+                BF, P_l, Dp, 2 * Dp, B, segs, self.Wfg[l].ptr, epi=L.EPI_GATED,
+                out0=self.z[l].view(), out1=self.pf[l].view(), out2=self.pg[l].view(),
+                bias_ptr=self.bias_bl.data_ptr() + 4 * l * 2 * Dp, bias_bs=NL * 2 * Dp, impl=impl),
+                f"G1.{l}", TAG_G1)
+            flags = (L.EF_ACCUM if l > 0 else 0) | (L.EF_OUT2_RELU if last else 0)
+            skv = self.skp.view(row_off=-lg.skip_lead)
+            plan.add(L.OP_GEMM_NT, make_nt(
+                BF, P_l, Sp if last else Rp + Sp, Sp if last else Rp + Sp, B, [self.z[l].seg(Dp)],
+                self.Wrs[l].ptr, epi=L.EPI_RES_SKIP, flags=flags,
+                out0=null_view() if last else self.x[l + 1].view(),
+                aux0=null_view() if last else x.view(row_off=lg.dil),
+                out1=skv, out2=self.h0.view(row_off=-lg.skip_lead) if last else null_view(),
+                n_split=0 if last else Rp, impl=impl), f"G2.{l}", TAG_G2)
+        # 7. post network (wavenet.py:359-360)
+        plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Pp, Pp, B, [self.h0.seg(Sp)], self.Wp1.ptr,
+                                       flags=L.EF_BIAS | L.EF_RELU, out0=self.h1.view(),
+                                       bias_ptr=self.bias_vec["post1"], impl=impl), "post1", TAG_POST)
+        plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Qp, Qp, B, [self.h1.seg(Pp)], self.Wp2.ptr,
+                                       flags=L.EF_BIAS, out0=self.logits.view(),
+                                       bias_ptr=self.bias_vec["post2"], impl=impl), "post2", TAG_POST)
+        # 8. fused log-softmax + NLL (wavenet.py:543-547)
+        plan.add(L.OP_SOFTMAX_NLL, self._softmax(False, 0.0), "softmax_nll", TAG_LOSS)
+
+    def _fill_spk(self, sb):
+        p, ps = self.pre, self.ps
+        sb.params, sb.voice = ps.params.data_ptr(), self.voice.data_ptr()
+        sb.off_bias_sig, sb.off_bias_gate = self.off_tbl["bs"].data_ptr(), self.off_tbl["bg"].data_ptr()
+        sb.off_proj_sig, sb.off_proj_gate = self.off_tbl["ps"].data_ptr(), self.off_tbl["pg"].data_ptr()
+        sb.off_spk_w = ps.off[p + "cond.speaker_embedding.weight"]
+        sb.off_spk_b = ps.off.get(p + "cond.speaker_embedding.bias", -1)
+        sb.B, sb.L, sb.D, sb.D_pad, sb.C_lc, sb.G = self.B, self.NL, self.D, self.Dp, self.Clc, self.Gc
+        sb.n_speakers = self.hps.n_speakers
+
+    def _softmax(self, backward: bool, scale: float) -> L.SoftmaxNll:
+        sm = L.SoftmaxNll()
+        sm.logits, sm.bs, sm.pitch = self.logits.ptr, self.logits.bs, self.logits.pitch
+        sm.wav, sm.wav_pitch, sm.tgt_off = self.wav.data_ptr(), self.wav.shape[1], self.g.wav_out_off
+        sm.B, sm.w, sm.Q, sm.Q_pad = self.B, self.w, self.Q, self.Qp
+        sm.nll, sm.ptgt = self.nll.data_ptr(), self.ptgt.data_ptr()
+        sm.dlogits, sm.dl_bs, sm.dl_pitch = self.dlogits.ptr, self.dlogits.bs, self.dlogits.pitch
+        sm.scale, sm.backward = scale, int(backward)
+        return sm
+
+    # -- backward --------------------------------------------------------------------------
+    def _colsum(self, plan: Plan, X: Mat, M: int, N: int, out_ptr: int, out_bs: int = 0,
+                row_off: int = 0, label: str = "colsum"):
+        cs = L.Colsum()
+        cs.x = X.seg(128, row_off=row_off)
+        cs.dtype, cs.M, cs.N, cs.batch = X.dtype, M, N, self.B
+        cs.out, cs.out_bs, cs.accumulate = out_ptr, out_bs, 0
+        plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
+
+    def _wgrad(self, plan: Plan, name: str, dtype: int, Mc: int, N: int, N_pad: int, gseg: L.Seg,
+               segs: Sequence[L.Seg], tag: int) -> Tuple[int, int, int]:
+        t = make_tn(dtype, Mc, self.B, N, N_pad, gseg, segs, impl=self.impl)
+        slabs = L.tn_slabs(t)
+        ptr, stride = self._gslab(name, N_pad, t.K_total, slabs)
+        t.out, t.out_batch_stride = ptr, stride
+        plan.add(L.OP_GEMM_TN, t, "wgrad." + name, tag)
+        self.gbuf[name] = (ptr, stride, slabs)
+        return ptr, stride, slabs
+
+    def build_backward(self, plan: Plan, nll_scale: float):
+        """nll_scale = d(loss)/d(per-position nll): 1/(B*(w-1)) for mean-type losses, 1 for
+        sum-type (times the upstream gradient)."""
+        B, g, hps, p, ps = self.B, self.g, self.hps, self.pre, self.ps
+        R, D, S, P, Q, Clc = self.R, self.D, self.S, self.P, self.Q, self.Clc
+        Rp, Dp, Sp, Pp, Qp, Cp, Lp = self.Rp, self.Dp, self.Sp, self.Pp, self.Qp, self.Cp, self.Lp
+        impl, NL, w, T = self.impl, self.NL, self.w, self.T
+        pk = self.pk
+        plan.add(L.OP_SOFTMAX_NLL, self._softmax(True, nll_scale), "softmax_grad", TAG_LOSS)
+        # ---- post network
+        if ps.has(p + "post2.bias"):
+            self._colsum(plan, self.dlogits, w, Q, ps.ptr(p + "post2.bias", True), label="db.post2")
+        gp, gs, gn = self._wgrad(plan, "p2", BF, w, Q, Qp, self.dlogits.seg(Qp), [self.h1.seg(Pp)], TAG_POST)
+        pk.rec(p + "post2.weight", 0, [P, 1], [Q, P], None, 0, [Pp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+        plan.add(L.OP_GEMM_NT, make_nt(BF, w, Pp, Pp, B, [self.dlogits.seg(Qp)], self.Wp2T.ptr,
+                                       flags=L.EF_MUL_POS1, out0=self.dh1.view(), aux1=self.h1.view(),
+                                       impl=impl), "d.post2", TAG_POST)
+        if ps.has(p + "post1.bias"):
+            self._colsum(plan, self.dh1, w, P, ps.ptr(p + "post1.bias", True), label="db.post1")
+        gp, gs, gn = self._wgrad(plan, "p1", BF, w, P, Pp, self.dh1.seg(Pp), [self.h0.seg(Sp)], TAG_POST)
+        pk.rec(p + "post1.weight", 0, [S, 1], [P, S], None, 0, [Sp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+        plan.add(L.OP_GEMM_NT, make_nt(BF, w, Sp, Sp, B, [self.dh1.seg(Pp)], self.Wp1T.ptr,
+                                       flags=L.EF_MUL_POS1, out0=self.dskp.view(), aux1=self.h0.view(),
+                                       impl=impl), "d.post1", TAG_POST)
+        # ---- gated stack, last layer first
+        Kfg = 2 * Rp + Cp
+        Cc = Clc + self.Gc
+        dx_next: Optional[Mat] = None
+        bufs = [self.dxa, self.dxb]
+        for l in range(NL - 1, -1, -1):
+            lg = g.layers[l]
+            last = l == NL - 1
+            P_l, d = lg.out_len, lg.dil
+            q = p + f"conv_layers.{l}."
+            segs = []
+            if not last:
+                segs.append(dx_next.seg(Rp, hi=P_l))
+            segs.append(self.dskp.seg(Sp, row_off=-lg.skip_lead))
+            plan.add(L.OP_GEMM_NT, make_nt(BF, P_l, Dp, Dp, B, segs, self.WrsT[l].ptr, epi=L.EPI_DFG,
+                                           aux0=self.pf[l].view(), aux1=self.pg[l].view(),
+                                           out0=self.dfg[l].view(), impl=impl), f"dz.{l}", TAG_DZ)
+            if not last:
+                gp, gs, gn = self._wgrad(plan, f"res{l}", BF, P_l, R, Rp, dx_next.seg(Rp, hi=P_l),
+                                         [self.z[l].seg(Dp)], TAG_WG_RS)
+                pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+            gp, gs, gn = self._wgrad(plan, f"skp{l}", BF, w, S, Sp, self.dskp.seg(Sp),
+                                     [self.z[l].seg(Dp, row_off=lg.skip_lead)], TAG_WG_RS)
+            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+            self._colsum(plan, self.dfg[l], P_l, 2 * Dp, self.colsum_fg.data_ptr() + 4 * l * 2 * Dp,
+                         out_bs=NL * 2 * Dp, label=f"colsum.dfg{l}")
+            x = self.x[l]
+            gp, gs, gn = self._wgrad(plan, f"fg{l}", BF, P_l, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp),
+                                     [x.seg(Rp), x.seg(Rp, row_off=d), self.cond.seg(Cp, row_off=lg.cond_lead)],
+                                     TAG_WG_FG)
+            for gate, nm in ((0, "signal"), (1, "gate")):
+                for co0, ng, gl in _gate_groups(D):
+                    row0 = (co0 // 16) * 32 + 16 * gate
+                    pk.rec(q + f"conv_{nm}.weight", co0 * R * 2, [16 * R * 2, R * 2, 2, 1], [ng, gl, R, 2],
+                           None, row0 * Kfg, [32 * Kfg, Kfg, 1, Rp], g_ptr=gp, slabs=gn, slab_stride=gs)
+                    pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
+                           None, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+            dx = bufs[l & 1]
+            segs = [self.dfg[l].seg(2 * Dp), self.dfg[l].seg(2 * Dp, row_off=-d)]
+            plan.add(L.OP_GEMM_NT, make_nt(
+                BF, lg.in_len, Rp, Rp, B, segs, self.WfgT[l].ptr,
+                flags=0 if last else L.EF_ADD_AUX0,
+                out0=dx.view(hi=lg.in_len),
+                aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=impl), f"dx.{l}", TAG_DX)
+            dx_next = dx
+        dx0 = dx_next
+        # ---- base layer (wavenet.py:351)
+        if ps.has(p + "base_layer.bias"):
+            self._colsum(plan, dx0, T, R, ps.ptr(p + "base_layer.bias", True), label="db.base")
+        gp, gs, gn = self._wgrad(plan, "base", BF, T, R, Rp, dx0.seg(Rp), [self.onehot.seg(Qp)], TAG_MISC)
+        pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], None, 0, [Qp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+        # ---- conditioning gradient: one GEMM over all layers' dfg (wavenet.py:100-101 cond terms)
+        segs = [self.dfg[l].seg(2 * Dp, row_off=-lg.cond_lead) for l, lg in enumerate(g.layers)]
+        plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT.ptr, out0=self.dcond.view(),
+                                       impl=impl), "dcond", TAG_DCOND)
+        # ---- speaker / gated-bias gradients
+        sbw = L.SpkBwd()
+        self._fill_spk(sbw)
+        sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
+        plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC)
+        # ---- upsamplers, last stage first (wavenet.py:154)
+        n_ups = len(hps.lc_upsample_strides)
+        for i in range(n_ups - 1, -1, -1):
+            f, s = hps.lc_upsample_filt_sizes[i], hps.lc_upsample_strides[i]
+            pad = f - s
+            X, dX = self.ups_in[i], self.dups[i]
+            last = i == n_ups - 1
+            dY = self.dcond if last else self.dups[i + 1]
+            trim0 = g.trim_ups_out[0] if last else 0
+            self._colsum(plan, dY, dY.rows, Clc, ps.ptr(p + f"lc_upsample.{i}.tconv.bias", True),
+                         label=f"db.up{i}")
+            segs = [dY.seg(Cp, row_step=s, row_off=k - pad - trim0) for k in range(f)]
+            gp, gs, gn = self._wgrad(plan, f"up{i}", BF, X.rows, Clc, Cp, X.seg(Cp), segs, TAG_UPS)
+            pk.rec(p + f"lc_upsample.{i}.tconv.weight", 0, [Clc * f, f, 1], [Clc, Clc, f], None, 0,
+                   [f * Cp, 1, Cp], g_ptr=gp, slabs=gn, slab_stride=gs)
+            plan.add(L.OP_GEMM_NT, make_nt(BF, X.rows, Cp, Cp, B, segs, self.WupT[i].ptr, out0=dX.view(),
+                                           impl=impl), f"d.ups{i}", TAG_UPS)
+        # ---- LC conv (wavenet.py:337)
+        dlc1, lc1 = self.dups[0], self.ups_in[0]
+        if ps.has(p + "lc_conv.bias"):
+            self._colsum(plan, dlc1, lc1.rows, Clc, ps.ptr(p + "lc_conv.bias", True), label="db.lc")
+        nin = self.n_lc_in
+        gp, gs, gn = self._wgrad(plan, "lc", BF, lc1.rows, Clc, Cp, dlc1.seg(Cp),
+                                 [self.lcj.seg(Lp, row_off=t) for t in range(3)], TAG_UPS)
+        pk.rec(p + "lc_conv.weight", 0, [nin * 3, 3, 1], [Clc, nin, 3], None, 0, [3 * Lp, 1, Lp],
+               g_ptr=gp, slabs=gn, slab_stride=gs)
+        plan.add(L.OP_GEMM_NT, make_nt(BF, self.Ne, ru(nin, 4), Lp, B,
+                                       [dlc1.seg(Cp, row_off=-t) for t in range(3)], self.WlcT.ptr,
+                                       out0=self.dlcj.view(), impl=impl), "d.lc_conv", TAG_UPS)
+        # ---- jitter scatter back to the LC source
+        plan.zero(self.ws, self.dlc_src.name)
+        sc = L.LcScatter()
+        sc.d, sc.d_bs, sc.d_pitch = self.dlcj.ptr, self.dlcj.bs, self.dlcj.pitch
+        sc.jitter, sc.jit_pitch = self.jitter.data_ptr(), self.jitter.shape[1]
+        sc.dsrc, sc.dsrc_bs, sc.dsrc_pitch = self.dlc_src.ptr, self.dlc_src.bs, self.dlc_src.pitch
+        sc.B, sc.N, sc.C, sc.take_compat = B, self.Ne, nin, int(self.take_compat)
+        plan.add(L.OP_LC_SCATTER, sc, "lc_scatter", TAG_UPS)
+
+
+# ------------------------------------------------------------------------------------------
+# encoder + bottleneck (fp32 exact chain)
+# ------------------------------------------------------------------------------------------
+class EncoderPlan:
+    def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, n_mel: int,
+                 mel_cl: Mat, packer: Packer, impl: int = 0):
+        self.ws, self.ps, self.hps, self.g, self.B, self.impl = ws, ps, hps, geom, B, impl
+        self.pk = packer
+        self.n_mel, self.Mp = n_mel, ru(n_mel, 64)
+        self.E, self.Ep = hps.enc_n_out, ru(hps.enc_n_out, 64)
+        self.lens = geom.enc_lens                      # 10 entries
+        self.y: List[Mat] = [mel_cl]
+        self.r: List[Optional[Mat]] = [None]
+        for i in range(9):
+            self.y.append(Mat.new(ws, f"enc.y{i + 1}", B, self.lens[i + 1], self.Ep, F3))
+            self.r.append(Mat.new(ws, f"enc.r{i + 1}", B, self.lens[i + 1], self.Ep, F3))
+        self.dy = [Mat.new(ws, f"enc.dy{i}", B, self.lens[i], self.Mp if i == 0 else self.Ep, F3) for i in range(10)]
+        self.dpre = [None] + [Mat.new(ws, f"enc.dpre{i}", B, self.lens[i], self.Ep, F3) for i in range(1, 10)]
+        self.zero_cnt = ws.alloc("enc.zero_cnt", 9, torch.int64)
+        self.W, self.WT, self.bias = [], [], []
+        cin, cinp = n_mel, self.Mp
+        E, Ep = self.E, self.Ep
+        for i, (f, s) in enumerate(zip(G.ENCODER_FILTERS, G.ENCODER_STRIDES)):
+            nm = f"encoder.net.{i}.conv."
+            Wm = Mat.new(ws, f"enc.wp.{i}", 1, Ep, f * cinp, F3)
+            packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], Wm, 0, [f * cinp, 1, cinp])
+            self.W.append(Wm)
+            if s == 1:
+                WT = Mat.new(ws, f"enc.wpT.{i}", 1, cinp, f * Ep, F3)
+                packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], WT, 0, [1, f * Ep, Ep])
+                self.WT.append([WT])
+            else:
+                phs = []
+                for ph in range(s):
+                    WT = Mat.new(ws, f"enc.wpT.{i}.{ph}", 1, cinp, (f // s) * Ep, F3)
+                    # [ci][j*Ep + co] <- W[co][ci][ph + s*j]
+                    packer.rec(nm + "weight", ph, [cin * f, f, s], [E, cin, f // s], WT, 0, [1, (f // s) * Ep, Ep])
+                    phs.append(WT)
+                self.WT.append(phs)
+            bt = ws.alloc(f"enc.wp.bias{i}", Ep, torch.float32)
+            packer.pack_tbl.add(ps.ptr(nm + "bias"), bt.data_ptr(), [E], [1], [1], F3, F3)
+            self.bias.append(bt)
+            cin, cinp = E, Ep
+        self.gbuf = {}
+
+    def build_forward(self, plan: Plan):
+        B, impl, Ep = self.B, self.impl, self.Ep
+        plan.zero(self.ws, "enc.zero_cnt")
+        cinp = self.Mp
+        for i, (f, s, res) in enumerate(zip(G.ENCODER_FILTERS, G.ENCODER_STRIDES, G.ENCODER_RESIDUAL)):
+            X, Y, Rm = self.y[i], self.y[i + 1], self.r[i + 1]
+            segs = [X.seg(cinp, row_step=s, row_off=k) for k in range(f)]
+            flags = L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE | L.EF_COUNT_ZERO | (L.EF_ADD_AUX0 if res else 0)
+            plan.add(L.OP_GEMM_NT, make_nt(
+                F3, Y.rows, self.E, Ep, B, segs, self.W[i].ptr, flags=flags, out0=Y.view(), out1=Rm.view(),
+                aux0=X.view(row_off=(f - 1) // 2) if res else null_view(), bias_ptr=self.bias[i].data_ptr(),
+                counter_ptr=self.zero_cnt.data_ptr() + 8 * i, impl=impl), f"enc.{i}", TAG_ENC)
+            cinp = Ep
+
+    def build_backward(self, plan: Plan, need_input_grad: bool = True):
+        """Expects dy[9] and dpre[9] already written (by the bottleneck backward)."""
+        B, impl, E, Ep, ps, pk = self.B, self.impl, self.E, self.Ep, self.ps, self.pk
+        for i in range(8, -1, -1):
+            f, s, res = G.ENCODER_FILTERS[i], G.ENCODER_STRIDES[i], G.ENCODER_RESIDUAL[i]
+            X = self.y[i]
+            cin, cinp = (self.n_mel, self.Mp) if i == 0 else (E, Ep)
+            dpre, dyo = self.dpre[i + 1], self.dy[i + 1]
+            Lo = dpre.rows
+            cs = L.Colsum()
+            cs.x = dpre.seg(64)
+            cs.dtype, cs.M, cs.N, cs.batch = F3, Lo, E, B
+            cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 0
+            plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
+            t = make_tn(F3, Lo, B, E, Ep, dpre.seg(64), [X.seg(cinp, row_step=s, row_off=k) for k in range(f)],
+                        impl=impl)
+            slabs = L.tn_slabs(t)
+            gt = self.ws.alloc(f"enc.wg.{i}", slabs * Ep * t.K_total, torch.float32)
+            t.out, t.out_batch_stride = gt.data_ptr(), Ep * t.K_total
+            plan.add(L.OP_GEMM_TN, t, f"wgrad.enc{i}", TAG_ENC)
+            pk.rec(f"encoder.net.{i}.conv.weight", 0, [cin * f, f, 1], [E, cin, f], None, 0,
+                   [f * cinp, 1, cinp], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=Ep * t.K_total)
+            if i == 0 and not need_input_grad:
+                continue
+            dX = self.dy[i]
+            Li = dX.rows
+            lw = (f - 1) // 2
+            for ph in range(s):
+                Mq = (Li - ph + s - 1) // s
+                if Mq <= 0:
+                    continue
+                segs = [dpre.seg(Ep, row_off=-j) for j in range(f // s)] if s > 1 else \
+                       [dpre.seg(Ep, row_off=-k) for k in range(f)]
+                flags = (L.EF_ADD_AUX0 if res else 0) | (L.EF_OUT1_POS1 if i > 0 else 0)
+                plan.add(L.OP_GEMM_NT, make_nt(
+                    F3, Mq, ru(cin, 4), cinp, B, segs, self.WT[i][ph].ptr, flags=flags,
+                    out0=dX.view(row_step=s, row_off=ph),
+                    out1=self.dpre[i].view(row_step=s, row_off=ph) if i > 0 else null_view(),
+                    aux0=dyo.view(row_step=s, row_off=ph - lw) if res else null_view(),
+                    aux1=self.r[i].view(row_step=s, row_off=ph) if i > 0 else null_view(), impl=impl),
+                    f"d.enc{i}.ph{ph}", TAG_ENC)

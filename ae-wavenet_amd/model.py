@@ -1,0 +1,384 @@
+"""Training-step engine behind the drop-in module surfaces.
+
+`TrainEngine` owns the workspace, the flat parameter / gradient buffers and the forward /
+backward / optimizer plans for one (model, batch size, window).  `autoencoder_model.AutoEncoder`
+and `mfcc_inverter.MfccInverter` wrap it in the reference's nn.Module surface
+(autoencoder_model.py:206-259, mfcc_inverter.py:89-108); `bench.py` drives it directly.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import geometry as G
+from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC,
+                     TAG_LOSS, TAG_MISC, TAG_PACK, TAG_VQ, bottleneck_param_specs,
+                     decoder_param_specs, encoder_param_specs)
+from .plan import CopyTableBuilder, Mat, Plan, Workspace, make_nt, make_tn, null_view, ru
+
+MEAN_LOSS = {"none": True, "ae": True, "vae": True, "vqvae": False, "vqvae-ema": False}
+
+
+class TrainEngine:
+    """kind: 'autoencoder' | 'mfcc_inverter'.
+
+    loss_mode (vqvae-ema only): 'intended' = rec.sum() + com.sum() (vqema_bn.py:244);
+    'head' = commitment only, the debug state HEAD ships (vqema_bn.py:246, SURVEY C-3).
+    take_compat: reproduce the reference's torch.take jitter gather (SURVEY C-1).
+    update_codebook_every_step: refresh emb from the EMA statistics each step (standard
+    VQ-VAE-EMA); the reference only refreshes at global_step == 10000 (chassis.py:175-176).
+    """
+
+    def __init__(self, hps, B: int, device, n_mel: Optional[int] = None, loss_mode: str = "intended",
+                 take_compat: bool = False, update_codebook_every_step: bool = True, impl: int = 0,
+                 n_win: Optional[int] = None):
+        self.hps, self.B, self.impl = hps, B, impl
+        self.kind = hps.global_model
+        self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
+        self.loss_mode, self.take_compat = loss_mode, take_compat
+        self.update_codebook_every_step = update_codebook_every_step
+        self.device = torch.device(device)
+        self.n_win = n_win or hps.n_win_batch
+        with_enc = self.kind == "autoencoder"
+        self.geom = G.model_geometry(hps, with_enc, self.n_win)
+        self.n_mel = n_mel if n_mel is not None else hps.n_lc_in if not with_enc else 3 * hps.n_mfcc
+        self.ws = ws = Workspace(self.device)
+        g = self.geom
+        # ---- parameters
+        dec_pre = "decoder." if with_enc else "wavenet."
+        specs = []
+        if with_enc:
+            specs += encoder_param_specs(self.n_mel, hps.enc_n_out)
+            specs += bottleneck_param_specs(hps)
+        specs += decoder_param_specs(hps, hps.n_lc_in, dec_pre)
+        self.ps = ps = ParamStore(ws, specs)
+        self.dec_pre = dec_pre
+        # ---- static inputs
+        self.in_wav = ws.alloc("in.wav", B * g.enc_in_len, torch.float32)[:B * g.enc_in_len].view(B, g.enc_in_len)
+        self.in_mel = ws.alloc("in.mel", B * self.n_mel * g.mel_len, torch.float32)[:B * self.n_mel * g.mel_len] \
+            .view(B, self.n_mel, g.mel_len)
+        self.in_voice = ws.alloc("in.voice", B, torch.int64)[:B]
+        self.in_jitter = ws.alloc("in.jitter", B * g.embed_len, torch.int64)[:B * g.embed_len].view(B, g.embed_len)
+        self.loss_buf = ws.alloc("loss", 8, torch.float32)
+        # ---- tables
+        self.pack_tbl = CopyTableBuilder(ws, "tbl.pack")
+        self.unpack_tbl = CopyTableBuilder(ws, "tbl.unpack")
+        self.in_tbl = CopyTableBuilder(ws, "tbl.in")
+        self.pk = Packer(ps, self.pack_tbl, self.unpack_tbl)
+        Mp = ru(self.n_mel, 64)
+        self.mel_cl = Mat.new(ws, "mel_cl", B, g.mel_len, Mp, F3)
+        self.in_tbl.add(self.in_mel.data_ptr(), self.mel_cl.ptr, [B, g.mel_len, self.n_mel],
+                        [self.n_mel * g.mel_len, 1, g.mel_len], [self.mel_cl.bs, Mp, 1], F3, F3)
+        # ---- sub-plans
+        self.enc: Optional[EncoderPlan] = None
+        if with_enc:
+            self.enc = EncoderPlan(ws, ps, hps, g, B, self.n_mel, self.mel_cl, self.pk, impl)
+            self._alloc_bottleneck()
+            lc_src = self.code
+        else:
+            lc_src = self.mel_cl
+        self.dec = DecoderPlan(ws, ps, hps, g, B, dec_pre, hps.n_lc_in, lc_src, self.in_wav, self.in_voice,
+                               self.in_jitter, take_compat, self.pk, impl)
+        self._build()
+        self.adam_state = None
+        self.step_count = 0
+
+    # --------------------------------------------------------------------------------------
+    def _alloc_bottleneck(self):
+        ws, hps, B, g = self.ws, self.hps, self.B, self.geom
+        bn, E, d = self.bn_type, hps.enc_n_out, hps.bn_n_out
+        self.d, self.dp = d, ru(d, 64)
+        Ne = g.embed_len
+        self.Q = B * Ne
+        Ep = ru(E, 64)
+        nlin = 2 * d if bn == "vae" else d
+        self.nlin, self.nlin_p = nlin, ru(nlin, 64)
+        self.lin = Mat.new(ws, "bn.lin", B, Ne, self.nlin_p, F3)          # ze / (mu|logvar)
+        self.Wl = Mat.new(ws, "bn.wp.lin", 1, self.nlin_p, Ep, F3)
+        self.WlT = Mat.new(ws, "bn.wp.linT", 1, Ep, self.nlin_p, F3)
+        self.pk.rec("bottleneck.linear.weight", 0, [E, 1], [nlin, E], self.Wl, 0, [Ep, 1])
+        self.pk.rec("bottleneck.linear.weight", 0, [E, 1], [nlin, E], self.WlT, 0, [1, self.nlin_p])
+        self.dlin = Mat.new(ws, "bn.dlin", B, Ne, self.nlin_p, F3)
+        if bn in ("vqvae-ema", "vqvae"):
+            K = hps.bn_vq_n_embed
+            self.K = K
+            self.code = Mat.new(ws, "bn.zq", B, Ne, self.dp, F3)
+            self.ind = ws.alloc("bn.ind", self.Q, torch.int64)
+            self.min_dist = ws.alloc("bn.min_dist", self.Q, torch.float32)
+            if bn == "vqvae-ema":
+                self.emb = ws.alloc("bn.emb", K * d, torch.float32)[:K * d].view(K, d)
+                self.ema_numer = ws.alloc("bn.ema_numer", K * d, torch.float32)[:K * d].view(K, d)
+                self.ema_denom = ws.alloc("bn.ema_denom", K, torch.float32)[:K]
+                self.z_sum = ws.alloc("bn.z_sum", K * d, torch.float32)[:K * d].view(K, d)
+                self.n_sum = ws.alloc("bn.n_sum", K, torch.float32)[:K]
+                self.ind_hist = ws.alloc("bn.ind_hist", K, torch.float32)[:K]
+            else:
+                self.emb = self.ps.view("bottleneck.emb")
+        elif bn == "vae":
+            self.code = Mat.new(ws, "bn.sample", B, Ne, self.dp, F3)
+            self.eps = ws.alloc("bn.eps", self.Q * d, torch.float32)[:self.Q * d].view(B, Ne, d)
+            self.kl_terms = ws.alloc("bn.kl_terms", self.Q, torch.float32)
+            self.anneal_weight = 0.0
+        elif bn == "ae":
+            self.code = self.lin
+            self.norm_terms = ws.alloc("bn.norm_terms", self.Q, torch.float32)
+            bt = ws.alloc("bn.wp.bias", self.nlin_p, torch.float32)
+            self.pack_tbl.add(self.ps.ptr("bottleneck.linear.bias"), bt.data_ptr(), [d], [1], [1], F3, F3)
+            self.lin_bias = bt
+        else:
+            raise ValueError(f"unknown bn_type {bn}")
+
+    # --------------------------------------------------------------------------------------
+    def _build(self):
+        ws, hps, B, g, ps, impl = self.ws, self.hps, self.B, self.geom, self.ps, self.impl
+        bn = self.bn_type
+        w = self.n_win
+        n_pos = B * (w - 1)
+        # ===== forward, part A: pack, inputs, encoder, bottleneck up to the EMA statistics
+        self.fwd_a = fa = Plan("fwd_a")
+        self.fwd_b = fb = Plan("fwd_b")
+        pack_slot = len(fa.ops)
+        self.in_tbl.emit(fa, "mel->channels-last")
+        if self.enc is not None:
+            self.enc.build_forward(fa)
+            E, Ep = hps.enc_n_out, ru(hps.enc_n_out, 64)
+            y9 = self.enc.y[9]
+            flags = L.EF_BIAS if bn == "ae" else 0
+            fa.add(L.OP_GEMM_NT, make_nt(F3, g.embed_len, ru(self.nlin, 4), self.nlin_p, B, [y9.seg(Ep)],
+                                         self.Wl.ptr, flags=flags, out0=self.lin.view(),
+                                         bias_ptr=self.lin_bias.data_ptr() if bn == "ae" else 0, impl=impl),
+                   "bn.linear", TAG_VQ)
+            if bn in ("vqvae-ema", "vqvae"):
+                vq = L.VqNearest()
+                vq.ze, vq.emb = self.lin.ptr, self.emb.data_ptr()
+                vq.Q, vq.K, vq.d, vq.d_pitch = self.Q, self.K, self.d, self.nlin_p
+                vq.metric = 0 if bn == "vqvae-ema" else 1
+                vq.ind, vq.dist, vq.zq = self.ind.data_ptr(), self.min_dist.data_ptr(), self.code.ptr
+                assert self.dp == self.nlin_p
+                fa.add(L.OP_VQ_NEAREST, vq, "vq.nearest", TAG_VQ)
+                if bn == "vqvae-ema":
+                    st = L.VqStats()
+                    st.ze, st.ind = self.lin.ptr, self.ind.data_ptr()
+                    st.Q, st.K, st.d, st.d_pitch = self.Q, self.K, self.d, self.nlin_p
+                    st.z_sum, st.n_sum, st.hist = self.z_sum.data_ptr(), self.n_sum.data_ptr(), self.ind_hist.data_ptr()
+                    fa.add(L.OP_VQ_STATS, st, "vq.stats", TAG_VQ)
+                    em = L.VqEma()
+                    em.numer, em.denom = self.ema_numer.data_ptr(), self.ema_denom.data_ptr()
+                    em.z_sum, em.n_sum, em.emb = self.z_sum.data_ptr(), self.n_sum.data_ptr(), self.emb.data_ptr()
+                    em.K, em.d, em.update_codebook = self.K, self.d, 0
+                    em.gamma = float(hps.bn_vq_ema_gamma)
+                    em.gamma_comp = float(1.0 - hps.bn_vq_ema_gamma)
+                    # EMA runs at the START of part B (after the optional cross-rank sum); the
+                    # codebook refresh is deferred to after backward so that forward and backward
+                    # of one step see the same emb
+                    fb.add(L.OP_VQ_EMA, em, "vq.ema", TAG_VQ)
+            elif bn == "vae":
+                va = self._vae_op(False)
+                fa.add(L.OP_VAE, va, "vae.sample", TAG_VQ)
+            elif bn == "ae":
+                an = self._ae_norm_op(False)
+                fa.add(L.OP_AE_NORM, an, "ae.norm", TAG_VQ)
+        # ===== forward, part B: decoder + loss
+        self.dec.build_forward(fb)
+        red = L.Reduce()
+        nll_ptr = self.dec.nll.data_ptr()
+        terms = []
+        if bn in ("none",):
+            terms = [(nll_ptr, B * w, 1.0 / n_pos)]
+        elif bn == "vqvae-ema":
+            com = (self.min_dist.data_ptr(), self.Q, float(hps.bn_vq_gamma))
+            terms = [com] if self.loss_mode == "head" else [(nll_ptr, B * w, 1.0), com]
+        elif bn == "vqvae":
+            terms = [(nll_ptr, B * w, 1.0), (self.min_dist.data_ptr(), self.Q, 1.0 + float(hps.bn_vq_gamma))]
+        elif bn == "vae":
+            terms = [(nll_ptr, B * w, 1.0 / n_pos), (self.kl_terms.data_ptr(), self.Q, -0.5)]
+        elif bn == "ae":
+            terms = [(nll_ptr, B * w, 1.0 / n_pos), (self.norm_terms.data_ptr(), self.Q, 0.001 / self.Q)]
+        red.n_terms = len(terms)
+        for i, (p_, n_, s_) in enumerate(terms):
+            red.x[i], red.n[i], red.scale[i] = p_, n_, s_
+            red.post_scale[i] = 1.0
+        if bn == "vae":
+            red.clamp[1], red.clamp_min[1], red.post_scale[1] = 1, float(hps.bn_free_nats), 0.0
+            self._red_index = len(fb.ops)
+        red.out = self.loss_buf.data_ptr()
+        fb.add(L.OP_REDUCE, red, "loss", TAG_LOSS)
+        # ===== backward
+        self.bwd = bw = Plan("bwd")
+        bw.zero(ws, "grads")
+        mean = MEAN_LOSS[bn]
+        nll_scale = (1.0 / n_pos) if mean else 1.0
+        if bn == "vqvae-ema" and self.loss_mode == "head":
+            nll_scale = 0.0
+        self.dec.build_backward(bw, nll_scale)
+        if self.enc is not None:
+            dcode = self.dec.dlc_src                      # d(loss)/d(code) [B][Ne][dp]
+            Ep = ru(hps.enc_n_out, 64)
+            y9 = self.enc.y[9]
+            if bn in ("vqvae-ema", "vqvae"):
+                vb = L.VqBwd()
+                vb.ze, vb.emb, vb.ind, vb.dzq = self.lin.ptr, self.emb.data_ptr(), self.ind.data_ptr(), dcode.ptr
+                vb.Q, vb.d, vb.d_pitch = self.Q, self.d, self.nlin_p
+                vb.metric = 0 if bn == "vqvae-ema" else 1
+                vb.coef = float(hps.bn_vq_gamma)
+                vb.demb_coef = 1.0
+                vb.dze = self.dlin.ptr
+                vb.demb = ps.ptr("bottleneck.emb", True) if bn == "vqvae" else None
+                bw.add(L.OP_VQ_BWD, vb, "vq.bwd", TAG_VQ)
+            elif bn == "vae":
+                self._vae_bwd_index = len(bw.ops)
+                bw.add(L.OP_VAE, self._vae_op(True, dcode), "vae.bwd", TAG_VQ)
+            elif bn == "ae":
+                bw.add(L.OP_AE_NORM, self._ae_norm_op(True, dcode), "ae.norm.bwd", TAG_VQ)
+                cs = L.Colsum()
+                cs.x = self.dlin.seg(64)
+                cs.dtype, cs.M, cs.N, cs.batch = F3, g.embed_len, self.d, B
+                cs.out, cs.out_bs, cs.accumulate = ps.ptr("bottleneck.linear.bias", True), 0, 0
+                bw.add(L.OP_COLSUM, cs, "db.bn", TAG_VQ)
+            # linear wgrad / dgrad
+            t = make_tn(F3, g.embed_len, B, self.nlin, self.nlin_p, self.dlin.seg(64), [y9.seg(Ep)], impl=impl)
+            slabs = L.tn_slabs(t)
+            gt = ws.alloc("bn.wg.lin", slabs * self.nlin_p * Ep, torch.float32)
+            t.out, t.out_batch_stride = gt.data_ptr(), self.nlin_p * Ep
+            bw.add(L.OP_GEMM_TN, t, "wgrad.bn.linear", TAG_VQ)
+            self.pk.rec("bottleneck.linear.weight", 0, [hps.enc_n_out, 1], [self.nlin, hps.enc_n_out], None, 0,
+                        [Ep, 1], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=self.nlin_p * Ep)
+            bw.add(L.OP_GEMM_NT, make_nt(F3, g.embed_len, hps.enc_n_out, Ep, B, [self.dlin.seg(self.nlin_p)],
+                                         self.WlT.ptr, flags=L.EF_OUT1_POS1, out0=self.enc.dy[9].view(),
+                                         out1=self.enc.dpre[9].view(), aux1=self.enc.r[9].view(), impl=impl),
+                   "d.bn.linear", TAG_VQ)
+            self.enc.build_backward(bw, need_input_grad=True)
+        self.unpack_tbl.emit(bw, "unpack grads")
+        if bn == "vqvae-ema":
+            # deferred codebook refresh (vqema_bn.py:216-222)
+            self.cb = Plan("codebook")
+            em = L.VqEma()
+            em.numer, em.denom = self.ema_numer.data_ptr(), self.ema_denom.data_ptr()
+            z0 = ws.alloc("bn.zero_k", self.K * self.d, torch.float32)
+            em.z_sum, em.n_sum, em.emb = z0.data_ptr(), z0.data_ptr(), self.emb.data_ptr()
+            em.K, em.d, em.update_codebook = self.K, self.d, 1
+            em.gamma, em.gamma_comp = 1.0, 0.0     # numer/denom unchanged: emb = numer/denom
+            self.cb.add(L.OP_VQ_EMA, em, "vq.codebook", TAG_VQ)
+        # pack goes first in fwd_a (its table is complete only now)
+        pk_plan = Plan("pack")
+        self.pack_tbl.emit(pk_plan, "pack weights")
+        fa.ops[pack_slot:pack_slot] = pk_plan.ops
+        fa.labels[pack_slot:pack_slot] = pk_plan.labels
+        for op in pk_plan.ops:
+            op.tag = TAG_PACK
+        fa.keep += pk_plan.keep
+        # ===== optimizer
+        self.opt = Plan("adam")
+        self.adam_m = ws.alloc("adam.m", ps.numel, torch.float32)
+        self.adam_v = ws.alloc("adam.v", ps.numel, torch.float32)
+        ad = L.Adam()
+        ad.p, ad.g, ad.m, ad.v = ps.params.data_ptr(), ps.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        ad.n = ps.numel
+        ad.lr, ad.beta1, ad.beta2, ad.eps, ad.bc1, ad.bc2, ad.grad_scale = 1e-4, 0.9, 0.999, 1e-8, 1.0, 1.0, 1.0
+        self.opt.add(L.OP_ADAM, ad, "adam", TAG_ADAM)
+
+    def _vae_op(self, backward: bool, dcode: Optional[Mat] = None) -> L.Vae:
+        va = L.Vae()
+        va.lin, va.lin_pitch, va.eps = self.lin.ptr, self.nlin_p, self.eps.data_ptr()
+        va.Q, va.d, va.d_pitch = self.Q, self.d, self.dp
+        va.sample, va.kl_terms = self.code.ptr, self.kl_terms.data_ptr()
+        va.backward = int(backward)
+        if backward:
+            va.dsample = dcode.ptr
+            va.kl_coef = float(self.anneal_weight)
+            va.kl_value = self.loss_buf.data_ptr() + 4 * 2       # out[1 + term 1]
+            va.free_nats = float(self.hps.bn_free_nats)
+            va.dlin = self.dlin.ptr
+        return va
+
+    def _ae_norm_op(self, backward: bool, dcode: Optional[Mat] = None) -> L.AeNorm:
+        an = L.AeNorm()
+        an.ze, an.Q, an.d, an.d_pitch = self.lin.ptr, self.Q, self.d, self.nlin_p
+        an.term = self.norm_terms.data_ptr()
+        an.backward = int(backward)
+        if backward:
+            an.dze_in, an.coef, an.dze = dcode.ptr, 0.001 / self.Q, self.dlin.ptr
+        return an
+
+    # --------------------------------------------------------------------------------------
+    # execution
+    # --------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        raise L.AewError("the HIP plans can only run on a GPU device; this engine was built on "
+                         f"'{self.device}' (plan construction only)")
+
+    def set_inputs(self, wav, mel, voice, jitter, eps=None):
+        g = self.geom
+        self.in_wav.copy_(wav)
+        self.in_mel.copy_(mel)
+        self.in_voice.copy_(voice)
+        self.in_jitter.copy_(jitter[:, :g.embed_len])
+        if self.bn_type == "vae":
+            if eps is None:
+                self.eps.normal_()
+            else:
+                self.eps.copy_(eps.permute(0, 2, 1) if eps.shape[1] == self.d and eps.dim() == 3 else eps)
+
+    def set_anneal_weight(self, a: float):
+        """SGVBLoss.update_anneal_weight (vae_bn.py:72-73)."""
+        self.anneal_weight = float(a)
+        arr = self.fwd_b.array()
+        arr[self._red_index].u.red.post_scale[1] = float(a)
+        self.bwd.array()[self._vae_bwd_index].u.vae.kl_coef = float(a)
+
+    def forward(self, ema_allreduce=None):
+        s = self._stream()
+        self.fwd_a.run(s)
+        if ema_allreduce is not None and self.bn_type == "vqvae-ema":
+            ema_allreduce(self.z_sum, self.n_sum)
+        self.fwd_b.run(s)
+        return self.loss_buf[0]
+
+    def backward(self):
+        self.bwd.run(self._stream())
+        if self.bn_type == "vqvae-ema" and self.update_codebook_every_step:
+            self.cb.run(self._stream())
+
+    def update_codebook(self):
+        self.cb.run(self._stream())
+
+    def adam_step(self, lr: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.step_count += 1
+        a = self.opt.array()[0].u.adam
+        a.lr, a.beta1, a.beta2, a.eps = lr, betas[0], betas[1], eps
+        a.bc1 = 1.0 - betas[0] ** self.step_count
+        a.bc2 = 1.0 - betas[1] ** self.step_count
+        a.grad_scale = grad_scale
+        self.opt.run(self._stream())
+
+    # --------------------------------------------------------------------------------------
+    # views for the module surface / tests
+    # --------------------------------------------------------------------------------------
+    def logits(self) -> torch.Tensor:
+        """(B, w, Q) fp32 channels-last view."""
+        return self.dec.logits.tensor()[:, :, :self.hps.n_quant]
+
+    def init_ema_from_emb(self):
+        """vqema_bn.py:117-118."""
+        comp = 1.0 - self.hps.bn_vq_ema_gamma
+        self.ema_numer.copy_(self.emb * comp)
+        self.ema_denom.fill_(comp)
+
+    def flops_per_step(self) -> Dict[str, float]:
+        """Algorithmic FLOPs of one training step by the formula of SURVEY Appendix B /
+        BASELINE.md §4 (decoder stack + post network; x3 for fwd + dgrad + wgrad)."""
+        h, g = self.hps, self.geom
+        R, D, S, P, Q = h.n_res, h.n_dil, h.n_skp, h.n_post, h.n_quant
+        C = h.n_lc_out + h.n_global_embed
+        nl = len(g.layers)
+        mac = 0
+        for i, lg in enumerate(g.layers):
+            mac += lg.out_len * (2 * 2 * R * D + 2 * C * D + (D * R if i < nl - 1 else 0))
+        mac += nl * g.n_win * D * S + g.n_win * (S * P + P * Q)
+        fwd = 2.0 * mac * self.B
+        return {"fwd": fwd, "step": 3.0 * fwd}

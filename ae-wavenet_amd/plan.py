@@ -1,0 +1,234 @@
+"""Launch-plan infrastructure: workspace buffers, ctypes op emission, plan execution.
+
+A *plan* is a ctypes array of `aew_op_t` (include/aewavenet.h) that `aew_run_plan` executes
+in order on one HIP stream.  Plans are built once per (model, batch, window) against a
+persistent :class:`Workspace`, so a training step is a handful of C calls with no
+per-step Python work proportional to the number of kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+TORCH_DT = {L.BF16: torch.bfloat16, L.F32: torch.float32}
+ESIZE = {L.BF16: 2, L.F32: 4}
+
+
+def ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Workspace:
+    """Named device buffers.  Every buffer is a flat torch tensor; plans hold raw pointers
+    into them, so buffers are never reallocated once a plan references them."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def alloc(self, name: str, numel: int, dtype, zero: bool = True) -> torch.Tensor:
+        if name in self.bufs:
+            raise KeyError(f"buffer {name} already allocated")
+        numel = max(int(numel), 8)
+        # +64 elements of slack so 16-byte vector accesses at the tail stay in bounds
+        t = (torch.zeros if zero else torch.empty)(numel + 64, dtype=dtype, device=self.device)
+        self.bufs[name] = t
+        return t
+
+    def get(self, name: str) -> torch.Tensor:
+        return self.bufs[name]
+
+    def ptr(self, name: str, off: int = 0) -> int:
+        t = self.bufs[name]
+        return t.data_ptr() + off * t.element_size()
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+    def resolve(self, addr: int) -> Tuple[str, int]:
+        """(buffer name, element offset) containing device address `addr` (used by the CPU
+        plan interpreter in tests/)."""
+        for n, t in self.bufs.items():
+            p = t.data_ptr()
+            if p <= addr < p + t.numel() * t.element_size():
+                return n, (addr - p) // t.element_size()
+        raise KeyError(f"address {addr:#x} is not inside any workspace buffer")
+
+
+class Mat:
+    """A channels-last matrix [batch][rows][pitch] inside a workspace buffer."""
+
+    def __init__(self, ws: Workspace, name: str, batch: int, rows: int, pitch: int, dtype: int,
+                 cols: Optional[int] = None, base_off: int = 0):
+        self.ws, self.name, self.batch, self.rows, self.pitch, self.dtype = ws, name, batch, rows, pitch, dtype
+        self.cols = pitch if cols is None else cols
+        self.base_off = base_off
+        self.bs = rows * pitch
+
+    @staticmethod
+    def new(ws: Workspace, name: str, batch: int, rows: int, pitch: int, dtype: int,
+            cols: Optional[int] = None) -> "Mat":
+        ws.alloc(name, batch * rows * pitch, TORCH_DT[dtype])
+        return Mat(ws, name, batch, rows, pitch, dtype, cols)
+
+    @property
+    def ptr(self) -> int:
+        return self.ws.ptr(self.name, self.base_off)
+
+    def tensor(self) -> torch.Tensor:
+        t = self.ws.get(self.name)[self.base_off:self.base_off + self.batch * self.bs]
+        return t.view(self.batch, self.rows, self.pitch)
+
+    def seg(self, k_len: int, row_off: int = 0, row_step: int = 1, lo: int = 0,
+            hi: Optional[int] = None, col_off: int = 0) -> L.Seg:
+        s = L.Seg()
+        s.ptr = self.ptr + col_off * ESIZE[self.dtype]
+        s.batch_stride, s.row_pitch = self.bs, self.pitch
+        s.row_step, s.row_off = row_step, row_off
+        s.row_lo, s.row_hi = lo, self.rows if hi is None else hi
+        s.k_len = k_len
+        return s
+
+    def view(self, row_off: int = 0, row_step: int = 1, lo: int = 0, hi: Optional[int] = None,
+             col_off: int = 0) -> L.View:
+        v = L.View()
+        v.ptr = self.ptr + col_off * ESIZE[self.dtype]
+        v.batch_stride, v.row_pitch = self.bs, self.pitch
+        v.row_step, v.row_off = row_step, row_off
+        v.row_lo, v.row_hi = lo, self.rows if hi is None else hi
+        v.dtype = self.dtype
+        return v
+
+
+def null_view() -> L.View:
+    return L.View()
+
+
+class Plan:
+    def __init__(self, name: str):
+        self.name = name
+        self.ops: List[L.Op] = []
+        self.labels: List[str] = []
+        self._arr = None
+        self.keep: list = []          # device tables etc. that must outlive the plan
+
+    def add(self, kind: int, payload, label: str, tag: int = 0) -> L.Op:
+        op = L.Op()
+        # tag = semantic tag + 100 * kernel class (1 NT bf16, 2 TN bf16, 3 NT f32, 4 TN f32)
+        cls = 0
+        if kind == L.OP_GEMM_NT:
+            cls = 1 if payload.dtype == L.BF16 else 3
+        elif kind == L.OP_GEMM_TN:
+            cls = 2 if payload.dtype == L.BF16 else 4
+        op.kind, op.tag = kind, tag + 100 * cls
+        setattr(op.u, L.OP_FIELD[kind], payload)
+        self.ops.append(op)
+        self.labels.append(label)
+        self._arr = None
+        return op
+
+    def zero(self, ws: Workspace, name: str, label: Optional[str] = None):
+        z = L.Zero()
+        t = ws.get(name)
+        z.ptr, z.bytes = t.data_ptr(), t.numel() * t.element_size()
+        self.add(L.OP_ZERO, z, label or f"zero:{name}")
+
+    def array(self):
+        if self._arr is None:
+            self._arr = (L.Op * len(self.ops))(*self.ops)
+        return self._arr
+
+    def run(self, stream: int = 0):
+        if not self.ops:
+            return
+        fail = C.c_int(-1)
+        rc = L.load().aew_run_plan(C.cast(self.array(), C.c_void_p), len(self.ops), C.c_void_p(stream),
+                                   C.byref(fail))
+        if rc != 0:
+            lab = self.labels[fail.value] if 0 <= fail.value < len(self.labels) else "?"
+            L.check(rc, f"plan '{self.name}' op '{lab}'", fail.value)
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM op construction helpers
+# ------------------------------------------------------------------------------------------
+def make_nt(dtype: int, M: int, N: int, N_pad: int, batch: int, segs: Sequence[L.Seg], W_ptr: int,
+            epi: int = L.EPI_STORE, flags: int = 0, out0: Optional[L.View] = None,
+            out1: Optional[L.View] = None, out2: Optional[L.View] = None,
+            aux0: Optional[L.View] = None, aux1: Optional[L.View] = None, bias_ptr: int = 0,
+            bias_bs: int = 0, n_split: int = 0, counter_ptr: int = 0, impl: int = 0) -> L.GemmNT:
+    g = L.GemmNT()
+    g.dtype, g.impl, g.M, g.N, g.N_pad, g.batch = dtype, impl, M, N, N_pad, batch
+    if not 1 <= len(segs) <= L.MAX_SEGS:
+        raise ValueError(f"{len(segs)} segments (max {L.MAX_SEGS})")
+    g.n_segs = len(segs)
+    for i, s in enumerate(segs):
+        g.seg[i] = s
+    g.K_total = sum(s.k_len for s in segs)
+    g.W = W_ptr
+    g.epi, g.flags = epi, flags
+    for nm, v in (("out0", out0), ("out1", out1), ("out2", out2), ("aux0", aux0), ("aux1", aux1)):
+        if v is not None:
+            setattr(g, nm, v)
+    g.bias, g.bias_bs, g.n_split = bias_ptr or None, bias_bs, n_split
+    g.counter = counter_ptr or None
+    return g
+
+
+def make_tn(dtype: int, Mc: int, batch: int, N: int, N_pad: int, gseg: L.Seg, segs: Sequence[L.Seg],
+            impl: int = 0) -> L.GemmTN:
+    t = L.GemmTN()
+    t.dtype, t.impl, t.Mc, t.batch, t.N, t.N_pad = dtype, impl, Mc, batch, N, N_pad
+    t.g = gseg
+    if not 1 <= len(segs) <= L.MAX_SEGS:
+        raise ValueError(f"{len(segs)} segments (max {L.MAX_SEGS})")
+    t.n_segs = len(segs)
+    for i, s in enumerate(segs):
+        t.seg[i] = s
+    t.K_total = sum(s.k_len for s in segs)
+    return t
+
+
+class CopyTableBuilder:
+    """Collects strided-copy records and uploads them as one table op."""
+
+    def __init__(self, ws: Workspace, name: str):
+        self.ws, self.name = ws, name
+        self.recs: List[L.CopyRec] = []
+
+    def add(self, src_ptr: int, dst_ptr: int, dims: Sequence[int], ss: Sequence[int],
+            ds: Sequence[int], src_dtype: int, dst_dtype: int, red_n: int = 1, red_stride: int = 0,
+            accumulate: bool = False, scale: float = 1.0):
+        dims, ss, ds = list(dims), list(ss), list(ds)
+        while len(dims) < 4:
+            dims.insert(0, 1); ss.insert(0, 0); ds.insert(0, 0)
+        r = L.CopyRec()
+        r.src, r.dst = src_ptr, dst_ptr
+        for i in range(4):
+            r.dims[i], r.ss[i], r.ds[i] = dims[i], ss[i], ds[i]
+        r.src_dtype, r.dst_dtype, r.red_n, r.red_stride = src_dtype, dst_dtype, red_n, red_stride
+        r.accumulate, r.scale = int(accumulate), scale
+        self.recs.append(r)
+
+    def emit(self, plan: Plan, label: str):
+        if not self.recs:
+            return
+        block_rec: List[int] = []
+        for i, r in enumerate(self.recs):
+            n = r.dims[0] * r.dims[1] * r.dims[2] * r.dims[3]
+            r.first_block = len(block_rec)
+            block_rec.extend([i] * ((n + 1023) // 1024))
+        raw = bytes((L.CopyRec * len(self.recs))(*self.recs))
+        rec_t = self.ws.alloc(f"{self.name}.recs", (len(raw) + 7) // 8, torch.int64, zero=True)
+        host = torch.frombuffer(bytearray(raw + b"\0" * (-len(raw) % 8)), dtype=torch.int64)
+        rec_t[:host.numel()].copy_(host)
+        blk_t = self.ws.alloc(f"{self.name}.blocks", len(block_rec), torch.int32, zero=True)
+        blk_t[:len(block_rec)].copy_(torch.tensor(block_rec, dtype=torch.int32))
+        t = L.CopyTable()
+        t.recs, t.block_rec = rec_t.data_ptr(), blk_t.data_ptr()
+        t.n_blocks, t.n_recs = len(block_rec), len(self.recs)
+        plan.add(L.OP_COPY_TABLE, t, label)

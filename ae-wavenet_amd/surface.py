@@ -1,0 +1,328 @@
+"""Shared machinery of the drop-in nn.Module surfaces (see autoencoder_model.py and
+mfcc_inverter.py in this package).
+
+The reference harness drives a model through (chassis.py:151-171, checkpoint.py:35-67):
+    model = Model(hps); model.get_input_size(w); model.override(w); model.mfcc
+    optim = Adam(model.parameters()); model.to(device); model.train()
+    quant, target, loss = model.run(wav, mel, voice, jitter); loss.backward(); optim.step()
+    model.objective.metrics, model.encoder.metrics, model.bn_type,
+    model.bottleneck.update_codebook(), model.init_codebook(...)
+
+Parameters are nn.Parameters whose storage is a view into the engine's flat fp32 buffer and
+whose .grad is a view into the flat gradient buffer, so `loss.backward()` (one
+autograd.Function around the whole HIP training step) fills every .grad without per-parameter
+autograd traffic, and any torch optimizer — or the fused `optim.FusedAdam` — can step them.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import geometry as G
+from .model import TrainEngine
+
+
+class _StepFn(torch.autograd.Function):
+    """loss = f(parameters, batch) with a hand-written backward (the bwd plan)."""
+
+    @staticmethod
+    def forward(ctx, anchor, owner):
+        ctx.owner = owner
+        loss = owner._engine.forward(owner._ema_allreduce)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        owner = ctx.owner
+        owner._engine.backward()
+        owner._after_backward(g)
+        return torch.zeros_like(owner._anchor), None
+
+
+class Objective:
+    """Stand-in for the reference loss modules' attribute surface (metrics dict,
+    update_anneal_weight, free_nats, anneal_weight; chassis.py:124,149,215-220)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self.metrics: Dict[str, torch.Tensor] = {}
+        self.free_nats = torch.tensor(float(getattr(owner.hps, "bn_free_nats", 0.0)))
+        self.anneal_weight = torch.tensor(0.0)
+
+    def update_anneal_weight(self, w):
+        self.anneal_weight = torch.tensor(float(w))
+        eng = self._owner._engine
+        if eng is not None and eng.bn_type == "vae":
+            eng.set_anneal_weight(float(w))
+
+
+class _EncoderFacade(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.metrics: Dict[str, torch.Tensor] = {}
+
+
+class _BottleneckFacade(nn.Module):
+    def __init__(self, owner):
+        super().__init__()
+        self.__dict__["_owner"] = owner
+
+    def update_codebook(self):
+        """vqema_bn.py:216-222 (called by chassis.py:175-176)."""
+        eng = self._owner._engine
+        if eng is not None and eng.bn_type == "vqvae-ema":
+            eng.update_codebook()
+
+
+class HipModelBase(nn.Module):
+    """Common implementation; subclasses set `kind` and the parameter prefix layout."""
+
+    def __init__(self, hps, kind: str, loss_mode: str = "intended", take_compat: bool = False,
+                 update_codebook_every_step: bool = True, n_mel: Optional[int] = None):
+        super().__init__()
+        if hps.global_model != kind:
+            hps = type(hps)(hps)
+            hps["global_model"] = kind
+        self.hps = hps
+        self.kind = kind
+        self.bn_type = hps.bn_type if kind == "autoencoder" else "none"
+        self._opts = dict(loss_mode=loss_mode, take_compat=take_compat,
+                          update_codebook_every_step=update_codebook_every_step, n_mel=n_mel)
+        self.window_batch_size = hps.n_win_batch
+        self._engine: Optional[TrainEngine] = None
+        self._device = torch.device("cpu")
+        self._pending_state: Optional[Dict[str, torch.Tensor]] = None
+        self._ema_allreduce = None
+        self._dp = None
+        self.objective = Objective(self)
+        self._anchor = torch.zeros((), requires_grad=True)
+        # geometry attributes of the reference classes (autoencoder_model.py:119-146,
+        # mfcc_inverter.py:38-65)
+        self._set_geometry(self.window_batch_size)
+        # Parameters exist from construction (Checkpoint builds Adam before .to(device),
+        # checkpoint.py:48-50); they are re-homed into the engine's flat buffer on first use.
+        self._make_cpu_params()
+
+    # ---- geometry / harness queries ------------------------------------------------------
+    def _set_geometry(self, w):
+        g = G.model_geometry(self.hps, self.kind == "autoencoder", w)
+        self.geom = g
+        self.enc_in_len, self.enc_in_mel_len, self.embed_len = g.enc_in_len, g.mel_len, g.embed_len
+        self.dec_in_len = g.dec_in_len
+        self.trim_dec_in = torch.tensor(g.trim_dec_in)
+        self.trim_dec_out = torch.tensor(g.trim_dec_out)
+        self.trim_ups_out = torch.tensor(g.trim_ups_out)
+
+    def get_input_size(self, output_size):
+        """wav samples per window (wavenet.py:287-294 via checkpoint.py:40)."""
+        return G.input_size(self.hps, self.kind == "autoencoder", output_size)
+
+    def override(self, n_win_batch=None):
+        """mfcc_inverter.py:30-35 (checkpoint.py:46)."""
+        if n_win_batch is not None and n_win_batch != self.window_batch_size:
+            self.window_batch_size = n_win_batch
+            self._set_geometry(n_win_batch)
+            self._drop_engine()
+
+    # ---- parameters --------------------------------------------------------------------------
+    def _specs(self):
+        from .engine import bottleneck_param_specs, decoder_param_specs, encoder_param_specs
+        h = self.hps
+        if self.kind == "autoencoder":
+            n_mel = self._opts["n_mel"] or 3 * h.n_mfcc
+            return (encoder_param_specs(n_mel, h.enc_n_out) + bottleneck_param_specs(h)
+                    + decoder_param_specs(h, h.n_lc_in, "decoder."))
+        return decoder_param_specs(h, h.n_lc_in, "wavenet.")
+
+    def _make_cpu_params(self):
+        """Xavier-uniform weights, zero biases (netmisc.py:10-14); VQ codebooks with the
+        reference's gains (vq_bn.py:21)."""
+        self._pnames = []
+        for name, shape in self._specs():
+            t = torch.empty(shape)
+            if len(shape) >= 2:
+                nn.init.xavier_uniform_(t)
+            else:
+                t.zero_()
+            pname = name.replace(".", "__")
+            self.register_parameter(pname, nn.Parameter(t))
+            self._pnames.append((name, pname))
+        if self.bn_type == "vqvae-ema":
+            K, d = self.hps.bn_vq_n_embed, self.hps.bn_n_out
+            emb = torch.empty(K, d)
+            nn.init.xavier_uniform_(emb, gain=10)                        # vqema_bn.py:97
+            comp = 1.0 - self.hps.bn_vq_ema_gamma
+            self.register_buffer("bn_emb", emb)
+            self.register_buffer("bn_ema_numer", emb * comp)             # vqema_bn.py:117-118
+            self.register_buffer("bn_ema_denom", torch.full((K,), comp))
+            self.register_buffer("bn_ind_hist", torch.zeros(K))
+
+    # nn.Module hooks so that state_dict / named_parameters use the reference's dotted names
+    def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
+        for name, pname in self._pnames:
+            yield (prefix + ("." if prefix else "") + name), self._parameters[pname]
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    _BUF_NAMES = {"bn_emb": "bottleneck.emb", "bn_ema_numer": "bottleneck.ema_numer",
+                  "bn_ema_denom": "bottleneck.ema_denom", "bn_ind_hist": "bottleneck.ind_hist"}
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        self._sync_buffers_from_engine()
+        sd = destination if destination is not None else {}
+        for name, p in self.named_parameters():
+            sd[prefix + name] = p if keep_vars else p.detach()
+        for b, nm in self._BUF_NAMES.items():
+            if b in self._buffers:
+                sd[prefix + nm] = self._buffers[b]
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state_dict]
+        unexpected = []
+        inv = {v: k for k, v in self._BUF_NAMES.items()}
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k in own:
+                    own[k].copy_(v.reshape(own[k].shape))
+                elif k in inv and inv[k] in self._buffers:
+                    self._buffers[inv[k]].copy_(v)
+                else:
+                    unexpected.append(k)
+        self._push_buffers_to_engine()
+        if strict and (missing or [u for u in unexpected if "_lead" not in u and "eye" not in u
+                                   and "residual_offsets" not in u]):
+            raise RuntimeError(f"state_dict mismatch: missing {missing}, unexpected {unexpected}")
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ---- device placement / engine ---------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        # .to(device) / .float() ...: let nn.Module move the parameter tensors (views into the
+        # engine's flat buffer are copied out by this), then drop the engine; it is rebuilt
+        # lazily on the next run() and the values are copied back in.
+        if self._engine is not None:
+            self._sync_buffers_from_engine()
+        out = super()._apply(fn, recurse)
+        self._engine = None
+        self._device = next(iter(self._parameters.values())).device
+        self._anchor = torch.zeros((), requires_grad=True, device=self._device)
+        return out
+
+    def _drop_engine(self):
+        if self._engine is not None:
+            self._pull_params_to_cpu()
+        self._engine = None
+
+    def _pull_params_to_cpu(self):
+        eng = self._engine
+        self._sync_buffers_from_engine()
+        with torch.no_grad():
+            for name, pname in self._pnames:
+                self._parameters[pname].data = eng.ps.view(name).detach().clone()
+
+    def _sync_buffers_from_engine(self):
+        eng = self._engine
+        if eng is not None and eng.bn_type == "vqvae-ema":
+            self._buffers["bn_emb"] = eng.emb.detach().clone()
+            self._buffers["bn_ema_numer"] = eng.ema_numer.detach().clone()
+            self._buffers["bn_ema_denom"] = eng.ema_denom.detach().clone()
+            self._buffers["bn_ind_hist"] = eng.ind_hist.detach().clone()
+
+    def _push_buffers_to_engine(self):
+        eng = self._engine
+        if eng is not None and eng.bn_type == "vqvae-ema":
+            eng.emb.copy_(self._buffers["bn_emb"])
+            eng.ema_numer.copy_(self._buffers["bn_ema_numer"])
+            eng.ema_denom.copy_(self._buffers["bn_ema_denom"])
+            eng.ind_hist.copy_(self._buffers["bn_ind_hist"])
+
+    def _ensure_engine(self, B: int):
+        eng = self._engine
+        if eng is not None and eng.B == B:
+            return eng
+        if self._device.type != "cuda":
+            raise L.AewError("this model executes only through the HIP library on an MI355X; "
+                             "move it to a cuda device first (no CPU execution path exists)")
+        L.load()
+        if eng is not None:
+            self._pull_params_to_cpu()
+        eng = TrainEngine(self.hps, B, self._device, n_win=self.window_batch_size, **self._opts)
+        # re-home the parameters into the flat buffer (values preserved)
+        with torch.no_grad():
+            for name, pname in self._pnames:
+                p = self._parameters[pname]
+                view = eng.ps.view(name)
+                view.copy_(p.data.to(self._device))
+                p.data = view
+                p.grad = eng.ps.view(name, grad=True)
+        self._engine = eng
+        self._push_buffers_to_engine()
+        if eng.bn_type == "vae":
+            eng.set_anneal_weight(float(self.objective.anneal_weight))
+        return eng
+
+    # ---- the hot path ----------------------------------------------------------------------
+    def run(self, wav, mel, voice, jitter, eps=None):
+        """(wav, mel, voice, jitter) -> (pred, target, loss)   [chassis.py:152]
+
+        wav (B, enc_in_len) float32 holding mu-law ints; mel (B, n_mel, frames) float32;
+        voice (B,) int64; jitter (B, >= embed_len) int64.  pred (B, Q, w-1) logits, target
+        (B, w-1), loss scalar with a grad_fn whose backward fills every parameter's .grad."""
+        B = wav.shape[0]
+        eng = self._ensure_engine(B)
+        eng.set_inputs(wav, mel, voice, jitter, eps=eps)
+        loss = _StepFn.apply(self._anchor, self)
+        w, g = eng.n_win, eng.geom
+        pred = eng.logits()[:, :w - 1, :].permute(0, 2, 1)
+        target = wav[:, g.wav_out_off + 1: g.wav_out_off + w]
+        self._fill_forward_metrics(eng)
+        return pred, target, loss
+
+    def forward(self, wav, mel, voice, jitter):
+        """Logits (B, Q, w) for the batch (teacher-forced)."""
+        eng = self._ensure_engine(wav.shape[0])
+        eng.set_inputs(wav, mel, voice, jitter)
+        eng.forward(self._ema_allreduce)
+        return eng.logits().permute(0, 2, 1)
+
+    def _after_backward(self, g):
+        eng = self._engine
+        # re-attach .grad views (optim.zero_grad(set_to_none=True) detaches them)
+        for name, pname in self._pnames:
+            self._parameters[pname].grad = eng.ps.view(name, grad=True)
+        if self._dp is not None:
+            self._dp.allreduce_grads(eng)
+        m = self.objective.metrics
+        if self.kind == "autoencoder":
+            mg = eng.enc.dy[0].tensor()[:, :, :eng.n_mel]
+            m["mel_grad_sd"] = mg.std()
+            m["bn_grad_sd"] = eng.dec.dlc_src.tensor()[:, :, :self.hps.bn_n_out].std()
+        else:
+            mg = eng.dec.dlc_src.tensor()[:, :, :eng.n_mel]
+            m["mel_grad_sd"], m["mel_grad_mean"] = mg.std(), mg.mean()
+
+    def _fill_forward_metrics(self, eng):
+        w, B = eng.n_win, eng.B
+        n_pos = B * (w - 1)
+        m = self.objective.metrics
+        m["rec"] = eng.dec.nll[:B * w].sum() / n_pos
+        self.tprb_m = eng.dec.ptgt[:B * w].sum() / n_pos            # chassis.py:266-270
+        if eng.bn_type in ("vqvae-ema", "vqvae"):
+            md = eng.min_dist[:eng.Q]
+            m["com"] = (md * self.hps.bn_vq_gamma).mean()
+            m["nunq"] = eng.ind[:eng.Q].unique().numel
+        elif eng.bn_type == "vae":
+            m["kl_div_loss"], m["log_pred_loss"] = eng.loss_buf[2], m["rec"]
+        elif eng.bn_type == "ae":
+            m["norm"] = eng.loss_buf[2]
+        if eng.enc is not None and hasattr(self, "encoder"):
+            cnt = eng.enc.zero_cnt[:9].double()
+            for i in range(9):
+                numel = B * eng.geom.enc_lens[i + 1] * self.hps.enc_n_out
+                self.encoder.metrics[f"enc_az_{i}"] = cnt[i] / numel

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — 16 kHz audio samples / second / training step of the VQ-VAE-EMA WaveNet
+autoencoder (par/arch.vqvae-ema.json shape) on N MI355X, data-parallel.
+
+A step = forward + backward + gradient all-reduce (N>1) + fused Adam + EMA codebook update
+over one batch of 8 windows x 5000 output samples per GPU (BASELINE.json configs[1]; weak
+scaling), synthetic inputs resident in HBM before the timed region, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line.  `roofline` is for the dominant kernel (the bf16 NT GEMM that
+carries forward + dgrad of the gated stack): algorithmic FLOPs / HIP-event time measured on
+the plan's stream.  `cpu_baseline` times the oracle (torch fp32 CPU port of the reference) on
+one window of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def build_engine(args, device):
+    from ae_wavenet_amd import config, model as M
+    hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch)
+    eng = M.TrainEngine(hps, B=args.batch, device=device, n_mel=39)
+    gen = torch.Generator().manual_seed(2507)                     # hparams.py:92 random_seed
+    for k in eng.ps.names():
+        shp = eng.ps.shape[k]
+        t = torch.empty(shp)
+        if len(shp) >= 2:
+            torch.nn.init.xavier_uniform_(t, generator=gen)      # netmisc.py:10-14
+        else:
+            t.zero_()
+        eng.ps.view(k).copy_(t)
+    emb = torch.empty(hps.bn_vq_n_embed, hps.bn_n_out)
+    torch.nn.init.xavier_uniform_(emb, gain=10, generator=gen)    # vqema_bn.py:97
+    eng.emb.copy_(emb)
+    eng.init_ema_from_emb()
+    return hps, eng
+
+
+def synth_batch(eng, rank, device):
+    g = eng.geom
+    gen = torch.Generator().manual_seed(1000 + rank)
+    B = eng.B
+    wav = torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float()
+    mel = torch.randn(B, 39, g.mel_len, generator=gen)
+    voice = torch.randint(0, 40, (B,), generator=gen)
+    jitter = torch.arange(g.embed_len).repeat(B, 1)
+    return [t.to(device) for t in (wav, mel, voice, jitter)]
+
+
+def cpu_baseline(hps, eng, seconds_budget=40.0):
+    """Oracle (torch fp32 CPU restatement of the reference) forward+backward on ONE window of
+    the same workload (B=1, same n_win), all host cores."""
+    from oracle import ref_model as R
+    from ae_wavenet_amd import geometry
+    g = eng.geom
+    sd = {k: eng.ps.view(k).detach().cpu().clone().requires_grad_(True) for k in eng.ps.names()}
+    emb = eng.emb.detach().cpu().clone()
+    gen = torch.Generator().manual_seed(5)
+    wav = torch.randint(0, 256, (1, g.enc_in_len), generator=gen).float()
+    mel = torch.randn(1, 39, g.mel_len, generator=gen)
+    voice = torch.randint(0, 40, (1,), generator=gen)
+    jitter = torch.arange(g.embed_len).repeat(1, 1)
+    cores = torch.get_num_threads()
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        t0 = time.time()
+        out = R.ae_run(sd, {"emb": emb}, hps, g, wav, mel, voice, jitter, loss_mode="intended", take_compat=False)
+        out["loss"].backward()
+        times.append(time.time() - t0)
+        for v in sd.values():
+            v.grad = None
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times)
+    return {"value": g.n_win / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd, 1 window of {g.n_win} samples (B=1), best of {len(times)} "
+                      f"({best:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=1e-4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dp = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+        from ae_wavenet_amd.dp import DataParallel
+        dp = DataParallel()
+
+    from ae_wavenet_amd import _lib as L
+    lib = L.load()
+    hps, eng = build_engine(args, device)
+    if dp is not None:
+        dp.broadcast_params(eng)
+    batch = synth_batch(eng, rank, device)
+    eng.set_inputs(*batch)
+    ema_ar = dp.allreduce_ema if dp is not None else None
+    # sum-type loss (VQEMA 'intended'): summed gradients across ranks == single-process global batch
+    gscale = 1.0
+
+    def step():
+        eng.forward(ema_ar)
+        eng.backward()
+        if dp is not None:
+            dp.allreduce_grads(eng)
+        eng.adam_step(args.lr, gscale)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(eng.loss_buf[0])
+
+    # ---- per-kernel timing for the roofline (outside the timed region) ----------------------
+    roof = None
+    kern = {}
+    if rank == 0:
+        import ctypes as C
+        lib.aew_timing_enable(1)
+        n_t = 3
+        for _ in range(n_t):
+            eng.forward(None)
+            eng.backward()
+            eng.adam_step(args.lr, gscale)
+        cap = 1 << 16
+        ms = (C.c_float * cap)()
+        tags = (C.c_int32 * cap)()
+        cnt = C.c_int(0)
+        L.check(lib.aew_timing_read(ms, tags, cap, C.byref(cnt)), "timing_read")
+        lib.aew_timing_enable(0)
+        cls_ms = {}
+        cls_n = {}
+        for i in range(min(cnt.value, cap)):
+            c = tags[i] // 100
+            cls_ms[c] = cls_ms.get(c, 0.0) + ms[i] / n_t
+            cls_n[c] = cls_n.get(c, 0) + 1
+            kern[tags[i]] = kern.get(tags[i], 0.0) + ms[i] / n_t
+        fl = eng.flops_per_step()
+        # forward + dgrad of the gated stack / post network run on the bf16 NT kernel,
+        # wgrad on the bf16 TN kernel  (90.4 MFLOP per output sample per step)
+        nt_flops, nt_ms = fl["step"] * 2.0 / 3.0, cls_ms.get(1, 0.0)
+        n_launch = max(cls_n.get(1, 0) // n_t, 1)
+        achieved = nt_flops / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "k_gemm_nt_bf16", "achieved": round(achieved, 2), "peak": 2500.0,
+                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": None,
+                "launches_per_step": n_launch, "avg_launch_ms": round(nt_ms / n_launch, 5),
+                "alg_flops_per_launch": nt_flops / n_launch,
+                "tn_bf16": {"achieved": round((fl["step"] / 3.0) / (cls_ms.get(2, 1e9) * 1e-3) / 1e12, 2),
+                            "ms_per_step": round(cls_ms.get(2, 0.0), 4)},
+                "ms_per_step_by_class": {str(k): round(v, 4) for k, v in sorted(cls_ms.items())}}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(hps, eng)
+        except Exception as e:                                   # never lose the GPU line
+            cpu = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"failed: {type(e).__name__}: {e}"}
+
+    if rank == 0:
+        samples = world * args.batch * args.n_win * args.steps
+        out = {
+            "metric": "16kHz audio samples/sec/step (VQ-VAE-EMA train)",
+            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "VQ-VAE-EMA (arch.vqvae-ema shape: 2x10 gated layers, 368 res / 256 dil "
+                                   "/ 256 skip, K=4096 d=32) fwd+bwd+Adam",
+                       "global_batch": world * args.batch, "n_win_batch": args.n_win,
+                       "parallelism": f"dp{world}", "loss": float(loss_val),
+                       "decoder": "bf16 MFMA, fp32 accumulate", "encoder_vq": "fp32 MFMA exact chain"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernel_ms_by_tag": {str(k): round(v, 4) for k, v in sorted(kern.items())},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,356 @@
+/* aewavenet.h — C ABI of the MI355X-native WaveNet-autoencoder training hot path.
+ *
+ * The reference (hrbigelow/ae-wavenet) is pure Python on torch ATen; it has no FFI.  Its
+ * drop-in boundary is the nn.Module surface (autoencoder_model.py:206-259,
+ * mfcc_inverter.py:89-108, driven by chassis.py:151-171).  This header is the C ABI the
+ * build adds *underneath* that surface: plain pointers, sizes and POD descriptors, no torch
+ * types.  Each entry point / op lists the reference ATen call sites it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative AEW_E_* on argument errors, or a
+ *     positive hipError_t; nothing throws across the ABI
+ *   - the library never allocates or frees device memory; the caller owns all buffers
+ *   - all work is enqueued on the hipStream_t passed in (stream-ordered, no host sync)
+ *   - activations are CHANNELS-LAST: tensor[b][t][c], c fastest.  bf16 is stored as uint16
+ *   - "row" means a time index t; a buffer is addressed as
+ *         ptr + b*batch_stride + row*row_pitch + c            (element units)
+ *
+ * The hot path is a static LAUNCH PLAN: an array of aew_op_t records executed in order by
+ * aew_run_plan().  Almost every record is one of two GEMM forms over *row-affine segments*:
+ *
+ *   NT ("forward/dgrad"):  C[b][m][n]  = sum_s sum_k A_s[b][m*step_s + off_s][k] * W[n][K_s + k]
+ *   TN ("wgrad")        :  dW[b][n][K_s + k] = sum_m G[b][m*gstep + goff][n] * A_s[b][m*step_s + off_s][k]
+ *
+ * Rows outside a segment's [row_lo,row_hi) read as zero.  With this one form:
+ *   dilated causal conv (wavenet.py:100-101)      = 3 segments  x[t], x[t+dil], cond[t+lead]
+ *   strided encoder conv (wave_encoder.py:39)      = f segments  x[t*s + tap]
+ *   ConvTranspose1d upsampler (wavenet.py:154)     = f/s segments per output phase, x[q - j]
+ *   every dgrad                                    = the transposed segment table
+ *   every wgrad                                    = TN over the same segments
+ */
+#ifndef AEWAVENET_H
+#define AEWAVENET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AEW_ABI_VERSION 1
+#define AEW_MAX_SEGS 32
+
+/* error codes (negative; positive values are hipError_t) */
+#define AEW_E_ARG      (-1)   /* malformed descriptor */
+#define AEW_E_UNSUP    (-2)   /* unsupported op / dtype / flag combination */
+#define AEW_E_ALIGN    (-3)   /* pointer or pitch violates the documented alignment */
+
+/* element types */
+#define AEW_BF16 0
+#define AEW_F32  1
+
+/* ---------------------------------------------------------------------------------------
+ * A-operand segment: rows m*row_step + row_off of a channels-last buffer, k_len channels.
+ * k_len must be a multiple of the kernel's K tile (64 for bf16, 32 for f32); the buffer
+ * must hold k_len (zero-padded) channels per row.  16-byte alignment of ptr and of
+ * row_pitch*sizeof(elem) is required.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* ptr;
+    int64_t batch_stride;
+    int32_t row_pitch;
+    int32_t row_step;
+    int32_t row_off;
+    int32_t row_lo, row_hi;      /* valid source rows [lo,hi); others read as zero */
+    int32_t k_len;
+} aew_seg_t;
+
+/* generic channels-last view used by epilogues */
+typedef struct {
+    void* ptr;
+    int64_t batch_stride;
+    int32_t row_pitch;
+    int32_t row_step;            /* view row = m*row_step + row_off */
+    int32_t row_off;
+    int32_t row_lo, row_hi;      /* rows of the *view* that exist: stores outside are dropped,
+                                    loads outside read as zero */
+    int32_t dtype;               /* AEW_BF16 | AEW_F32 */
+} aew_view_t;
+
+/* NT epilogues */
+#define AEW_EPI_STORE     0   /* flag-driven store, see AEW_EF_* */
+#define AEW_EPI_GATED     1   /* a=tanh(f+bf), s=sigmoid(g+bg); N is (16 filt | 16 gate)-interleaved.
+                                 out0 = z = a*s, out1 = dz/df = s(1-a^2), out2 = dz/dg = a s(1-s)
+                                 (bf16)                                   wavenet.py:100-102 */
+#define AEW_EPI_RES_SKIP  2   /* n<n_split: out0[m]=acc+aux0[m] (residual, wavenet.py:108-109)
+                                 n>=n_split: out1[m][n-n_split] (+)= acc (skip sum, :103,:357);
+                                 with AEW_EF_OUT2_RELU also out2=relu(out1) bf16 (:359)          */
+#define AEW_EPI_DFG       3   /* acc=dz; aux0=dz/df, aux1=dz/dg (from GATED); out0 = (dfilt|dgate)-
+                                 interleaved bf16: dz*aux0, dz*aux1    (backward of wavenet.py:102) */
+
+/* AEW_EPI_STORE flags */
+#define AEW_EF_BIAS        (1u << 0)  /* val += bias[b*bias_bs + n]                           */
+#define AEW_EF_RELU        (1u << 1)  /* val = max(val,0)          (after bias)               */
+#define AEW_EF_OUT1_PRE    (1u << 2)  /* out1 = val  (before the aux add; encoder relu out)    */
+#define AEW_EF_ADD_AUX0    (1u << 3)  /* val += aux0[view row of m][n]  (zero outside range)   */
+#define AEW_EF_MUL_POS1    (1u << 4)  /* val *= (aux1[m][n] > 0)                               */
+#define AEW_EF_OUT1_POS1   (1u << 5)  /* out1 = val * (aux1[m][n] > 0)  (out0 keeps val)       */
+#define AEW_EF_ACCUM       (1u << 6)  /* RES_SKIP: out1 += acc instead of =                    */
+#define AEW_EF_OUT2_RELU   (1u << 7)  /* RES_SKIP: out2 = relu(new out1) as bf16              */
+#define AEW_EF_COUNT_ZERO  (1u << 8)  /* atomically add #(out0==0) into counter (enc_az metric,
+                                         wave_encoder.py:46)                                   */
+
+typedef struct {
+    int32_t dtype;               /* operand type AEW_BF16 | AEW_F32 */
+    int32_t impl;                /* 0 = MFMA kernel, 1 = scalar check kernel (same math)      */
+    int32_t M;                   /* output rows per batch                                     */
+    int32_t N;                   /* real output columns                                       */
+    int32_t N_pad;               /* rows of W (multiple of 128 for bf16, 64 for f32)          */
+    int32_t batch;
+    int32_t n_segs;
+    int32_t K_total;             /* sum of k_len = row length of W                            */
+    aew_seg_t seg[AEW_MAX_SEGS];
+    const void* W;               /* packed [N_pad][K_total], same dtype as the operands       */
+    int32_t epi;
+    uint32_t flags;
+    aew_view_t out0, out1, out2; /* views are indexed with the GEMM row m                     */
+    aew_view_t aux0, aux1;
+    const float* bias;           /* fp32 [*, N_pad]                                           */
+    int64_t bias_bs;             /* per-batch stride of bias (0 = shared)                     */
+    int32_t n_split;             /* RES_SKIP column boundary (multiple of the N tile)         */
+    int32_t reserved;
+    unsigned long long* counter; /* AEW_EF_COUNT_ZERO target                                  */
+} aew_gemm_nt_t;
+
+typedef struct {
+    int32_t dtype;
+    int32_t impl;
+    int32_t Mc;                  /* contraction rows per batch                                */
+    int32_t batch;
+    int32_t N;                   /* real columns of G                                         */
+    int32_t N_pad;               /* multiple of the tile (128 bf16 / 64 f32); G has N_pad cols */
+    aew_seg_t g;                 /* G operand; k_len ignored                                  */
+    int32_t n_segs;
+    int32_t K_total;
+    aew_seg_t seg[AEW_MAX_SEGS];
+    float* out;                  /* fp32 [batch][N_pad][K_total] per-batch partial sums       */
+    int64_t out_batch_stride;
+} aew_gemm_tn_t;
+
+/* ---------------------------------------------------------------------------------------
+ * table-driven strided copy / convert / reduce (weight pack, gradient unpack, NCL<->NLC)
+ *   dst[sum_d i_d*ds_d] = cvt( sum_{r<red_n} src[sum_d i_d*ss_d + r*red_stride] )
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* src;
+    void* dst;
+    int32_t dims[4];
+    int64_t ss[4], ds[4];
+    int32_t src_dtype, dst_dtype;
+    int32_t red_n;
+    int32_t accumulate;          /* dst += (f32 dst only) */
+    int64_t red_stride;
+    float scale;
+    int32_t first_block;         /* filled by the host: first 1024-element block of this record */
+} aew_copy_rec_t;
+
+typedef struct {
+    const aew_copy_rec_t* recs;  /* DEVICE array                                              */
+    const int32_t* block_rec;    /* DEVICE array: record index of every block                 */
+    int32_t n_blocks;
+    int32_t n_recs;
+} aew_copy_table_t;
+
+/* ---------------------------------------------------------------------------------------
+ * small ops
+ * ------------------------------------------------------------------------------------- */
+typedef struct {                 /* nearest code  (vqema_bn.py:135-142, vq_bn.py:39-41)        */
+    const float* ze;             /* [Q][d_pitch] fp32, Q = B*N_e                              */
+    const float* emb;            /* [K][d]                                                    */
+    int32_t Q, K, d, d_pitch;
+    int32_t metric;              /* 0 scaled_l2, 1 sq_l2                                      */
+    int64_t* ind;                /* [Q]                                                       */
+    float* dist;                 /* [Q]                                                       */
+    float* zq;                   /* [Q][d_pitch] (pad channels zeroed)                        */
+} aew_vq_nearest_t;
+
+typedef struct {                 /* z_sum/n_sum, deterministic order (vqema_bn.py:172-188)     */
+    const float* ze; const int64_t* ind;
+    int32_t Q, K, d, d_pitch;
+    float* z_sum; float* n_sum;  /* [K][d], [K]                                               */
+    float* hist;                 /* optional ind_hist accumulator [K] (util.py:107-123)       */
+} aew_vq_stats_t;
+
+typedef struct {                 /* EMA + optional codebook refresh (vqema_bn.py:190-195,216) */
+    float* numer; float* denom; const float* z_sum; const float* n_sum;
+    float* emb;                  /* written when update_codebook != 0                         */
+    int32_t K, d, update_codebook;
+    float gamma, gamma_comp;
+} aew_vq_ema_t;
+
+typedef struct {                 /* d(ze) = d(zq) + gscale*gamma * d(min_dist)/d(ze)          */
+    const float* ze; const float* emb; const int64_t* ind; const float* dzq;
+    int32_t Q, d, d_pitch, metric;
+    float coef;                  /* vq_gamma * upstream loss gradient                         */
+    float demb_coef;             /* upstream loss gradient (weight of the l2 term, vq_bn.py:78) */
+    float* dze;                  /* [Q][d_pitch]                                              */
+    float* demb;                 /* optional [K][d], pre-zeroed: d/d(emb) of sum (sg(ze)-emb)^2 */
+} aew_vq_bwd_t;
+
+typedef struct {                 /* jitter gather (wavenet.py:330-336) fp32 -> bf16           */
+    const float* src; int64_t src_bs; int32_t src_pitch;   /* [B][N][C]                       */
+    const int64_t* jitter; int32_t jit_pitch;              /* [B][N]                          */
+    uint16_t* dst; int64_t dst_bs; int32_t dst_pitch;      /* [B][N][C_pad] bf16              */
+    int32_t B, N, C, C_pad;
+    int32_t take_compat;         /* 1: reproduce torch.take flattening (SURVEY C-1)           */
+} aew_lc_gather_t;
+
+typedef struct {                 /* transpose of the gather: dsrc[b][j][c] += d[b][t][c]       */
+    const float* d; int64_t d_bs; int32_t d_pitch;
+    const int64_t* jitter; int32_t jit_pitch;
+    float* dsrc; int64_t dsrc_bs; int32_t dsrc_pitch;
+    int32_t B, N, C;
+    int32_t take_compat;
+} aew_lc_scatter_t;
+
+typedef struct {                 /* per-(batch,layer) gated bias incl. speaker term           */
+    /* bias[b][l][pack(co)] = conv_bias_l[co] + sum_j V_l[co][C_lc + j] * gc[b][j]
+       gc[b] = Wspk[:, voice[b]] + bspk             (wavenet.py:135-139 folded)   */
+    const float* params;         /* flat fp32 parameter buffer                                */
+    const int64_t* voice;        /* [B]                                                       */
+    const int64_t* off_bias_sig; const int64_t* off_bias_gate;  /* DEVICE [L] offsets or -1   */
+    const int64_t* off_proj_sig; const int64_t* off_proj_gate;  /* DEVICE [L] offsets         */
+    int64_t off_spk_w, off_spk_b;                              /* -1 if no bias               */
+    int32_t B, L, D, D_pad, C_lc, G, n_speakers;
+    float* bias;                 /* [B][L][2*D_pad]                                           */
+    float* gc;                   /* [B][G] saved for backward                                 */
+} aew_spk_bias_t;
+
+typedef struct {                 /* backward of the above from per-batch column sums of dfg   */
+    const float* params; const int64_t* voice;
+    const int64_t* off_bias_sig; const int64_t* off_bias_gate;
+    const int64_t* off_proj_sig; const int64_t* off_proj_gate;
+    int64_t off_spk_w, off_spk_b;
+    int32_t B, L, D, D_pad, C_lc, G, n_speakers;
+    const float* colsum;         /* [B][L][2*D_pad]                                           */
+    const float* gc;             /* [B][G]                                                    */
+    float* grads;                /* flat fp32 gradient buffer (same offsets as params)        */
+} aew_spk_bwd_t;
+
+typedef struct {                 /* base layer as a column gather (wavenet.py:348-351)        */
+    const float* wav; int32_t wav_pitch; int32_t wav_off;   /* [B][n_wav] float-encoded ints  */
+    const float* W; const float* bias;                      /* [R][Q] (k=1), [R] or NULL      */
+    int32_t B, T, R, R_pad, Q;
+    uint16_t* x; int64_t x_bs; int32_t x_pitch;             /* bf16 [B][T][R_pad]             */
+    uint16_t* onehot; int64_t oh_bs; int32_t oh_pitch;      /* optional bf16 [B][T][Q_pad]    */
+    int32_t Q_pad;
+} aew_base_gather_t;
+
+typedef struct {                 /* fused log-softmax + NLL (+ gradient)  wavenet.py:543-547  */
+    const float* logits; int64_t bs; int32_t pitch;         /* fp32 [B][w][Q_pad]             */
+    const float* wav; int32_t wav_pitch; int32_t tgt_off;   /* target[b][u] = wav[b][tgt_off+u] */
+    int32_t B, w, Q, Q_pad;      /* positions u in [0, w-1) carry loss; u = w-1 is dropped    */
+    float* nll;                  /* fwd: [B][w] per-position nll (0 at u=w-1)                 */
+    float* ptgt;                 /* fwd: [B][w] probability of the target (chassis.py:266-270)*/
+    uint16_t* dlogits; int64_t dl_bs; int32_t dl_pitch;     /* bwd: bf16 [B][w][Q_pad]        */
+    float scale;                 /* bwd: d(loss)/d(nll term) incl. upstream gradient          */
+    int32_t backward;
+} aew_softmax_nll_t;
+
+typedef struct {                 /* column sums over rows: out[b][n] (+)= sum_m x[b][m][n]     */
+    aew_seg_t x; int32_t dtype; int32_t M, N, batch;
+    float* out; int64_t out_bs; int32_t accumulate;
+} aew_colsum_t;
+
+typedef struct {                 /* v_i = scale_i * sum(x_i[0:n_i]);  out[1+i] = v_i;
+                                    out[0] = sum_i (clamp_i ? post_scale_i*max(v_i, clamp_min_i) : v_i)
+                                    (loss scalar; the clamp is SGVB's free-nats, vae_bn.py:113-116) */
+    const float* x[4]; int32_t n[4]; float scale[4]; int32_t clamp[4]; float clamp_min[4];
+    float post_scale[4]; int32_t n_terms;
+    float* out;                  /* [5] */
+} aew_reduce_t;
+
+typedef struct {                 /* fused Adam over a flat fp32 buffer (torch.optim.Adam defaults,
+                                    checkpoint.py:49-50)                                      */
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float lr, beta1, beta2, eps;
+    float bc1, bc2;              /* 1-beta1^t, 1-beta2^t                                      */
+    float grad_scale;            /* g is multiplied by this first (e.g. 1/world for a mean)   */
+} aew_adam_t;
+
+typedef struct { void* ptr; int64_t bytes; } aew_zero_t;
+
+typedef struct {                 /* VAE reparameterisation (vae_bn.py:44-53) and its backward */
+    const float* lin; int32_t lin_pitch;   /* [Q][2d pitch]: mu | log_sigma_sq               */
+    const float* eps;                       /* [Q][d]                                        */
+    int32_t Q, d, d_pitch;
+    float* sample;                          /* [Q][d_pitch]                                  */
+    float* kl_terms;                        /* fwd: [Q] per-row sum of 1+ls-mu^2-sigma^2     */
+    const float* dsample; float kl_coef;    /* bwd: d(loss)/d(sample); d(loss)/d(KL)          */
+    const float* kl_value; float free_nats; /* bwd: if kl_value != NULL the KL gradient is gated by
+                                               [kl_value[0] >= free_nats] (torch.clamp backward)   */
+    float* dlin;                            /* bwd: [Q][2d pitch]                            */
+    int32_t backward;
+} aew_vae_t;
+
+typedef struct {                 /* AE norm term (ae_bn.py:36-38): | ||ze|| - 1 | per row      */
+    const float* ze; int32_t Q, d, d_pitch;
+    float* term;                 /* fwd: [Q]                                                  */
+    const float* dze_in; float coef; float* dze;  /* bwd: dze = dze_in + coef*sign*ze/||ze||   */
+    int32_t backward;
+} aew_ae_norm_t;
+
+/* ---------------------------------------------------------------------------------------
+ * plan
+ * ------------------------------------------------------------------------------------- */
+enum {
+    AEW_OP_GEMM_NT = 1, AEW_OP_GEMM_TN, AEW_OP_COPY_TABLE, AEW_OP_VQ_NEAREST, AEW_OP_VQ_STATS,
+    AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
+    AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
+    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM
+};
+
+typedef struct {
+    int32_t kind;
+    int32_t tag;                 /* caller-defined label, reported by the timing interface    */
+    union {
+        aew_gemm_nt_t nt; aew_gemm_tn_t tn; aew_copy_table_t copy; aew_vq_nearest_t vqn;
+        aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;
+        aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
+        aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
+        aew_vae_t vae; aew_ae_norm_t aen;
+    } u;
+} aew_op_t;
+
+/* Library / build identification. */
+int aew_abi_version(void);
+/* sizeof(aew_op_t) etc. so the binding can verify its struct mirrors. */
+int aew_sizeof(int which);      /* 0 op, 1 gemm_nt, 2 gemm_tn, 3 seg, 4 view, 5 copy_rec */
+
+/* Execute ops[0..n) in order on `stream` (a hipStream_t).  Returns at the first error and
+ * writes the failing index to *fail_index if non-NULL. */
+int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index);
+
+/* Per-op timing: while enabled, aew_run_plan brackets every op with HIP events on `stream`;
+ * aew_timing_read synchronises the stream and returns elapsed ms per executed op (in
+ * execution order since the last enable) and its tag. */
+int aew_timing_enable(int on);
+int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
+
+/* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */
+int aew_tn_slabs(const aew_gemm_tn_t* g);
+/* 1: read TN fragments with a scalar LDS gather instead of ds_read_b64_tr_b16 (debug aid). */
+int aew_set_tn_safe(int on);
+
+/* Human-readable string for a return code. */
+const char* aew_strerror(int code);
+
+/* Device self-test of the MFMA / LDS-transpose lane mappings this library relies on.
+ * scratch: >= 1 MiB device buffer.  Returns 0 if the hardware behaves as assumed. */
+int aew_selftest(void* scratch, int64_t scratch_bytes, void* stream, int32_t* detail /*[8]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEWAVENET_H */

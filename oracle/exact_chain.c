@@ -5,9 +5,9 @@
  * reproduced bit-exactly.  The reference leaves the summation order to ATen; this file
  * fixes one order, documents it, and the HIP kernels are written to the same order:
  *
- *   conv  : acc = bias[co]; for tap in 0..f-1: for ci in 0..Cin-1:
+ *   conv  : acc = 0; for tap in 0..f-1: for ci in 0..Cin-1:
  *               acc = fmaf(x[t*stride+tap][ci], W[co][ci][tap], acc)
- *           y = relu(acc) (+ x[t+lw][co] if residual)          (wave_encoder.py:39-43)
+ *           y = relu(acc + bias[co]) (+ x[t+lw][co] if residual) (wave_encoder.py:39-43)
  *   dist  : dd = fma-chain_j (z_j-q_j)^2 ; zz = fma-chain_j z_j^2 ; qq = fma-chain_j q_j^2
  *           scaled_l2 = sqrtf(dd) / (sqrtf(zz) + sqrtf(qq))    (vqema_bn.py:67-76)
  *           sq_l2     = dd                                      (vq_bn.py:39)
@@ -41,7 +41,7 @@ int aewo_conv_cl(const float* x, int B, int L, int Cin, const float* W, const fl
     for (int b = 0; b < B; ++b)
         for (int t = 0; t < Lout; ++t) {
             float* acc = y + ((size_t)b * Lout + t) * Cout;
-            for (int co = 0; co < Cout; ++co) acc[co] = bias ? bias[co] : 0.0f;
+            for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
             for (int k = 0; k < f; ++k) {
                 const float* xr = x + ((size_t)b * L + (size_t)t * stride + k) * Cin;
                 for (int ci = 0; ci < Cin; ++ci) {
@@ -50,6 +50,8 @@ int aewo_conv_cl(const float* x, int B, int L, int Cin, const float* W, const fl
                     for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
                 }
             }
+            if (bias)
+                for (int co = 0; co < Cout; ++co) acc[co] = acc[co] + bias[co];
             if (relu)
                 for (int co = 0; co < Cout; ++co) acc[co] = acc[co] > 0.0f ? acc[co] : 0.0f;
             if (res_lw >= 0) {

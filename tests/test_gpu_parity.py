@@ -1,0 +1,480 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X).  Everything goes through the C ABI
+(aew_run_plan).  Checkers: the CPU plan interpreter (tests/plan_emulator.py, itself pinned to
+the reference goldens by tests/test_plan_cpu.py), the golden vectors directly, the exact-order
+C oracle (bit-exact sub-path) and the torch fp32 oracle (full-width training step).
+
+Stated tolerances (bf16 decoder, fp32 accumulate; fp32 exact encoder/VQ):
+  VQ code indices, EMA counts ............ exact
+  encoder / ze (fp32 MFMA fmaf chain) ..... bit-exact vs oracle/exact_chain.c
+  logits (full width) ..................... |err| <= 0.06 abs  (logit scale ~ 1-5)
+  loss .................................... 1 % relative
+  gradients ............................... max-normalised error <= 8 % per tensor, cosine >= 0.995
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from ae_wavenet_amd import _lib as L, config, geometry, model as M, plan as PL
+from ae_wavenet_amd.plan import Mat, Plan, Workspace, make_nt, make_tn, null_view
+from tests.plan_emulator import Emu
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from weights import np_weights  # noqa: E402
+
+DEV = "cuda:0"
+BF, F3 = L.BF16, L.F32
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_selftest_lane_mappings():
+    """MFMA C/D + operand maps, fp32 MFMA = k-ascending fmaf chain, ds_read_b64_tr_b16 and
+    LDS-DMA placement behave as the kernels assume."""
+    lib = L.load()
+    scratch = torch.zeros(1 << 18, dtype=torch.uint8, device=DEV)
+    detail = (C.c_int32 * 8)()
+    rc = lib.aew_selftest(scratch.data_ptr(), scratch.numel(), None, detail)
+    assert rc == 0, f"selftest rc={rc} detail={list(detail)[:5]}"
+
+
+# ----------------------------------------------------------------------------------------------
+# single GEMM ops, random descriptors: GPU MFMA kernel and GPU check kernel vs CPU interpreter
+# ----------------------------------------------------------------------------------------------
+def _fill(ws, name, gen, scale=1.0):
+    t = ws.get(name)
+    v = (torch.rand(t.shape, generator=gen) * 2 - 1) * scale
+    t.copy_(v.to(t.dtype))
+
+
+def _mirror(ws_cpu, dev):
+    ws = Workspace(dev)
+    for n, t in ws_cpu.bufs.items():
+        ws.bufs[n] = t.to(dev)
+    return ws
+
+
+def _nt_case(ws, dtype, epi, impl):
+    B, M_, K1, K2, N_pad = 2, 300, 128, 256, 256
+    pitchA = 256
+    A1 = Mat(ws, "A1", B, 340, pitchA, dtype)
+    A2 = Mat(ws, "A2", B, 400, pitchA, dtype)
+    Wm = Mat(ws, "W", 1, N_pad, 2 * K1 + K2, dtype)
+    segs = [A1.seg(K1, row_off=0), A1.seg(K1, row_off=7, col_off=64, hi=330), A2.seg(K2, row_off=-5, row_step=1)]
+    odt = F3 if dtype == F3 else BF
+    O0 = Mat(ws, "O0", B, 320, 512, odt)
+    O1 = Mat(ws, "O1", B, 320, 256, F3 if epi == L.EPI_RES_SKIP else odt)
+    O2 = Mat(ws, "O2", B, 320, 256, BF)
+    X0 = Mat(ws, "X0", B, 320, 256, odt)
+    X1 = Mat(ws, "X1", B, 320, 256, odt)
+    bias = ws.get("bias")
+    kw = dict(impl=impl)
+    if epi == L.EPI_STORE:
+        return make_nt(dtype, M_, 252, N_pad, B, segs, Wm.ptr, flags=L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE
+                       | L.EF_ADD_AUX0, out0=O0.view(row_off=3, row_step=1), out1=O1.view(),
+                       aux0=X0.view(row_off=-2), bias_ptr=bias.data_ptr(), bias_bs=256, **kw)
+    if epi == "mask":
+        return make_nt(dtype, M_, N_pad, N_pad, B, segs, Wm.ptr, flags=L.EF_OUT1_POS1 | L.EF_ADD_AUX0,
+                       out0=O0.view(), out1=O1.view(), aux0=X0.view(row_off=4, hi=250), aux1=X1.view(), **kw)
+    if epi == L.EPI_GATED:
+        return make_nt(dtype, M_, 128, N_pad, B, segs, Wm.ptr, epi=epi, out0=O0.view(), out1=O1.view(),
+                       out2=O2.view(), bias_ptr=bias.data_ptr(), bias_bs=256, **kw)
+    if epi == L.EPI_RES_SKIP:
+        return make_nt(dtype, M_, N_pad, N_pad, B, segs, Wm.ptr, epi=epi, flags=L.EF_ACCUM | L.EF_OUT2_RELU,
+                       out0=O0.view(), aux0=X0.view(row_off=9), out1=O1.view(row_off=-200, hi=100),
+                       out2=O2.view(row_off=-200, hi=100), n_split=128, **kw)
+    if epi == L.EPI_DFG:
+        return make_nt(dtype, M_, 256, N_pad, B, segs, Wm.ptr, epi=epi, out0=O0.view(), aux0=X0.view(),
+                       aux1=X1.view(), **kw)
+
+
+def _alloc_nt(ws, dtype, epi):
+    tdt = PL.TORCH_DT[dtype]
+    odt = torch.float32 if dtype == F3 else torch.bfloat16
+    ws.alloc("A1", 2 * 340 * 256, tdt); ws.alloc("A2", 2 * 400 * 256, tdt)
+    ws.alloc("W", 256 * 512, tdt)
+    ws.alloc("O0", 2 * 320 * 512, odt)
+    ws.alloc("O1", 2 * 320 * 256, torch.float32 if epi == L.EPI_RES_SKIP else odt)
+    ws.alloc("O2", 2 * 320 * 256, torch.bfloat16)
+    ws.alloc("X0", 2 * 320 * 256, odt); ws.alloc("X1", 2 * 320 * 256, odt)
+    ws.alloc("bias", 2 * 256, torch.float32)
+
+
+@pytest.mark.parametrize("dtype,epi", [(BF, L.EPI_STORE), (BF, "mask"), (BF, L.EPI_GATED), (BF, L.EPI_RES_SKIP),
+                                       (BF, L.EPI_DFG), (F3, L.EPI_STORE), (F3, "mask")])
+def test_gemm_nt(dtype, epi):
+    gen = torch.Generator().manual_seed(1)
+    ws_c = Workspace("cpu")
+    _alloc_nt(ws_c, dtype, epi)
+    for n in ("A1", "A2", "X0", "X1", "O1", "bias"):
+        _fill(ws_c, n, gen)
+    _fill(ws_c, "W", gen, 0.08)
+    results = {}
+    for impl in (0, 1):
+        ws_g = _mirror(ws_c, DEV)
+        p = Plan("nt")
+        p.add(L.OP_GEMM_NT, _nt_case(ws_g, dtype, epi, impl), "nt")
+        p.run(stream())
+        torch.cuda.synchronize()
+        results[impl] = {n: ws_g.get(n).float().cpu() for n in ("O0", "O1", "O2")}
+    ws_e = Workspace("cpu")
+    for n, t in ws_c.bufs.items():
+        ws_e.bufs[n] = t.clone()
+    p = Plan("nt")
+    p.add(L.OP_GEMM_NT, _nt_case(ws_e, dtype, epi, 0), "nt")
+    Emu(ws_e).run(p)
+    tol = 2e-2 if dtype == BF else 2e-5
+    for n in ("O0", "O1", "O2"):
+        ref = ws_e.get(n).float()
+        for impl in (1, 0):
+            err = (results[impl][n] - ref).abs().max().item()
+            assert err <= tol * max(1.0, ref.abs().max().item()), (n, "impl", impl, err)
+    if dtype == F3:
+        # same fmaf chain in the same order: MFMA kernel == scalar check kernel bit for bit
+        assert torch.equal(results[0]["O0"], results[1]["O0"])
+
+
+@pytest.mark.parametrize("dtype", [BF, F3])
+@pytest.mark.parametrize("safe,Mc", [(0, 777), (1, 777), (0, 5000)])
+def test_gemm_tn(dtype, safe, Mc):
+    """Mc=777 folds the batch into one slab; Mc=5000 exercises split-K slabs."""
+    if dtype == F3 and safe:
+        pytest.skip("safe mode only affects the bf16 transpose read")
+    lib = L.load()
+    gen = torch.Generator().manual_seed(2)
+    tdt = PL.TORCH_DT[dtype]
+    B, Np, K1, K2 = 2, 256, 128, 256
+    R0 = Mc + 43
+    ws_c = Workspace("cpu")
+    ws_c.alloc("G", B * R0 * Np, tdt); ws_c.alloc("A1", B * R0 * 256, tdt); ws_c.alloc("A2", B * R0 * 256, tdt)
+    for n in ("G", "A1", "A2"):
+        _fill(ws_c, n, gen)
+
+    def build(ws, impl):
+        Gm = Mat(ws, "G", B, R0, Np, dtype)
+        A1 = Mat(ws, "A1", B, R0, 256, dtype)
+        A2 = Mat(ws, "A2", B, R0, 256, dtype)
+        t = make_tn(dtype, Mc, B, Np, Np, Gm.seg(Np, row_off=3, hi=Mc - 77),
+                    [A1.seg(K1, row_off=11), A1.seg(K1, row_off=-4, col_off=128), A2.seg(K2, row_step=1, row_off=0)],
+                    impl=impl)
+        slabs = L.tn_slabs(t)
+        if "out" not in ws.bufs:
+            ws.alloc("out", slabs * Np * t.K_total, torch.float32)
+        t.out, t.out_batch_stride = ws.get("out").data_ptr(), Np * t.K_total
+        return t, slabs
+
+    res = {}
+    lib.aew_set_tn_safe(safe)
+    try:
+        for impl in (0, 1):
+            ws_g = _mirror(ws_c, DEV)
+            t, slabs = build(ws_g, impl)
+            p = Plan("tn"); p.add(L.OP_GEMM_TN, t, "tn"); p.run(stream())
+            torch.cuda.synchronize()
+            res[impl] = ws_g.get("out")[:slabs * Np * t.K_total].view(slabs, Np, t.K_total).sum(0).cpu()
+    finally:
+        lib.aew_set_tn_safe(0)
+    ws_e = Workspace("cpu")
+    for n, tt in ws_c.bufs.items():
+        ws_e.bufs[n] = tt.clone()
+    t, slabs = build(ws_e, 0)
+    p = Plan("tn"); p.add(L.OP_GEMM_TN, t, "tn"); Emu(ws_e).run(p)
+    ref = ws_e.get("out")[:slabs * Np * t.K_total].view(slabs, Np, t.K_total).sum(0)
+    scale = ref.abs().max().item()
+    for impl in (1, 0):
+        err = (res[impl] - ref).abs().max().item()
+        assert err <= (2e-3 if dtype == BF else 2e-5) * scale, ("impl", impl, "safe", safe, err, scale)
+
+
+# ----------------------------------------------------------------------------------------------
+# whole training steps on the reduced-width golden models: GPU vs interpreter vs golden
+# ----------------------------------------------------------------------------------------------
+def tiny_hps(z, **over):
+    h = json.loads(str(z["hps_json"]))
+    n_mel = h.pop("n_mel_ch", None)
+    return config.make_hps(**{k: v for k, v in h.items() if k not in over}, **over), n_mel
+
+
+def build_pair(z, kind, n_mel, **kw):
+    hps, nm = tiny_hps(z, global_model=kind)
+    B = z["wav"].shape[0]
+    engs = []
+    for dev in ("cpu", DEV):
+        e = M.TrainEngine(hps, B=B, device=dev, n_mel=n_mel or nm, take_compat=True,
+                          update_codebook_every_step=False, **kw)
+        for k in e.ps.names():
+            e.ps.view(k).copy_(torch.from_numpy(z["w." + k]))
+        if e.bn_type == "vqvae-ema":
+            e.emb.copy_(torch.from_numpy(z["emb0"]))
+            e.init_ema_from_emb()
+        engs.append(e)
+    return hps, engs[0], engs[1]
+
+
+def run_pair(ec, eg, z, eps=None):
+    args = [torch.from_numpy(z[k]) for k in ("wav", "mel", "voice", "jitter")]
+    ec.set_inputs(*args, eps=eps)
+    eg.set_inputs(*[a.to(DEV) for a in args], eps=None if eps is None else eps.to(DEV))
+    emu = Emu(ec.ws)
+    for name in ("fwd_a", "fwd_b", "bwd"):
+        emu.run(getattr(ec, name))
+    eg.forward()
+    eg.backward()
+    torch.cuda.synchronize()
+
+
+def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.")):
+    """First buffers (in allocation order) whose GPU content deviates from the interpreter."""
+    bad = []
+    for n, tc in ec.ws.bufs.items():
+        if n.startswith(skip_prefix) or ".wg." in n or n.startswith("enc.wg") or n.startswith("bn.wg"):
+            continue                     # wgrad slabs: split layout is implementation detail
+        tg = eg.ws.get(n).cpu()
+        if tc.dtype in (torch.int64, torch.int32):
+            if not torch.equal(tc, tg):
+                bad.append((n, "int mismatch"))
+            continue
+        a, b = tc.float(), tg.float()
+        scale = max(a.abs().max().item(), 1e-6)
+        err = (a - b).abs().max().item() / scale
+        lim = 3e-2 if tc.dtype == torch.bfloat16 else 2e-2
+        if not np.isfinite(err) or err > lim:
+            bad.append((n, round(err, 5)))
+    return bad
+
+
+def grads_vs_golden(eng, z, tag, lim=0.25):
+    for k in eng.ps.names():
+        ref = z[f"{tag}.{k}"]
+        got = eng.ps.view(k, grad=True).cpu().numpy()
+        if ref.size == 0:
+            assert np.abs(got).max() == 0, k
+            continue
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        assert err < lim, (k, err)
+
+
+@pytest.mark.parametrize("tag", ["identity", "jitter"])
+def test_mfcc_inverter_step(golden_dir, tag):
+    z = load(golden_dir, f"mi_tiny_{tag}.npz")
+    hps, ec, eg = build_pair(z, "mfcc_inverter", 7)
+    run_pair(ec, eg, z)
+    bad = diff_workspaces(ec, eg)
+    assert not bad, bad[:8]
+    pred = eg.logits()[:, :-1, :].permute(0, 2, 1).cpu().numpy()
+    np.testing.assert_allclose(pred, z["pred"], rtol=5e-2, atol=3e-2)
+    assert abs(float(eg.loss_buf[0]) - float(z["loss"])) < 2e-2
+    grads_vs_golden(eg, z, "grad")
+
+
+@pytest.mark.parametrize("name,gtag,ltag,kw", [
+    ("ae_tiny_vqvae-ema_random.npz", "gint", "loss_intended", dict(loss_mode="intended")),
+    ("ae_tiny_vqvae-ema_identity.npz", "ghead", "loss_head", dict(loss_mode="head")),
+    ("ae_tiny_ae_identity.npz", "g", "loss", {}),
+    ("ae_tiny_vqvae_identity.npz", "gint", "loss_intended", {}),
+])
+def test_autoencoder_step(golden_dir, name, gtag, ltag, kw):
+    z = load(golden_dir, name)
+    hps, ec, eg = build_pair(z, "autoencoder", None, **kw)
+    run_pair(ec, eg, z)
+    bad = diff_workspaces(ec, eg)
+    assert not bad, bad[:8]
+    if "min_ind" in z:
+        assert np.array_equal(eg.ind[:eg.Q].view(eg.B, -1).cpu().numpy(), z["min_ind"])       # bit-exact
+    assert abs(float(eg.loss_buf[0]) / float(z[ltag]) - 1) < 1e-2
+    grads_vs_golden(eg, z, gtag)
+    if hps.bn_type == "vqvae-ema":
+        np.testing.assert_array_equal(eg.n_sum.cpu().numpy(), z["n_sum"])
+        np.testing.assert_allclose(eg.z_sum.cpu().numpy(), z["z_sum"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(eg.ema_numer.cpu().numpy(), z["ema_numer"], rtol=1e-5, atol=1e-7)
+        eg.update_codebook()
+        np.testing.assert_allclose(eg.emb.cpu().numpy(), z["emb1"], rtol=1e-4, atol=1e-6)
+
+
+def test_autoencoder_vae_step(golden_dir):
+    z = load(golden_dir, "ae_tiny_vae_random.npz")
+    hps, _ = tiny_hps(z, global_model="autoencoder")
+    hps = config.make_hps(**{**dict(hps), "bn_free_nats": float(z["free_nats"])})
+    engs = []
+    for dev in ("cpu", DEV):
+        e = M.TrainEngine(hps, B=2, device=dev, n_mel=9, take_compat=True)
+        for k in e.ps.names():
+            e.ps.view(k).copy_(torch.from_numpy(z["w." + k]))
+        e.set_anneal_weight(float(z["anneal"]))
+        engs.append(e)
+    ec, eg = engs
+    run_pair(ec, eg, z, eps=torch.from_numpy(z["eps"]))
+    bad = diff_workspaces(ec, eg)
+    assert not bad, bad[:8]
+    assert abs(float(eg.loss_buf[0]) / float(z["loss"]) - 1) < 1e-2
+    grads_vs_golden(eg, z, "g")
+
+
+# ----------------------------------------------------------------------------------------------
+# bit-exact sub-path at full width: encoder -> linear -> VQ vs the exact-order C oracle
+# ----------------------------------------------------------------------------------------------
+def seeded_full_engine(B, w, seed=3, n_embed=4096):
+    hps = config.make_hps("vqvae-ema", n_win_batch=w, bn_vq_n_embed=n_embed)
+    eng = M.TrainEngine(hps, B=B, device=DEV, n_mel=39)
+    shapes = {k: eng.ps.shape[k] for k in eng.ps.names()}
+    wts = np_weights(shapes, seed)
+    for k, v in wts.items():
+        eng.ps.view(k).copy_(torch.from_numpy(v))
+    rs = np.random.RandomState(seed + 1)
+    emb = (rs.standard_normal((n_embed, hps.bn_n_out)) * 0.7).astype(np.float32)
+    eng.emb.copy_(torch.from_numpy(emb))
+    eng.init_ema_from_emb()
+    g = eng.geom
+    wav = torch.from_numpy(rs.randint(0, 256, (B, g.enc_in_len)).astype(np.float32))
+    mel = torch.from_numpy(rs.standard_normal((B, 39, g.mel_len)).astype(np.float32))
+    voice = torch.from_numpy(rs.randint(0, 40, (B,)).astype(np.int64))
+    jitter = torch.arange(g.embed_len).repeat(B, 1)
+    return hps, eng, wts, emb, (wav, mel, voice, jitter)
+
+
+def test_encoder_vq_bit_exact_full_width():
+    from oracle import exact
+    hps, eng, wts, emb, inp = seeded_full_engine(B=2, w=100)
+    eng.set_inputs(*[t.to(DEV) for t in inp])
+    eng.fwd_a.run(stream())
+    torch.cuda.synchronize()
+    mel_cl = inp[1].permute(0, 2, 1).contiguous().numpy()
+    enc = exact.encoder_cl(wts, "encoder.", mel_cl)
+    got_enc = eng.enc.y[9].tensor()[:, :, :768].cpu().numpy()
+    assert np.array_equal(got_enc, enc), f"encoder not bit-exact: max diff {np.abs(got_enc - enc).max()}"
+    ze = exact.linear_cl(enc, wts["bottleneck.linear.weight"])
+    got_ze = eng.lin.tensor()[:, :, :32].cpu().numpy()
+    assert np.array_equal(got_ze, ze)
+    ind, dist, sec = exact.vq_nearest(ze.reshape(-1, 32), emb, "scaled_l2")
+    assert np.array_equal(eng.ind[:eng.Q].cpu().numpy(), ind)
+    assert np.array_equal(eng.min_dist[:eng.Q].cpu().numpy(), dist)
+    z_sum, n_sum = exact.vq_stats(ze.reshape(-1, 32), ind, 4096)
+    assert np.array_equal(eng.z_sum.cpu().numpy(), z_sum) and np.array_equal(eng.n_sum.cpu().numpy(), n_sum)
+    numer, denom = exact.ema(emb * np.float32(1 - 0.99), np.full(4096, 1 - 0.99, np.float32), z_sum, n_sum, 0.99)
+    eng.fwd_b.run(stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.ema_numer.cpu().numpy(), numer) and np.array_equal(eng.ema_denom.cpu().numpy(), denom)
+    eng.update_codebook()
+    assert np.array_equal(eng.emb.cpu().numpy(), exact.codebook(numer, denom))
+    print(f"min top-2 margin (relative): {((sec - dist) / dist).min():.3e}")
+
+
+# ----------------------------------------------------------------------------------------------
+# full-width training step vs the torch fp32 oracle
+# ----------------------------------------------------------------------------------------------
+def test_full_width_step_vs_oracle():
+    from oracle import ref_model as R
+    hps, eng, wts, emb, inp = seeded_full_engine(B=2, w=100)
+    eng.set_inputs(*[t.to(DEV) for t in inp])
+    loss = eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in wts.items()}
+    out = R.ae_run(sd, {"emb": torch.from_numpy(emb)}, hps, eng.geom, *inp, loss_mode="intended", take_compat=False)
+    out["loss"].backward()
+    assert np.array_equal(eng.ind[:eng.Q].cpu().numpy(), out["min_ind"].reshape(-1).numpy()), \
+        "end-to-end code indices differ from the fp32 oracle"
+    lg = eng.logits().permute(0, 2, 1).cpu()
+    err = (lg - out["quant"].detach()).abs().max().item()
+    print(f"logit max abs err {err:.4f} (scale {out['quant'].abs().max().item():.2f})")
+    assert err <= 0.06
+    assert abs(float(loss) / float(out["loss"]) - 1) < 1e-2
+    worst = (0.0, "")
+    for k in eng.ps.names():
+        ref = sd[k].grad
+        got = eng.ps.view(k, grad=True).cpu()
+        if ref is None:
+            continue
+        scale = ref.abs().max().item()
+        if scale == 0:
+            continue
+        e = (got - ref).abs().max().item() / scale
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        worst = max(worst, (e, k))
+        assert e < 0.08 and cos > 0.995, (k, e, cos)
+    print("worst gradient max-normalised error:", worst)
+
+
+def test_module_surface_trains():
+    """Drop-in surface: run() -> loss.backward() -> FusedAdam.step() reduces the loss on a
+    fixed batch; torch.optim.Adam on the same parameters gives the same first update."""
+    from ae_wavenet_amd import autoencoder_model as ae, optim
+    hps = config.make_hps("vqvae-ema", n_res=64, n_dil=64, n_skp=64, n_post=64, n_lc_out=32, enc_n_out=64,
+                          bn_n_out=16, bn_vq_n_embed=128, n_win_batch=256, n_blocks=2, n_block_layers=5)
+    torch.manual_seed(0)
+    m = ae.AutoEncoder(hps, n_mel=39).to(DEV)
+    opt = optim.FusedAdam(m, lr=1e-3)
+    g = m.geom
+    gen = torch.Generator().manual_seed(1)
+    wav = torch.randint(0, 256, (4, g.enc_in_len), generator=gen).float().to(DEV)
+    mel = torch.randn(4, 39, g.mel_len, generator=gen).to(DEV)
+    voice = torch.randint(0, 40, (4,), generator=gen).to(DEV)
+    jitter = torch.arange(g.embed_len).repeat(4, 1).to(DEV)
+    losses = []
+    for it in range(12):
+        opt.zero_grad()
+        pred, target, loss = m.run(wav, mel, voice, jitter)
+        assert pred.shape == (4, 256, 255) and target.shape == (4, 255)
+        loss.backward()
+        if it == 0:
+            n_with_grad = sum(1 for p in m.parameters() if p.grad is not None and p.grad.abs().sum() > 0)
+            assert n_with_grad > 0.9 * len(list(m.parameters()))
+        opt.step()
+        losses.append(float(m.objective.metrics["rec"]))
+    assert losses[-1] < losses[0] - 0.2, losses
+    sd = m.state_dict()
+    assert "decoder.conv_layers.3.conv_signal.weight" in sd and "bottleneck.emb" in sd
+
+
+# ----------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE.json's full size (B=8, w=5000)
+# ----------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    hps, eng, wts, emb, inp = seeded_full_engine(B=8, w=5000, seed=7)
+    wav, mel, voice, jitter = [t.to(DEV) for t in inp]
+    eng.set_inputs(wav, mel, voice, jitter)
+    l0 = float(eng.forward())
+    eng.backward()
+    torch.cuda.synchronize()
+    lg0 = eng.logits().clone()
+    ind0 = eng.ind[:eng.Q].clone()
+    g0 = eng.ps.grads[:eng.ps.numel].clone()
+    assert np.isfinite(l0) and torch.isfinite(g0).all()
+    # (1) determinism of the integer path and of the forward
+    eng.init_ema_from_emb()
+    l1 = float(eng.forward())
+    assert torch.equal(eng.ind[:eng.Q], ind0) and l1 == l0 and torch.equal(eng.logits(), lg0)
+    # (2) batch-permutation equivariance: permuting the windows permutes logits/indices and
+    #     leaves the (sum-type) loss and the gradients unchanged up to summation order
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=DEV)
+    eng.init_ema_from_emb()
+    eng.set_inputs(wav[perm], mel[perm], voice[perm], jitter[perm])
+    l2 = float(eng.forward())
+    eng.backward()
+    torch.cuda.synchronize()
+    Ne = eng.geom.embed_len
+    assert torch.equal(eng.ind[:eng.Q].view(8, Ne), ind0.view(8, Ne)[perm])
+    assert torch.equal(eng.logits(), lg0[perm])
+    assert abs(l2 / l0 - 1) < 1e-5
+    g2 = eng.ps.grads[:eng.ps.numel]
+    rel = (g2 - g0).abs().max().item() / g0.abs().max().item()
+    assert rel < 2e-3, rel
+    # (3) causality of the valid-conv stack: the target-independent logits do not change when
+    #     the wav samples after the last decoder input are altered
+    wav2 = wav.clone()
+    wav2[:, eng.geom.trim_dec_in[1]:] = 0
+    eng.init_ema_from_emb()
+    eng.set_inputs(wav2, mel, voice, jitter)
+    eng.forward()
+    assert torch.equal(eng.logits(), lg0)

@@ -1,0 +1,181 @@
+"""Plan construction verified on CPU: a TrainEngine is built on device 'cpu' (plans only — it
+cannot execute them), the CPU plan interpreter (tests/plan_emulator.py) runs the exact op
+records, and results are compared with the golden vectors captured from the reference.
+
+Two passes: 'wide' stores the decoder's bf16 tensors as fp32 (tight tolerances: checks every
+index map / pack record / epilogue flag), 'bf16' keeps the real storage types (loose
+tolerance: sizes the rounding error the GPU path will show)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ae_wavenet_amd import _lib as L, config, model as M, plan as PL
+from tests.plan_emulator import Emu
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+@pytest.fixture(params=["wide", "bf16"])
+def mode(request, monkeypatch):
+    if request.param == "wide":
+        monkeypatch.setitem(PL.TORCH_DT, L.BF16, torch.float32)
+        monkeypatch.setitem(PL.ESIZE, L.BF16, 4)
+    return request.param
+
+
+def tiny_hps(z, **over):
+    h = json.loads(str(z["hps_json"]))
+    n_mel = h.pop("n_mel_ch", None)
+    return config.make_hps(**{k: v for k, v in h.items() if k not in over}, **over), n_mel
+
+
+def make_engine(z, kind, n_mel, loss_mode="intended"):
+    hps, nm = tiny_hps(z, global_model=kind)
+    eng = M.TrainEngine(hps, B=z["wav"].shape[0], device="cpu", n_mel=n_mel or nm, loss_mode=loss_mode,
+                        take_compat=True, update_codebook_every_step=False)
+    for k in eng.ps.names():
+        eng.ps.view(k).copy_(torch.from_numpy(z["w." + k]))
+    return hps, eng
+
+
+def run(eng, z, eps=None):
+    eng.set_inputs(torch.from_numpy(z["wav"]), torch.from_numpy(z["mel"]), torch.from_numpy(z["voice"]),
+                   torch.from_numpy(z["jitter"]), eps=eps)
+    emu = Emu(eng.ws)
+    emu.run(eng.fwd_a)
+    emu.run(eng.fwd_b)
+    emu.run(eng.bwd)
+    return emu
+
+
+def tol(mode, tight, loose):
+    return tight if mode == "wide" else loose
+
+
+def check_grads(eng, z, tag, mode, skip=()):
+    worst = 0.0
+    for k in eng.ps.names():
+        ref = z[f"{tag}.{k}"]
+        got = eng.ps.view(k, grad=True).numpy()
+        if ref.size == 0:
+            assert np.abs(got).max() == 0, k
+            continue
+        scale = max(np.abs(ref).max(), 1e-12)
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, err)
+        assert err < tol(mode, 2e-4, 0.25), (k, err)
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["identity", "jitter"])
+def test_mfcc_inverter_plan(golden_dir, mode, tag):
+    z = load(golden_dir, f"mi_tiny_{tag}.npz")
+    hps, eng = make_engine(z, "mfcc_inverter", 7)
+    run(eng, z)
+    pred = eng.logits()[:, :-1, :].permute(0, 2, 1).numpy()
+    np.testing.assert_allclose(pred, z["pred"], rtol=tol(mode, 1e-4, 5e-2), atol=tol(mode, 2e-5, 3e-2))
+    assert abs(float(eng.loss_buf[0]) - float(z["loss"])) < tol(mode, 1e-5, 2e-2)
+    check_grads(eng, z, "grad", mode)
+    # d(loss)/d(mel) comes out of the jitter scatter (channels-last)
+    mg = eng.dec.dlc_src.tensor()[:, :, :7].permute(0, 2, 1).numpy()
+    scale = np.abs(z["mel_grad"]).max()
+    assert np.abs(mg - z["mel_grad"]).max() / scale < tol(mode, 2e-4, 6e-2)
+
+
+@pytest.mark.parametrize("jk,loss_mode,gtag,ltag", [("random", "intended", "gint", "loss_intended"),
+                                                    ("identity", "intended", "gint", "loss_intended"),
+                                                    ("random", "head", "ghead", "loss_head")])
+def test_autoencoder_vqema_plan(golden_dir, mode, jk, loss_mode, gtag, ltag):
+    z = load(golden_dir, f"ae_tiny_vqvae-ema_{jk}.npz")
+    hps, eng = make_engine(z, "autoencoder", None, loss_mode)
+    eng.emb.copy_(torch.from_numpy(z["emb0"]))
+    eng.init_ema_from_emb()
+    run(eng, z)
+    ze = eng.lin.tensor()[:, :, :eng.d].permute(0, 2, 1).numpy()
+    np.testing.assert_allclose(ze, z["ze"], rtol=2e-5, atol=2e-6)
+    assert np.array_equal(eng.ind[:eng.Q].view(eng.B, -1).numpy(), z["min_ind"])
+    np.testing.assert_allclose(eng.min_dist[:eng.Q].view(eng.B, -1).numpy(), z["min_dist"], rtol=1e-5)
+    np.testing.assert_allclose(eng.z_sum.numpy(), z["z_sum"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(eng.n_sum.numpy(), z["n_sum"])
+    np.testing.assert_allclose(eng.ema_numer.numpy(), z["ema_numer"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(eng.ema_denom.numpy(), z["ema_denom"], rtol=1e-5)
+    pred = eng.logits()[:, :-1, :].permute(0, 2, 1).numpy()
+    np.testing.assert_allclose(pred, z["pred"], rtol=tol(mode, 1e-4, 5e-2), atol=tol(mode, 2e-5, 3e-2))
+    assert abs(float(eng.loss_buf[0]) / float(z[ltag]) - 1) < tol(mode, 1e-5, 5e-3)
+    check_grads(eng, z, gtag, mode)
+    mg = eng.enc.dy[0].tensor()[:, :, :9].permute(0, 2, 1).numpy()
+    ref = z[gtag + ".@mel"]
+    assert np.abs(mg - ref).max() / np.abs(ref).max() < tol(mode, 2e-4, 6e-2)
+    bg = eng.dec.dlc_src.tensor()[:, :, :eng.d].permute(0, 2, 1).numpy()
+    ref = z[gtag + ".@encoding_bn"]
+    if ref.size:
+        assert np.abs(bg - ref).max() / max(np.abs(ref).max(), 1e-12) < tol(mode, 2e-4, 6e-2)
+    # codebook refresh
+    Emu(eng.ws).run(eng.cb)
+    np.testing.assert_allclose(eng.emb.numpy(), z["emb1"], rtol=1e-4, atol=1e-6)
+    # enc_az metric (wave_encoder.py:46)
+    cnt = eng.enc.zero_cnt[:9].numpy().astype(np.float64)
+    numel = np.array([eng.B * eng.geom.enc_lens[i + 1] * hps.enc_n_out for i in range(9)], np.float64)
+    np.testing.assert_allclose(cnt / numel, z["enc_frac_zero"], atol=1e-9)
+
+
+def test_autoencoder_vae_plan(golden_dir, mode):
+    z = load(golden_dir, "ae_tiny_vae_random.npz")
+    hps, eng = make_engine(z, "autoencoder", None)
+    eng.hps.bn_free_nats = float(z["free_nats"])
+    # rebuild so the free-nats clamp is baked with the fixture's value
+    hps2 = config.make_hps(**{**dict(hps), "bn_free_nats": float(z["free_nats"])})
+    eng = M.TrainEngine(hps2, B=2, device="cpu", n_mel=9, take_compat=True)
+    for k in eng.ps.names():
+        eng.ps.view(k).copy_(torch.from_numpy(z["w." + k]))
+    eng.set_anneal_weight(float(z["anneal"]))
+    run(eng, z, eps=torch.from_numpy(z["eps"]))
+    pred = eng.logits()[:, :-1, :].permute(0, 2, 1).numpy()
+    np.testing.assert_allclose(pred, z["pred"], rtol=tol(mode, 1e-4, 5e-2), atol=tol(mode, 2e-5, 3e-2))
+    assert abs(float(eng.loss_buf[0]) / float(z["loss"]) - 1) < tol(mode, 1e-5, 5e-3)
+    assert abs(float(eng.loss_buf[2]) / float(z["metric.kl_div_loss"]) - 1) < 1e-5
+    check_grads(eng, z, "g", mode)
+
+
+def test_autoencoder_ae_plan(golden_dir, mode):
+    z = load(golden_dir, "ae_tiny_ae_identity.npz")
+    hps, eng = make_engine(z, "autoencoder", None)
+    run(eng, z)
+    assert abs(float(eng.loss_buf[0]) / float(z["loss"]) - 1) < tol(mode, 1e-5, 5e-3)
+    check_grads(eng, z, "g", mode)
+
+
+def test_autoencoder_vq_plan(golden_dir, mode):
+    z = load(golden_dir, "ae_tiny_vqvae_identity.npz")
+    hps, eng = make_engine(z, "autoencoder", None)
+    run(eng, z)
+    assert np.array_equal(eng.ind[:eng.Q].view(eng.B, -1).numpy(), z["min_ind"])
+    assert abs(float(eng.loss_buf[0]) / float(z["loss_intended"]) - 1) < tol(mode, 1e-5, 5e-3)
+    check_grads(eng, z, "gint", mode)
+
+
+def test_adam_plan(mode):
+    hps = config.make_hps("mi", n_res=8, n_dil=8, n_skp=8, n_post=8, n_lc_out=8, n_global_embed=2,
+                          n_speakers=3, n_blocks=1, n_block_layers=2, n_win_batch=5, n_lc_in=4)
+    eng = M.TrainEngine(hps, B=1, device="cpu", n_mel=4)
+    torch.manual_seed(0)
+    n = eng.ps.numel
+    p0 = torch.randn(n)
+    eng.ps.params[:n].copy_(p0)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-4)
+    for step in range(3):
+        g = torch.randn(n)
+        eng.ps.grads[:n].copy_(g)
+        ref.grad = g.clone()
+        opt.step()
+        eng.step_count += 1
+        a = eng.opt.array()[0].u.adam
+        a.lr, a.bc1, a.bc2 = 3e-4, 1 - 0.9 ** eng.step_count, 1 - 0.999 ** eng.step_count
+        Emu(eng.ws).run(eng.opt)
+        np.testing.assert_allclose(eng.ps.params[:n].numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
