@@ -143,37 +143,59 @@ __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, in
     return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
 }
 
-// issue one K tile (X rows then W rows) into LDS stage `stage`
-__device__ __forceinline__ void nt_issue_bf16(const aew_gemm_nt_t& g, char* stage, int b, int m0, int n0,
-                                              const KIter& it, int wave, int lane) {
-    const aew_seg_t& s = g.seg[it.seg];
+// Per-lane source pointers of the 4 X pieces + 4 W pieces a wave stages per K tile.  They are
+// computed once per segment (X) / once per kernel (W) and advanced by one K tile per step, so
+// the K loop carries no address arithmetic beyond 64-bit adds.
+struct NtPtrs {
+    const char* x[4];
+    const char* w[4];
+    int xinc[4];
+};
+
+__device__ __forceinline__ void nt_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
+                                           NtPtrs& P) {
+    const aew_seg_t& s = g.seg[seg];
     const int lr = lane >> 3, pc = lane & 7;
-    // X: 128 rows = 16 pieces of 8 rows; wave w takes pieces w*4 .. w*4+3
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (wave * 4 + j) * 8 + lr;
-        const int c = nt_swz(r, pc);
         const char* src = seg_row_ptr(s, b, m0 + r, 2);
-        src = src ? src + (it.kin + c * 8) * 2 : reinterpret_cast<const char*>(aew_zero_page);
-        glds16(src, stage + (wave * 4 + j) * 1024);
+        P.x[j] = src ? src + (nt_swz(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
+        P.xinc[j] = src ? NT_BK * 2 : 0;
     }
+}
+
+__device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int wave, int lane, NtPtrs& P) {
+    const int lr = lane >> 3, pc = lane & 7;
     const char* wbase = reinterpret_cast<const char*>(g.W);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (wave * 4 + j) * 8 + lr;
-        const int c = nt_swz(r, pc);
-        const char* src = wbase + ((int64_t)(n0 + r) * g.K_total + it.kglob + c * 8) * 2;
-        glds16(src, stage + NT_BM * NT_ROWB + (wave * 4 + j) * 1024);
+        P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 2 + (nt_swz(r, pc) << 4);
     }
 }
 
+__device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs& P) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        glds16(P.x[j], stage + (wave * 4 + j) * 1024);
+        P.x[j] += P.xinc[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        glds16(P.w[j], stage + NT_BM * NT_ROWB + (wave * 4 + j) * 1024);
+        P.w[j] += NT_BK * 2;
+    }
+}
+
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
     const int m0 = blockIdx.x * NT_BM, n0 = blockIdx.y * NT_BN, b = blockIdx.z;
     // RES_SKIP: skip-part tiles that lie entirely before the skip window do nothing
-    if (g.epi == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
+    if (EPI == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
         const int64_t last = (int64_t)(min(m0 + NT_BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
         if (last < g.out1.row_lo) return;
     }
@@ -184,31 +206,42 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    KIter it; it.init();
-    nt_issue_bf16(g, smem, b, m0, n0, it, wave, lane);
+    NtPtrs P;
+    int seg = 0, kin = 0;
+    nt_setup_w(g, n0, wave, lane, P);
+    nt_setup_x(g, 0, b, m0, wave, lane, P);
+    nt_issue_bf16(smem, wave, P);
     const int fi = lane & 15, fg = lane >> 4;
+    // fragment byte offsets inside a stage (constant over the K loop)
+    int woff[4][2], xoff[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rw = wn * 64 + i * 16 + fi, rx = wm * 64 + i * 16 + fi;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            woff[i][kk] = NT_BM * NT_ROWB + rw * NT_ROWB + (nt_swz(rw, kk * 4 + fg) << 4);
+            xoff[i][kk] = rx * NT_ROWB + (nt_swz(rx, kk * 4 + fg) << 4);
+        }
+    }
     for (int t = 0; t < nkt; ++t) {
         wait_vm0();
         __syncthreads();
         if (t + 1 < nkt) {
-            it.advance(g.seg, NT_BK);
-            nt_issue_bf16(g, smem + ((t + 1) & 1) * NT_STAGE_BYTES, b, m0, n0, it, wave, lane);
+            kin += NT_BK;
+            if (kin >= g.seg[seg].k_len) {             // wave-uniform: next segment
+                ++seg; kin = 0;
+                nt_setup_x(g, seg, b, m0, wave, lane, P);
+            }
+            nt_issue_bf16(smem + ((t + 1) & 1) * NT_STAGE_BYTES, wave, P);
         }
-        const char* xs = smem + (t & 1) * NT_STAGE_BYTES;
-        const char* ws = xs + NT_BM * NT_ROWB;
+        const char* st = smem + (t & 1) * NT_STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t wf[4], xf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = wn * 64 + i * 16 + fi;
-                wf[i] = *reinterpret_cast<const bf16x8_t*>(ws + r * NT_ROWB + (nt_swz(r, kk * 4 + fg) << 4));
-            }
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i][kk]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wm * 64 + j * 16 + fi;
-                xf[j] = *reinterpret_cast<const bf16x8_t*>(xs + r * NT_ROWB + (nt_swz(r, kk * 4 + fg) << 4));
-            }
+            for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j][kk]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -221,30 +254,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + fi;
-        if (m >= g.M) continue;
-        if (g.epi == AEW_EPI_GATED) {
+        const bool mok = m < g.M;
+        if (EPI == AEW_EPI_GATED) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int np_f = n0 + wn * 64 + p * 32 + 4 * fg;          // packed column of the filt quad
                 const int ch = (np_f >> 5) * 16 + 4 * fg;
-                if (ch >= g.N) continue;
                 float f[4] = {acc[2 * p][j][0], acc[2 * p][j][1], acc[2 * p][j][2], acc[2 * p][j][3]};
                 float q[4] = {acc[2 * p + 1][j][0], acc[2 * p + 1][j][1], acc[2 * p + 1][j][2], acc[2 * p + 1][j][3]};
-                epi_gated4(g, b, m, np_f, ch, f, q);
+                if (mok && ch < g.N) epi_gated4(g, b, m, np_f, ch, f, q);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = n0 + wn * 64 + i * 16 + 4 * fg;
-                if (n >= g.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (g.epi == AEW_EPI_STORE) epi_store4(g, b, m, n, v, zc);
-                else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip4(g, b, m, n, v);
-                else epi_dfg4(g, b, m, n, v);
+                if (mok && n < g.N) {
+                    if (EPI == AEW_EPI_STORE) epi_store4(g, b, m, n, v, zc);
+                    else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip4(g, b, m, n, v);
+                    else epi_dfg4(g, b, m, n, v);
+                }
             }
         }
     }
-    if ((g.flags & AEW_EF_COUNT_ZERO) && g.epi == AEW_EPI_STORE) {
+    if (EPI == AEW_EPI_STORE && (g.flags & AEW_EF_COUNT_ZERO)) {
         zc = (unsigned)wave_sum((float)zc);
         if (lane == 0 && zc) atomicAdd(g.counter, (unsigned long long)zc);
     }
@@ -259,25 +292,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) 
 #define NF_BK 32
 #define NF_STAGE_BYTES ((NF_BM + NF_BN) * 128)      // 12 KiB
 
-__device__ __forceinline__ void nt_issue_f32(const aew_gemm_nt_t& g, char* stage, int b, int m0, int n0,
-                                             const KIter& it, int wave, int lane) {
-    const aew_seg_t& s = g.seg[it.seg];
+struct NfPtrs {
+    const char* x;
+    const char* w[2];
+    int xinc;
+};
+
+__device__ __forceinline__ void nf_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
+                                           NfPtrs& P) {
+    // 96 staged rows = 12 pieces of 8 rows: pieces 0..3 = X (one per wave), 4..11 = W
     const int lr = lane >> 3, pc = lane & 7;
-    // 96 rows = 12 pieces of 8 rows: pieces 0..3 = X, 4..11 = W; wave w takes pieces w, w+4, w+8
-    {
-        const int r = wave * 8 + lr;
-        const int c = nt_swz(r, pc);
-        const char* src = seg_row_ptr(s, b, m0 + r, 4);
-        src = src ? src + (it.kin + c * 4) * 4 : reinterpret_cast<const char*>(aew_zero_page);
-        glds16(src, stage + wave * 1024);
-    }
-    const char* wbase = reinterpret_cast<const char*>(g.W);
+    const int r = wave * 8 + lr;
+    const char* src = seg_row_ptr(g.seg[seg], b, m0 + r, 4);
+    P.x = src ? src + (nt_swz(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
+    P.xinc = src ? NF_BK * 4 : 0;
+}
+
+__device__ __forceinline__ void nf_issue(char* stage, int wave, NfPtrs& P) {
+    glds16(P.x, stage + wave * 1024);
+    P.x += P.xinc;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int r = (wave + 4 * j) * 8 + lr;
-        const int c = nt_swz(r, pc);
-        const char* src = wbase + ((int64_t)(n0 + r) * g.K_total + it.kglob + c * 4) * 4;
-        glds16(src, stage + NF_BM * 128 + (wave + 4 * j) * 1024);
+        glds16(P.w[j], stage + NF_BM * 128 + (wave + 4 * j) * 1024);
+        P.w[j] += NF_BK * 4;
     }
 }
 
@@ -289,19 +326,34 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
     f32x4_t acc[2];
     acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    KIter it; it.init();
-    nt_issue_f32(g, smem, b, m0, n0, it, wave, lane);
+    NfPtrs P;
+    {
+        const int lr = lane >> 3, pc = lane & 7;
+        const char* wbase = reinterpret_cast<const char*>(g.W);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wave + 4 * j) * 8 + lr;
+            P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 4 + (nt_swz(r, pc) << 4);
+        }
+    }
+    int seg = 0, kin = 0;
+    nf_setup_x(g, 0, b, m0, wave, lane, P);
+    nf_issue(smem, wave, P);
     const int fi = lane & 15, kq = lane >> 4;
+    const int rw = wave * 16 + fi;
     for (int t = 0; t < nkt; ++t) {
         wait_vm0();
         __syncthreads();
         if (t + 1 < nkt) {
-            it.advance(g.seg, NF_BK);
-            nt_issue_f32(g, smem + ((t + 1) & 1) * NF_STAGE_BYTES, b, m0, n0, it, wave, lane);
+            kin += NF_BK;
+            if (kin >= g.seg[seg].k_len) {
+                ++seg; kin = 0;
+                nf_setup_x(g, seg, b, m0, wave, lane, P);
+            }
+            nf_issue(smem + ((t + 1) & 1) * NF_STAGE_BYTES, wave, P);
         }
         const char* xs = smem + (t & 1) * NF_STAGE_BYTES;
         const char* ws = xs + NF_BM * 128;
-        const int rw = wave * 16 + fi;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const float wv = *reinterpret_cast<const float*>(ws + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
@@ -318,9 +370,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + j * 16 + fi;
         const int n = n0 + wave * 16 + 4 * kq;
-        if (m >= g.M || n >= g.N) continue;
         float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-        epi_store4(g, b, m, n, v, zc);
+        if (m < g.M && n < g.N) epi_store4(g, b, m, n, v, zc);
     }
     if (g.flags & AEW_EF_COUNT_ZERO) {
         zc = (unsigned)wave_sum((float)zc);
@@ -399,32 +450,65 @@ __device__ __forceinline__ TnTile tn_locate(const aew_gemm_tn_t& g, int kt, int 
     return t;
 }
 
-template <int ESIZE>
-__device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, char* stage, int b, int r0, int r_end,
-                                         int n0, const TnTile& tt, int wave, int lane) {
-    // stage layout: G rows [0,TN_RC) then A rows [0,TN_RC), 256-byte rows (16 chunks)
-    const int lr = lane >> 4, pc = lane & 15;
+// Per-lane staging state of the TN kernels: 4 (bf16) / 2 (f32) pieces of 4 rows per operand and
+// wave.  Pointers advance by one stage (RC contraction rows) per step; validity is re-evaluated
+// per stage from the running row indices (cheap integer compares).
+template <int NP>
+struct TnPtrs {
+    const char* g[NP];
+    const char* a[NP];
+    int grow[NP], arow[NP], m[NP];
+    int64_t ginc, ainc;
+    int gstep, astep;
+};
+
+template <int NP, int ESIZE, int RC>
+__device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& tt, int b, int r_lo, int n0,
+                                         int wave, int lane, TnPtrs<NP>& P) {
     const aew_seg_t& sa = g.seg[tt.seg];
-    constexpr int EPC = 16 / ESIZE;                 // elements per chunk
+    const int lr = lane >> 4, pc = lane & 15;
+    constexpr int EPC = 16 / ESIZE;
+    P.gstep = RC * g.g.row_step; P.astep = RC * sa.row_step;
+    P.ginc = (int64_t)P.gstep * g.g.row_pitch * ESIZE;
+    P.ainc = (int64_t)P.astep * sa.row_pitch * ESIZE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 4 + lr;      // 16 pieces of 4 rows per operand
+    for (int j = 0; j < NP; ++j) {
+        const int r = (wave * NP + j) * 4 + lr;
         const int c = ESIZE == 2 ? tn_swz_bf16(r, pc) : tn_swz_f32(r, pc);
-        const int m = r0 + r;
-        const char* sg = (m < r_end) ? seg_row_ptr(g.g, b, m, ESIZE) : nullptr;
-        sg = sg ? sg + (n0 + c * EPC) * ESIZE : reinterpret_cast<const char*>(aew_zero_page);
-        glds16(sg, stage + (wave * 4 + j) * 1024);
-        const char* sp = (m < r_end) ? seg_row_ptr(sa, b, m, ESIZE) : nullptr;
-        sp = sp ? sp + (tt.kin + c * EPC) * ESIZE : reinterpret_cast<const char*>(aew_zero_page);
-        glds16(sp, stage + TN_RC * 256 + (wave * 4 + j) * 1024);
+        const int m = r_lo + r;
+        P.m[j] = m;
+        P.grow[j] = m * g.g.row_step + g.g.row_off;
+        P.arow[j] = m * sa.row_step + sa.row_off;
+        P.g[j] = reinterpret_cast<const char*>(g.g.ptr) +
+                 ((int64_t)b * g.g.batch_stride + (int64_t)P.grow[j] * g.g.row_pitch + n0 + c * EPC) * ESIZE;
+        P.a[j] = reinterpret_cast<const char*>(sa.ptr) +
+                 ((int64_t)b * sa.batch_stride + (int64_t)P.arow[j] * sa.row_pitch + tt.kin + c * EPC) * ESIZE;
     }
 }
 
-__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c0, int lane, int safe) {
+template <int NP, int RC>
+__device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, const TnTile& tt, char* stage, int r_end,
+                                         int wave, TnPtrs<NP>& P) {
+    const aew_seg_t& sa = g.seg[tt.seg];
+    const char* zp = reinterpret_cast<const char*>(aew_zero_page);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const bool in = P.m[j] < r_end;
+        const bool gok = in && P.grow[j] >= g.g.row_lo && P.grow[j] < g.g.row_hi;
+        const bool aok = in && P.arow[j] >= sa.row_lo && P.arow[j] < sa.row_hi;
+        glds16(gok ? P.g[j] : zp, stage + (wave * NP + j) * 1024);
+        glds16(aok ? P.a[j] : zp, stage + RC * 256 + (wave * NP + j) * 1024);
+        P.g[j] += P.ginc; P.a[j] += P.ainc;
+        P.grow[j] += P.gstep; P.arow[j] += P.astep; P.m[j] += RC;
+    }
+}
+
+template <int SAFE>
+__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c0, int lane) {
     // operand fragment for columns c0..c0+15, contraction rows r0..r0+31 of a [rows][128] bf16 tile
     const int q = lane & 15, gq = lane >> 4;
     s16x8_t out;
-    if (!safe) {
+    if (!SAFE) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = r0 + 8 * gq + 4 * h + (q >> 2);
@@ -436,7 +520,7 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
             out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
         }
     } else {
-        // scalar gather with the same result layout (fallback if the transpose read misbehaves)
+        // scalar gather with the same result layout (debug aid if the transpose read misbehaves)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int row = r0 + 8 * gq + e;
@@ -448,8 +532,9 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
     return __builtin_bit_cast(bf16x8_t, out);
 }
 
+template <int SAFE>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits, int rows_per_split,
-                                                         int fold_batch, int safe) {
+                                                         int fold_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 1, wn = wave >> 1;
@@ -467,13 +552,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, 
     const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
     const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
     const int total = nst * (b_hi - b_lo);
-    if (total > 0) tn_issue<2>(g, smem, b_lo, r_lo, r_hi, n0, tt, wave, lane);
+    TnPtrs<4> P;
+    int st_in_b = 0, bcur = b_lo;
+    if (total > 0) {
+        tn_setup<4, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+        tn_issue<4, TN_RC>(g, tt, smem, r_hi, wave, P);
+    }
     for (int t = 0; t < total; ++t) {
         wait_vm0();
         __syncthreads();
         if (t + 1 < total) {
-            const int bb = b_lo + (t + 1) / nst, st = (t + 1) % nst;
-            tn_issue<2>(g, smem + ((t + 1) & 1) * TN_STAGE_BYTES, bb, r_lo + st * TN_RC, r_hi, n0, tt, wave, lane);
+            if (++st_in_b == nst) {                    // wave-uniform: next batch element
+                st_in_b = 0; ++bcur;
+                tn_setup<4, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+            }
+            tn_issue<4, TN_RC>(g, tt, smem + ((t + 1) & 1) * TN_STAGE_BYTES, r_hi, wave, P);
         }
         const char* gs = smem + (t & 1) * TN_STAGE_BYTES;
         const char* as = gs + TN_RC * 256;
@@ -481,9 +574,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, 
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t af[4], gf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tn_frag_bf16(as, kk * 32, wk * 64 + i * 16, lane, safe);
+            for (int i = 0; i < 4; ++i) af[i] = tn_frag_bf16<SAFE>(as, kk * 32, wk * 64 + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16(gs, kk * 32, wn * 64 + j * 16, lane, safe);
+            for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16<SAFE>(gs, kk * 32, wn * 64 + j * 16, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -514,24 +607,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, 
 #define TF_RC 32
 #define TF_STAGE_BYTES (2 * TF_RC * 256)            // 16 KiB
 
-__device__ __forceinline__ void tnf_issue(const aew_gemm_tn_t& g, char* stage, int b, int r0, int r_end,
-                                          int n0, const TnTile& tt, int wave, int lane) {
-    const int lr = lane >> 4, pc = lane & 15;
-    const aew_seg_t& sa = g.seg[tt.seg];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave * 2 + j) * 4 + lr;      // 8 pieces of 4 rows per operand
-        const int c = tn_swz_f32(r, pc);
-        const int m = r0 + r;
-        const char* sg = (m < r_end) ? seg_row_ptr(g.g, b, m, 4) : nullptr;
-        sg = sg ? sg + (n0 + c * 4) * 4 : reinterpret_cast<const char*>(aew_zero_page);
-        glds16(sg, stage + (wave * 2 + j) * 1024);
-        const char* sp = (m < r_end) ? seg_row_ptr(sa, b, m, 4) : nullptr;
-        sp = sp ? sp + (tt.kin + c * 4) * 4 : reinterpret_cast<const char*>(aew_zero_page);
-        glds16(sp, stage + TF_RC * 256 + (wave * 2 + j) * 1024);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_gemm_tn_f32(const aew_gemm_tn_t g, int splits, int rows_per_split,
                                                      int fold_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -551,14 +626,22 @@ __global__ __launch_bounds__(256) void k_gemm_tn_f32(const aew_gemm_tn_t g, int 
     const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
     const int nst = (r_hi - r_lo + TF_RC - 1) / TF_RC;
     const int total = nst * (b_hi - b_lo);
-    if (total > 0) tnf_issue(g, smem, b_lo, r_lo, r_hi, n0, tt, wave, lane);
+    TnPtrs<2> P;
+    int st_in_b = 0, bcur = b_lo;
+    if (total > 0) {
+        tn_setup<2, 4, TF_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+        tn_issue<2, TF_RC>(g, tt, smem, r_hi, wave, P);
+    }
     const int q = lane & 15, kq = lane >> 4;
     for (int t = 0; t < total; ++t) {
         wait_vm0();
         __syncthreads();
         if (t + 1 < total) {
-            const int bb = b_lo + (t + 1) / nst, st = (t + 1) % nst;
-            tnf_issue(g, smem + ((t + 1) & 1) * TF_STAGE_BYTES, bb, r_lo + st * TF_RC, r_hi, n0, tt, wave, lane);
+            if (++st_in_b == nst) {
+                st_in_b = 0; ++bcur;
+                tn_setup<2, 4, TF_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+            }
+            tn_issue<2, TF_RC>(g, tt, smem + ((t + 1) & 1) * TF_STAGE_BYTES, r_hi, wave, P);
         }
         const char* gs = smem + (t & 1) * TF_STAGE_BYTES;
         const char* as = gs + TF_RC * 256;
@@ -660,7 +743,13 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_nt_check<float>, grid, dim3(64), 0, st, g);
     } else if (g.dtype == AEW_BF16) {
         dim3 grid((g.M + NT_BM - 1) / NT_BM, g.N_pad / NT_BN, g.batch);
-        hipLaunchKernelGGL(k_gemm_nt_bf16, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g);
+        switch (g.epi) {
+            case AEW_EPI_STORE: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_STORE>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
+            case AEW_EPI_GATED: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
+            case AEW_EPI_RES_SKIP: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
+            case AEW_EPI_DFG: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_DFG>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
+            default: return AEW_E_UNSUP;
+        }
     } else {
         dim3 grid((g.M + NF_BM - 1) / NF_BM, g.N_pad / NF_BN, g.batch);
         hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), 2 * NF_STAGE_BYTES, st, g);
@@ -716,7 +805,8 @@ static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_tn_check<float>, grid, dim3(64), 0, st, g, sp, rps, fold);
     } else if (g.dtype == AEW_BF16) {
         dim3 grid((g.N_pad / TN_BT) * (g.K_total / TN_BT), sp, fold ? 1 : g.batch);
-        hipLaunchKernelGGL(k_gemm_tn_bf16, grid, dim3(256), 2 * TN_STAGE_BYTES, st, g, sp, rps, fold, g_tn_safe);
+        if (g_tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(256), 2 * TN_STAGE_BYTES, st, g, sp, rps, fold);
+        else hipLaunchKernelGGL(k_gemm_tn_bf16<0>, grid, dim3(256), 2 * TN_STAGE_BYTES, st, g, sp, rps, fold);
     } else {
         dim3 grid((g.N_pad / TF_BT) * (g.K_total / TF_BT), sp, fold ? 1 : g.batch);
         hipLaunchKernelGGL(k_gemm_tn_f32, grid, dim3(256), 2 * TF_STAGE_BYTES, st, g, sp, rps, fold);

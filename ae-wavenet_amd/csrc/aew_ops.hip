@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
     const float* z = p.ze + (int64_t)q * p.d_pitch;
     float zz = 0.f;
     for (int j = 0; j < p.d; ++j) zz = __fmaf_rn(z[j], z[j], zz);
-    const float zn = __fsqrt_rn(zz);
+    const float zn = sqrtf(zz);          // sqrtf is IEEE-rounded; __fsqrt_rn lowers to a bare v_sqrt_f32
     float best = INFINITY;
     int bi = 0x7fffffff;
     for (int k = lane; k < p.K; k += 64) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
             qq = __fmaf_rn(cj, cj, qq);
         }
         float v;
-        if (p.metric == 0) v = __fdiv_rn(__fsqrt_rn(dd), __fadd_rn(zn, __fsqrt_rn(qq)));
+        if (p.metric == 0) v = __fdiv_rn(sqrtf(dd), __fadd_rn(zn, sqrtf(qq)));
         else v = dd;
         if (v < best) { best = v; bi = k; }          // ascending k within the lane: first min wins
     }
@@ -306,30 +306,39 @@ __global__ __launch_bounds__(256) void k_softmax_nll(const aew_softmax_nll_t p) 
 }
 
 // =============================================================================================
-// column sums (bias gradients).  grid: (ceil(N/64), batch, chunks); block 256 = 4 row-lanes x 64
-// columns; chunked over rows with atomics into a pre-zeroed (or accumulating) output.
+// column sums (bias gradients).  grid: (ceil(N/256), batch, row chunks); 4 waves stride the rows,
+// each lane owns 4 consecutive columns (8/16-byte loads); LDS combine, then one atomic per column.
 // =============================================================================================
-__global__ void k_colsum(const aew_colsum_t p, int rows_per_chunk) {
-    __shared__ float sh[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_per_chunk) {
+    __shared__ float sh[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4;
     const int b = blockIdx.y;
     const int r0 = blockIdx.z * rows_per_chunk, r1 = min(p.M, r0 + rows_per_chunk);
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (col < p.N)
-        for (int m = r0 + rl; m < r1; m += 4) {
+        for (int m = r0 + wv; m < r1; m += 4) {
             const int64_t row = (int64_t)m * p.x.row_step + p.x.row_off;
             if (row < p.x.row_lo || row >= p.x.row_hi) continue;
             const int64_t idx = (int64_t)b * p.x.batch_stride + row * p.x.row_pitch + col;
-            s += p.dtype == AEW_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.x.ptr)[idx])
-                                     : reinterpret_cast<const float*>(p.x.ptr)[idx];
+            float v[4];
+            if (p.dtype == AEW_BF16) unpack4_bf16(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.x.ptr) + idx), v);
+            else { const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x.ptr) + idx); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
-    sh[rl][threadIdx.x & 63] = s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[wv][lane * 4 + r] = s[r];
     __syncthreads();
-    if (rl == 0 && col < p.N) {
-        s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        atomicAdd(p.out + (int64_t)b * p.out_bs + col, s);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < p.N) {
+        const float t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        atomicAdd(p.out + (int64_t)b * p.out_bs + c, t);
     }
+}
+
+__global__ void k_zero(uint4* p, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
 }
 
 // =============================================================================================
@@ -504,11 +513,11 @@ static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
         }
     }
-    int chunks = (p.M + 511) / 512;
+    int chunks = (p.M + 255) / 256;
     if (chunks < 1) chunks = 1;
-    if (chunks > 256) chunks = 256;
+    if (chunks > 512) chunks = 512;
     const int rpc = (p.M + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv64(p.N, 64), p.batch, chunks), dim3(256), 0, st, p, rpc);
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv64(p.N, 256), p.batch, chunks), dim3(256), 0, st, p, rpc);
     return (int)hipGetLastError();
 }
 static int launch_reduce(const aew_reduce_t& p, hipStream_t st) {
@@ -519,6 +528,15 @@ static int launch_reduce(const aew_reduce_t& p, hipStream_t st) {
 static int launch_adam(const aew_adam_t& p, hipStream_t st) {
     if (((uintptr_t)p.p | (uintptr_t)p.g | (uintptr_t)p.m | (uintptr_t)p.v) & 15) return AEW_E_ALIGN;
     hipLaunchKernelGGL(k_adam, dim3(cdiv64((p.n + 3) / 4, 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_zero(const aew_zero_t& z, hipStream_t st) {
+    if (z.bytes <= 0) return 0;
+    if (((uintptr_t)z.ptr & 15) || (z.bytes & 15)) return (int)hipMemsetAsync(z.ptr, 0, (size_t)z.bytes, st);
+    const int64_t n16 = z.bytes / 16;
+    int blocks = (int)((n16 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(z.ptr), n16);
     return (int)hipGetLastError();
 }
 static int launch_vae(const aew_vae_t& p, hipStream_t st) {

@@ -41,9 +41,7 @@ static int dispatch(const aew_op_t& op, hipStream_t st) {
         case AEW_OP_COLSUM: return launch_colsum(op.u.cs, st);
         case AEW_OP_REDUCE: return launch_reduce(op.u.red, st);
         case AEW_OP_ADAM: return launch_adam(op.u.adam, st);
-        case AEW_OP_ZERO:
-            if (op.u.zero.bytes <= 0) return 0;
-            return (int)hipMemsetAsync(op.u.zero.ptr, 0, (size_t)op.u.zero.bytes, st);
+        case AEW_OP_ZERO: return launch_zero(op.u.zero, st);
         case AEW_OP_VAE: return launch_vae(op.u.vae, st);
         case AEW_OP_AE_NORM: return launch_ae_norm(op.u.aen, st);
         default: return AEW_E_UNSUP;
@@ -176,8 +174,11 @@ __global__ void k_selftest(int32_t* detail, float* scratch) {
         if (__any(bad) && lane == 0) detail[1] = 1;
         // order sensitivity: values with wide dynamic range, compare bitwise with fmaf chain
         f32x4_t d = {0.25f, 0.25f, 0.25f, 0.25f};
-        auto av = [](int i, int k) { return (1.0f + 0.37f * i) * (k % 3 == 0 ? 1.0e4f : (k % 3 == 1 ? 3.3e-3f : -7.1f)) + 0.001f * k; };
-        auto bv = [](int k, int j) { return (0.9f - 0.11f * j) * (k % 2 ? -1.7e2f : 2.9e-2f) + 0.003f * k; };
+        // exactly representable operands built without floating-point arithmetic: odd integers
+        // scaled by powers of two spread over 40 binades, so partial sums round differently
+        // under any other summation order
+        auto av = [](int i, int k) { return ldexpf((float)(((i * 37 + k * 11) % 97) * 2 + 1) * ((k & 1) ? -1.f : 1.f), ((k * 7) % 5) * 5 - 10); };
+        auto bv = [](int k, int j) { return ldexpf((float)(((j * 29 + k * 13) % 89) * 2 + 1), ((k * 3) % 4) * 5 - 10); };
         for (int ks = 0; ks < 8; ++ks) {
             const int k = 4 * ks + fg;
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(av(fi, k), bv(k, fi), d, 0, 0, 0);

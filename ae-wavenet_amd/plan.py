@@ -134,7 +134,7 @@ class Plan:
     def zero(self, ws: Workspace, name: str, label: Optional[str] = None):
         z = L.Zero()
         t = ws.get(name)
-        z.ptr, z.bytes = t.data_ptr(), t.numel() * t.element_size()
+        z.ptr, z.bytes = t.data_ptr(), (t.numel() * t.element_size()) // 16 * 16
         self.add(L.OP_ZERO, z, label or f"zero:{name}")
 
     def array(self):
