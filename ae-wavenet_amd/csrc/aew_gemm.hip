@@ -129,13 +129,20 @@ struct KIter {
 };
 
 // =============================================================================================
-// NT kernel, bf16:  block tile 128 (rows m) x 128 (channels n), BK = 64, 4 waves as 2(n) x 2(m)
+// NT kernel, bf16: block tile 256 (rows m) x 128 (channels n), BK = 64, 8 waves as 4(m) x 2(n),
+// each wave 64 x 64 (4x4 MFMA 16x16x32 tiles).  Operand tiles go global -> LDS by 16-byte LDS-DMA
+// into a 3-stage ring (3 x 48 KiB); tile t+2 is issued while tile t is computed, and the wait
+// before the per-step barrier is a COUNTED vmcnt that leaves tile t+1's loads in flight
+// (cdna_hip_programming.md T3+T4).  One raw s_barrier per K step.
 // =============================================================================================
-#define NT_BM 128
+#define NT_BM 256
 #define NT_BN 128
 #define NT_BK 64
 #define NT_ROWB 128                                 // bytes per staged row (64 bf16)
-#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 32 KiB
+#define NT_STAGES 3
+#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 48 KiB
+#define NT_LDS_BYTES (NT_STAGES * NT_STAGE_BYTES)   // 144 KiB
+#define NT_THREADS 512
 
 __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, int m, int esize) {
     const int64_t row = (int64_t)m * s.row_step + s.row_off;
@@ -143,12 +150,12 @@ __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, in
     return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
 }
 
-// Per-lane source pointers of the 4 X pieces + 4 W pieces a wave stages per K tile.  They are
-// computed once per segment (X) / once per kernel (W) and advanced by one K tile per step, so
-// the K loop carries no address arithmetic beyond 64-bit adds.
+// Per-lane source pointers of the 4 X pieces + 2 W pieces (8 rows x 128 B each) a wave stages per
+// K tile.  Computed once per segment (X) / once per kernel (W) and advanced by one K tile per
+// issue, so the K loop carries no address arithmetic beyond 64-bit adds.
 struct NtPtrs {
     const char* x[4];
-    const char* w[4];
+    const char* w[2];
     int xinc[4];
 };
 
@@ -158,7 +165,7 @@ __device__ __forceinline__ void nt_setup_x(const aew_gemm_nt_t& g, int seg, int 
     const int lr = lane >> 3, pc = lane & 7;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 8 + lr;
+        const int r = (wave * 4 + j) * 8 + lr;                       // 32 pieces of 8 rows
         const char* src = seg_row_ptr(s, b, m0 + r, 2);
         P.x[j] = src ? src + (nt_swz(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
         P.xinc[j] = src ? NT_BK * 2 : 0;
@@ -169,8 +176,8 @@ __device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int w
     const int lr = lane >> 3, pc = lane & 7;
     const char* wbase = reinterpret_cast<const char*>(g.W);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 8 + lr;
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 8 + lr;                       // 16 pieces of 8 rows
         P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 2 + (nt_swz(r, pc) << 4);
     }
 }
@@ -182,14 +189,18 @@ __device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs& P) 
         P.x[j] += P.xinc[j];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        glds16(P.w[j], stage + NT_BM * NT_ROWB + (wave * 4 + j) * 1024);
+    for (int j = 0; j < 2; ++j) {
+        glds16(P.w[j], stage + NT_BM * NT_ROWB + (wave * 2 + j) * 1024);
         P.w[j] += NT_BK * 2;
     }
 }
 
+struct NtIssue {                                    // walks K tiles across the segment table
+    int seg, kin, issued;
+};
+
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
@@ -207,10 +218,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     NtPtrs P;
-    int seg = 0, kin = 0;
+    NtIssue is = {0, 0, 0};
     nt_setup_w(g, n0, wave, lane, P);
     nt_setup_x(g, 0, b, m0, wave, lane, P);
-    nt_issue_bf16(smem, wave, P);
+    auto issue_next = [&]() {
+        if (is.issued > 0) {
+            is.kin += NT_BK;
+            if (is.kin >= g.seg[is.seg].k_len) {      // wave-uniform: next segment
+                ++is.seg; is.kin = 0;
+                nt_setup_x(g, is.seg, b, m0, wave, lane, P);
+            }
+        }
+        nt_issue_bf16(smem + (is.issued % NT_STAGES) * NT_STAGE_BYTES, wave, P);
+        ++is.issued;
+    };
+    issue_next();
+    if (nkt > 1) issue_next();
     const int fi = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (constant over the K loop)
     int woff[4][2], xoff[4][2];
@@ -223,18 +246,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) 
             xoff[i][kk] = rx * NT_ROWB + (nt_swz(rx, kk * 4 + fg) << 4);
         }
     }
+    int stage = 0;
     for (int t = 0; t < nkt; ++t) {
-        wait_vm0();
-        __syncthreads();
-        if (t + 1 < nkt) {
-            kin += NT_BK;
-            if (kin >= g.seg[seg].k_len) {             // wave-uniform: next segment
-                ++seg; kin = 0;
-                nt_setup_x(g, seg, b, m0, wave, lane, P);
-            }
-            nt_issue_bf16(smem + ((t + 1) & 1) * NT_STAGE_BYTES, wave, P);
-        }
-        const char* st = smem + (t & 1) * NT_STAGE_BYTES;
+        // tile t has landed once at most the 6 loads of tile t+1 are outstanding
+        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nkt) issue_next();                 // into the stage computed at step t-1
+        const char* st = smem + stage * NT_STAGE_BYTES;
+        stage = (stage + 1 == NT_STAGES) ? 0 : stage + 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t wf[4], xf[4];
@@ -532,53 +553,65 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
     return __builtin_bit_cast(bf16x8_t, out);
 }
 
+#define TN_STAGES 3
+#define TN_LDS_BYTES (TN_STAGES * TN_STAGE_BYTES)    // 96 KiB
+#define TN_THREADS 512
+
+// 8 waves as 4 (k) x 2 (n): each wave owns 32 (k cols of the A segment) x 64 (n cols of G) of the
+// 128 x 128 output tile.  3-stage LDS ring with counted vmcnt like the NT kernel.
 template <int SAFE>
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits, int rows_per_split,
-                                                         int fold_batch) {
+__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits,
+                                                                int rows_per_split, int fold_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave & 1, wn = wave >> 1;
+    const int wk = wave >> 1, wn = wave & 1;
     const int nkt = g.K_total / TN_BT;
     const int kt = blockIdx.x % nkt, nt = blockIdx.x / nkt;
     const int n0 = nt * TN_BT;
     const int sp = blockIdx.y;
     const TnTile tt = tn_locate(g, kt, TN_BT);
-    f32x4_t acc[4][4];
+    f32x4_t acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int b_lo = fold_batch ? 0 : blockIdx.z, b_hi = fold_batch ? g.batch : blockIdx.z + 1;
     const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
     const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
     const int total = nst * (b_hi - b_lo);
-    TnPtrs<4> P;
-    int st_in_b = 0, bcur = b_lo;
-    if (total > 0) {
-        tn_setup<4, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
-        tn_issue<4, TN_RC>(g, tt, smem, r_hi, wave, P);
-    }
-    for (int t = 0; t < total; ++t) {
-        wait_vm0();
-        __syncthreads();
-        if (t + 1 < total) {
-            if (++st_in_b == nst) {                    // wave-uniform: next batch element
-                st_in_b = 0; ++bcur;
-                tn_setup<4, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
-            }
-            tn_issue<4, TN_RC>(g, tt, smem + ((t + 1) & 1) * TN_STAGE_BYTES, r_hi, wave, P);
+    TnPtrs<2> P;
+    int st_in_b = 0, bcur = b_lo, issued = 0;
+    auto issue_next = [&]() {
+        if (issued == 0) {
+            tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+        } else if (++st_in_b == nst) {                 // wave-uniform: next batch element
+            st_in_b = 0; ++bcur;
+            tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
         }
-        const char* gs = smem + (t & 1) * TN_STAGE_BYTES;
+        tn_issue<2, TN_RC>(g, tt, smem + (issued % TN_STAGES) * TN_STAGE_BYTES, r_hi, wave, P);
+        ++issued;
+    };
+    if (total > 0) issue_next();
+    if (total > 1) issue_next();
+    int stage = 0;
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 loads per stage per wave
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < total) issue_next();
+        const char* gs = smem + stage * TN_STAGE_BYTES;
         const char* as = gs + TN_RC * 256;
+        stage = (stage + 1 == TN_STAGES) ? 0 : stage + 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[4], gf[4];
+            bf16x8_t af[2], gf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tn_frag_bf16<SAFE>(as, kk * 32, wk * 64 + i * 16, lane);
+            for (int i = 0; i < 2; ++i) af[i] = tn_frag_bf16<SAFE>(as, kk * 32, wk * 32 + i * 16, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16<SAFE>(gs, kk * 32, wn * 64 + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
@@ -591,8 +624,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, 
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = tt.koff + wk * 64 + i * 16 + 4 * gq;
+        for (int i = 0; i < 2; ++i) {
+            const int k = tt.koff + wk * 32 + i * 16 + 4 * gq;
             *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
@@ -714,6 +747,25 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 // =============================================================================================
 static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
 
+// kernels using more than 64 KiB of dynamic LDS must opt in once per process
+static int ensure_big_lds() {
+    static int done = 0;
+    if (done) return 0;
+    hipError_t e;
+#define AEW_SET_LDS(fn, bytes)                                                                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+    if (e != hipSuccess) return (int)e;
+    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_STORE>, NT_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_GATED>, NT_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, NT_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_DFG>, NT_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
+#undef AEW_SET_LDS
+    done = 1;
+    return 0;
+}
+
 static int check_seg(const aew_seg_t& s, int esize, int ktile) {
     if (!s.ptr) return AEW_E_ARG;
     if (s.k_len <= 0 || s.k_len % ktile) return AEW_E_ARG;
@@ -742,12 +794,14 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         if (g.dtype == AEW_BF16) hipLaunchKernelGGL(k_gemm_nt_check<uint16_t>, grid, dim3(64), 0, st, g);
         else hipLaunchKernelGGL(k_gemm_nt_check<float>, grid, dim3(64), 0, st, g);
     } else if (g.dtype == AEW_BF16) {
+        const int rc = ensure_big_lds();
+        if (rc) return rc;
         dim3 grid((g.M + NT_BM - 1) / NT_BM, g.N_pad / NT_BN, g.batch);
         switch (g.epi) {
-            case AEW_EPI_STORE: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_STORE>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
-            case AEW_EPI_GATED: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
-            case AEW_EPI_RES_SKIP: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
-            case AEW_EPI_DFG: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_DFG>, grid, dim3(256), 2 * NT_STAGE_BYTES, st, g); break;
+            case AEW_EPI_STORE: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_STORE>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
+            case AEW_EPI_GATED: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
+            case AEW_EPI_RES_SKIP: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
+            case AEW_EPI_DFG: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_DFG>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
             default: return AEW_E_UNSUP;
         }
     } else {
@@ -805,8 +859,10 @@ static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_tn_check<float>, grid, dim3(64), 0, st, g, sp, rps, fold);
     } else if (g.dtype == AEW_BF16) {
         dim3 grid((g.N_pad / TN_BT) * (g.K_total / TN_BT), sp, fold ? 1 : g.batch);
-        if (g_tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(256), 2 * TN_STAGE_BYTES, st, g, sp, rps, fold);
-        else hipLaunchKernelGGL(k_gemm_tn_bf16<0>, grid, dim3(256), 2 * TN_STAGE_BYTES, st, g, sp, rps, fold);
+        const int rc = ensure_big_lds();
+        if (rc) return rc;
+        if (g_tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
+        else hipLaunchKernelGGL(k_gemm_tn_bf16<0>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
     } else {
         dim3 grid((g.N_pad / TF_BT) * (g.K_total / TF_BT), sp, fold ? 1 : g.batch);
         hipLaunchKernelGGL(k_gemm_tn_f32, grid, dim3(256), 2 * TF_STAGE_BYTES, st, g, sp, rps, fold);
