@@ -204,7 +204,15 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
-    const int m0 = blockIdx.x * NT_BM, n0 = blockIdx.y * NT_BN, b = blockIdx.z;
+    // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (observed dispatch rule; used for
+    // speed only).  All N tiles of one (batch, row-tile) are consecutive on ONE XCD, so the
+    // activation tile is fetched from HBM into that XCD's L2 once and re-hit by the others.
+    const int n_mt = (g.M + NT_BM - 1) / NT_BM, n_nt = g.N_pad / NT_BN;
+    const int L = blockIdx.x, seq = L >> 3;
+    const int rt = (seq / n_nt) * 8 + (L & 7);
+    if (rt >= n_mt * g.batch) return;
+    const int b = rt / n_mt;
+    const int m0 = (rt - b * n_mt) * NT_BM, n0 = (seq % n_nt) * NT_BN;
     // RES_SKIP: skip-part tiles that lie entirely before the skip window do nothing
     if (EPI == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
         const int64_t last = (int64_t)(min(m0 + NT_BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
@@ -566,16 +574,24 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 1, wn = wave & 1;
     const int nkt = g.K_total / TN_BT;
-    const int kt = blockIdx.x % nkt, nt = blockIdx.x / nkt;
+    // XCD-aware order: the output tiles that contract over the same (batch, row chunk) are
+    // consecutive on ONE XCD, so the G / A rows of that chunk are fetched into its L2 once.
+    const int n_tiles = nkt * (g.N_pad / TN_BT);
+    const int n_chunks = splits * (fold_batch ? 1 : g.batch);
+    const int L = blockIdx.x, seq = L >> 3;
+    const int chunk = (seq / n_tiles) * 8 + (L & 7);
+    if (chunk >= n_chunks) return;
+    const int tile = seq % n_tiles;
+    const int kt = tile % nkt, nt = tile / nkt;
     const int n0 = nt * TN_BT;
-    const int sp = blockIdx.y;
+    const int sp = chunk % splits, bz = chunk / splits;
     const TnTile tt = tn_locate(g, kt, TN_BT);
     f32x4_t acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int b_lo = fold_batch ? 0 : blockIdx.z, b_hi = fold_batch ? g.batch : blockIdx.z + 1;
+    const int b_lo = fold_batch ? 0 : bz, b_hi = fold_batch ? g.batch : bz + 1;
     const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
     const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
     const int total = nst * (b_hi - b_lo);
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
         }
     }
-    const int slab = fold_batch ? sp : (blockIdx.z * splits + sp);
+    const int slab = fold_batch ? sp : (bz * splits + sp);
     float* out = g.out + (int64_t)slab * g.out_batch_stride;
     const int q = lane & 15, gq = lane >> 4;
 #pragma unroll
@@ -796,7 +812,8 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     } else if (g.dtype == AEW_BF16) {
         const int rc = ensure_big_lds();
         if (rc) return rc;
-        dim3 grid((g.M + NT_BM - 1) / NT_BM, g.N_pad / NT_BN, g.batch);
+        const int row_tiles = ((g.M + NT_BM - 1) / NT_BM) * g.batch;
+        dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / NT_BN));
         switch (g.epi) {
             case AEW_EPI_STORE: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_STORE>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
             case AEW_EPI_GATED: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
@@ -858,7 +875,8 @@ static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
         if (g.dtype == AEW_BF16) hipLaunchKernelGGL(k_gemm_tn_check<uint16_t>, grid, dim3(64), 0, st, g, sp, rps, fold);
         else hipLaunchKernelGGL(k_gemm_tn_check<float>, grid, dim3(64), 0, st, g, sp, rps, fold);
     } else if (g.dtype == AEW_BF16) {
-        dim3 grid((g.N_pad / TN_BT) * (g.K_total / TN_BT), sp, fold ? 1 : g.batch);
+        const int n_chunks = sp * (fold ? 1 : g.batch);
+        dim3 grid(((n_chunks + 7) / 8) * 8 * (g.N_pad / TN_BT) * (g.K_total / TN_BT));
         const int rc = ensure_big_lds();
         if (rc) return rc;
         if (g_tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
