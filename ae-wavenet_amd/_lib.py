@@ -112,7 +112,7 @@ class BaseGather(C.Structure):
     _fields_ = [("wav", vp), ("wav_pitch", i32), ("wav_off", i32), ("W", vp), ("bias", vp),
                 ("B", i32), ("T", i32), ("R", i32), ("R_pad", i32), ("Q", i32), ("x", vp),
                 ("x_bs", i64), ("x_pitch", i32), ("onehot", vp), ("oh_bs", i64),
-                ("oh_pitch", i32), ("Q_pad", i32)]
+                ("oh_pitch", i32), ("Q_pad", i32), ("ones_channel", i32)]
 
 
 class SoftmaxNll(C.Structure):
@@ -196,6 +196,10 @@ def load():
     lib.aew_timing_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.aew_selftest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.aew_tn_slabs.argtypes = [C.c_void_p]
+    lib.aew_tn_fold.argtypes = [C.c_void_p]
+    lib.aew_graph_capture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.aew_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+    lib.aew_graph_destroy.argtypes = [C.c_void_p]
     for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec)):
         want = lib.aew_sizeof(which)
         if want != C.sizeof(cls):
@@ -221,4 +225,5 @@ def tn_slabs(tn: GemmTN) -> int:
 
 
 EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
-           "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe")
+           "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe",
+           "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows")

@@ -66,11 +66,13 @@ __device__ __forceinline__ void view_store4(const aew_view_t& v, int b, int m, i
 }
 
 // ---- activation functions (fp32; outputs are rounded to bf16 by the caller) ----------------
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp): results are rounded to bf16 (8-bit mantissa) by the caller, so
+// the IEEE division sequence (~10 instructions) would buy nothing.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {
     // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
     const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 // ---- LDS tile geometry ----------------------------------------------------------------------

@@ -59,6 +59,14 @@ __device__ __forceinline__ void epi_gated4(const aew_gemm_nt_t& g, int b, int m,
     const float4 bf = *reinterpret_cast<const float4*>(bias + np_f);
     const float4 bg = *reinterpret_cast<const float4*>(bias + np_f + 16);
     float a[4], s[4], z[4], pf[4], pg[4];
+    if (g.reserved & 512) {                            // ablation: no transcendental math
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z[r] = f[r] + bf.x; pf[r] = gt[r] + bg.x; pg[r] = f[r] - gt[r]; }
+        view_store4(g.out0, b, m, ch, z);
+        view_store4(g.out1, b, m, ch, pf);
+        view_store4(g.out2, b, m, ch, pg);
+        return;
+    }
     a[0] = tanh_f(f[0] + bf.x); a[1] = tanh_f(f[1] + bf.y); a[2] = tanh_f(f[2] + bf.z); a[3] = tanh_f(f[3] + bf.w);
     s[0] = sigmoid_f(gt[0] + bg.x); s[1] = sigmoid_f(gt[1] + bg.y);
     s[2] = sigmoid_f(gt[2] + bg.z); s[3] = sigmoid_f(gt[3] + bg.w);
@@ -69,6 +77,10 @@ __device__ __forceinline__ void epi_gated4(const aew_gemm_nt_t& g, int b, int m,
         z[r] = a[r] * s[r];
         pf[r] = s[r] * (1.0f - a[r] * a[r]);
         pg[r] = z[r] * (1.0f - s[r]);
+    }
+    if (g.reserved & 256) {                            // ablation: math but no stores
+        asm volatile("" ::"v"(z[0] + pf[1] + pg[2] + z[3] + pf[0] + pg[1] + z[2] + pf[3] + pg[0] + z[1] + pf[2] + pg[3]));
+        return;
     }
     view_store4(g.out0, b, m, ch, z);
     view_store4(g.out1, b, m, ch, pf);
@@ -219,6 +231,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
         if (last < g.out1.row_lo) return;
     }
     const int nkt = g.K_total / NT_BK;
+    const int abl = g.reserved;                        // ablation switches (tools/ablate_gemm.py); 0 in production
+    if (abl & 32) return;                              // launch cost only
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -230,16 +244,17 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
     nt_setup_w(g, n0, wave, lane, P);
     nt_setup_x(g, 0, b, m0, wave, lane, P);
     auto issue_next = [&]() {
-        if (is.issued > 0) {
+        if (is.issued > 0 && !(abl & 128)) {
             is.kin += NT_BK;
             if (is.kin >= g.seg[is.seg].k_len) {      // wave-uniform: next segment
                 ++is.seg; is.kin = 0;
                 nt_setup_x(g, is.seg, b, m0, wave, lane, P);
             }
         }
-        nt_issue_bf16(smem + (is.issued % NT_STAGES) * NT_STAGE_BYTES, wave, P);
+        if (!(abl & 4)) nt_issue_bf16(smem + (is.issued % NT_STAGES) * NT_STAGE_BYTES, wave, P);
         ++is.issued;
     };
+    if (abl & 16) return;                              // launch + pointer setup
     issue_next();
     if (nkt > 1) issue_next();
     const int fi = lane & 15, fg = lane >> 4;
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
         // tile t has landed once at most the 6 loads of tile t+1 are outstanding
         if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(abl & 64)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 2 < nkt) issue_next();                 // into the stage computed at step t-1
         const char* st = smem + stage * NT_STAGE_BYTES;
@@ -267,16 +282,33 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t wf[4], xf[4];
+            if (!(abl & 2)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i][kk]);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i][kk]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j][kk]);
+                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j][kk]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) { wf[i] = __builtin_bit_cast(bf16x8_t, (s16x8_t){1, 2, 3, 4, 5, 6, 7, (short)t}); xf[i] = wf[i]; }
+            }
+            if (!(abl & 1)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]), "v"(xf[i]));
+            }
         }
+    }
+    if (abl & 8) {                                     // keep the accumulators live, skip the epilogue
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
     }
     // ---- epilogue: acc[i][j][r] = C[m = m0+wm*64+j*16+fi][n = n0+wn*64+i*16+4*fg+r]
     unsigned zc = 0;
@@ -828,10 +860,12 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+static int g_tn_fold_rows = 4096;                    // contractions up to this many rows fold the batch
+
 // split heuristic: aim for >= ~2 blocks per CU
 static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* rps, int* fold) {
     const int tiles = (g.N_pad / tile) * (g.K_total / tile);
-    int f = (g.Mc * g.batch <= 4096) ? 1 : 0;           // short contractions: fold the batch loop
+    int f = ((int64_t)g.Mc * g.batch <= g_tn_fold_rows) ? 1 : 0;   // short contractions: fold the batch loop
     int slabs_b = f ? 1 : g.batch;
     int want = (512 + tiles * slabs_b - 1) / (tiles * slabs_b);
     int max_sp = (g.Mc + 4 * rc - 1) / (4 * rc);        // keep >= 4 stages per block
@@ -852,6 +886,16 @@ extern "C" int aew_tn_slabs(const aew_gemm_tn_t* g) {
     tn_plan(*g, tile, rc, &sp, &rps, &fold);
     return fold ? sp : g->batch * sp;
 }
+
+extern "C" int aew_tn_fold(const aew_gemm_tn_t* g) {
+    int sp, rps, fold;
+    const int tile = g->dtype == AEW_BF16 ? TN_BT : TF_BT;
+    const int rc = g->dtype == AEW_BF16 ? TN_RC : TF_RC;
+    tn_plan(*g, tile, rc, &sp, &rps, &fold);
+    return fold;
+}
+
+extern "C" int aew_set_tn_fold_rows(int rows) { g_tn_fold_rows = rows; return 0; }
 
 static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.Mc <= 0 || g.batch <= 0 || !g.out) return AEW_E_ARG;

@@ -38,16 +38,20 @@ __global__ void k_copy_table(const aew_copy_table_t t) {
 // lowest index wins).   vqema_bn.py:135-142, vq_bn.py:39-41
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.Q) return;
+    // one block (4 waves) per query; wave w scans codes w*64+lane, +256, ...  The argmin with
+    // lowest-index tie-break is independent of the scan order, so the result equals the
+    // sequential oracle loop.
+    __shared__ float sh_d[4];
+    __shared__ int sh_i[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x;
     const float* z = p.ze + (int64_t)q * p.d_pitch;
     float zz = 0.f;
     for (int j = 0; j < p.d; ++j) zz = __fmaf_rn(z[j], z[j], zz);
     const float zn = sqrtf(zz);          // sqrtf is IEEE-rounded; __fsqrt_rn lowers to a bare v_sqrt_f32
     float best = INFINITY;
     int bi = 0x7fffffff;
-    for (int k = lane; k < p.K; k += 64) {
+    for (int k = threadIdx.x; k < p.K; k += 256) {
         const float* c = p.emb + (int64_t)k * p.d;
         float dd = 0.f, qq = 0.f;
         for (int j = 0; j < p.d; ++j) {
@@ -59,19 +63,24 @@ __global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
         float v;
         if (p.metric == 0) v = __fdiv_rn(sqrtf(dd), __fadd_rn(zn, sqrtf(qq)));
         else v = dd;
-        if (v < best) { best = v; bi = k; }          // ascending k within the lane: first min wins
+        if (v < best) { best = v; bi = k; }          // ascending k within the thread: first min wins
     }
-    // wave argmin with lowest-index tie-break
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
         if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
+    if (lane == 0) { sh_d[wv] = best; sh_i[wv] = bi; }
+    __syncthreads();
+    best = sh_d[0]; bi = sh_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (sh_d[w] < best || (sh_d[w] == best && sh_i[w] < bi)) { best = sh_d[w]; bi = sh_i[w]; }
     if (bi == 0x7fffffff) bi = 0;                    // all-NaN row: torch.min would return NaN; pick 0
-    if (lane == 0) { p.ind[q] = bi; p.dist[q] = best; }
+    if (threadIdx.x == 0) { p.ind[q] = bi; p.dist[q] = best; }
     float* zq = p.zq + (int64_t)q * p.d_pitch;
-    for (int j = lane; j < p.d_pitch; j += 64) zq[j] = j < p.d ? p.emb[(int64_t)bi * p.d + j] : 0.f;
+    for (int j = threadIdx.x; j < p.d_pitch; j += 256) zq[j] = j < p.d ? p.emb[(int64_t)bi * p.d + j] : 0.f;
 }
 
 // z_sum / n_sum: one thread per (code, channel), queries in ascending order (deterministic and
@@ -212,31 +221,34 @@ __global__ void k_spk_bias(const aew_spk_bias_t p) {
 }
 
 __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
-    // one block per layer; thread per output channel `co` for both filt and gate
-    const int l = blockIdx.x;
-    const int tid = threadIdx.x;
-    extern __shared__ float sh[];                    // [B][G] partial dgc for this layer
+    // grid (L, 2): one block per (layer, filt|gate); thread = output channel co
+    const int l = blockIdx.x, half = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    extern __shared__ float sh[];                    // [B][G] d(gc) of this (layer, half)
     for (int i = tid; i < p.B * p.G; i += blockDim.x) sh[i] = 0.f;
     __syncthreads();
-    for (int half = 0; half < 2; ++half)
-        for (int co = tid; co < p.D; co += blockDim.x) {
-            const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
-            const int64_t ob = half ? p.off_bias_gate[l] : p.off_bias_sig[l];
-            const int64_t ov = (half ? p.off_proj_gate[l] : p.off_proj_sig[l]) + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
-            float bsum = 0.f;
-            for (int b = 0; b < p.B; ++b) bsum += p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
-            if (ob >= 0) p.grads[ob + co] = bsum;
-            for (int j = 0; j < p.G; ++j) {
-                float gv = 0.f;
-                const float vj = p.params[ov + j];
-                for (int b = 0; b < p.B; ++b) {
-                    const float cs = p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
-                    gv += cs * p.gc[b * p.G + j];
-                    atomicAdd(&sh[b * p.G + j], cs * vj);
-                }
-                p.grads[ov + j] = gv;
+    const int64_t ob = half ? p.off_bias_gate[l] : p.off_bias_sig[l];
+    const int64_t ov0 = half ? p.off_proj_gate[l] : p.off_proj_sig[l];
+    for (int co0 = 0; co0 < p.D; co0 += blockDim.x) {
+        const int co = co0 + tid;
+        const bool ok = co < p.D;
+        const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
+        const int64_t ov = ov0 + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
+        float bsum = 0.f;
+        for (int b = 0; b < p.B; ++b) bsum += ok ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+        if (ok && ob >= 0) p.grads[ob + co] = bsum;
+        for (int j = 0; j < p.G; ++j) {
+            const float vj = ok ? p.params[ov + j] : 0.f;
+            float gv = 0.f;
+            for (int b = 0; b < p.B; ++b) {
+                const float cs = ok ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+                gv += cs * p.gc[b * p.G + j];
+                const float part = wave_sum(cs * vj);
+                if (lane == 0) atomicAdd(&sh[b * p.G + j], part);
             }
+            if (ok) p.grads[ov + j] = gv;
         }
+    }
     __syncthreads();
     // speaker embedding grads accumulate over layers -> global atomics (caller zeroes them)
     for (int i = tid; i < p.B * p.G; i += blockDim.x) {
@@ -259,7 +271,8 @@ __global__ void k_base_gather(const aew_base_gather_t p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = c4 + r;
-            v[r] = c < p.R ? p.W[(int64_t)c * p.Q + q] + (p.bias ? p.bias[c] : 0.f) : 0.f;
+            v[r] = c < p.R ? p.W[(int64_t)c * p.Q + q] + (p.bias ? p.bias[c] : 0.f)
+                           : ((p.ones_channel && c == p.R) ? 1.0f : 0.f);
         }
         *reinterpret_cast<uint2*>(p.x + (int64_t)b * p.x_bs + (int64_t)t * p.x_pitch + c4) = pack4_bf16(v);
     }
@@ -465,7 +478,7 @@ static int launch_copy(const aew_copy_table_t& t, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_vq_nearest(const aew_vq_nearest_t& p, hipStream_t st) {
-    hipLaunchKernelGGL(k_vq_nearest, dim3(cdiv64(p.Q, 4)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_vq_nearest, dim3(p.Q), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 static int launch_vq_stats(const aew_vq_stats_t& p, hipStream_t st) {
@@ -494,7 +507,7 @@ static int launch_spk_bias(const aew_spk_bias_t& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
-    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L), dim3(256), p.B * p.G * sizeof(float), st, p);
+    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2), dim3(256), p.B * p.G * sizeof(float), st, p);
     return (int)hipGetLastError();
 }
 static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {
@@ -508,7 +521,10 @@ static int launch_softmax(const aew_softmax_nll_t& p, hipStream_t st) {
 }
 static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
     if (!p.accumulate) {
-        for (int b = 0; b < p.batch; ++b) {
+        // contiguous or shared outputs are cleared with one memset; strided per-batch outputs one
+        // per batch (callers on the hot path pre-zero the buffer and pass accumulate = 1)
+        const int nset = p.out_bs == 0 ? 1 : p.batch;
+        for (int b = 0; b < nset; ++b) {
             hipError_t e = hipMemsetAsync(p.out + (int64_t)b * p.out_bs, 0, (size_t)p.N * sizeof(float), st);
             if (e != hipSuccess) return (int)e;
         }

@@ -88,6 +88,49 @@ extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// hipGraph capture of a plan: the ops are recorded once on a private capture stream and
+// replayed with one hipGraphLaunch per step (removes the per-kernel host launch gaps).
+// ---------------------------------------------------------------------------------------------
+static hipStream_t g_cap_stream = nullptr;
+
+extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, int* fail_index) {
+    if (!ops || n <= 0 || !exec_out) return AEW_E_ARG;
+    int rc = ensure_big_lds();                       // attribute calls are not capturable
+    if (rc) return rc;
+    hipError_t e;
+    if (!g_cap_stream) {
+        e = hipStreamCreateWithFlags(&g_cap_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return (int)e;
+    }
+    e = hipStreamBeginCapture(g_cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < n && rc == 0; ++i) {
+        rc = dispatch(ops[i], g_cap_stream);
+        if (rc != 0 && fail_index) *fail_index = i;
+    }
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(g_cap_stream, &graph);
+    if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *exec_out = (void*)exec;
+    return 0;
+}
+
+extern "C" int aew_graph_launch(void* exec, void* stream) {
+    if (!exec) return AEW_E_ARG;
+    return (int)hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream);
+}
+
+extern "C" int aew_graph_destroy(void* exec) {
+    if (!exec) return 0;
+    return (int)hipGraphExecDestroy((hipGraphExec_t)exec);
+}
+
 extern "C" int aew_timing_enable(int on) {
     g_timing = on ? 1 : 0;
     g_ev_used = 0;

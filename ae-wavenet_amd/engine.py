@@ -388,6 +388,7 @@ class DecoderPlan:
         bg.x, bg.x_bs, bg.x_pitch = self.x[0].ptr, self.x[0].bs, self.x[0].pitch
         if need_onehot:
             bg.onehot, bg.oh_bs, bg.oh_pitch, bg.Q_pad = self.onehot.ptr, self.onehot.bs, self.onehot.pitch, Qp
+        bg.ones_channel = int(self.R < Rp)
         plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
         # 6. gated dilated stack (wavenet.py:91-111, 355-357)
         NL = self.NL
@@ -446,7 +447,7 @@ class DecoderPlan:
         cs = L.Colsum()
         cs.x = X.seg(128, row_off=row_off)
         cs.dtype, cs.M, cs.N, cs.batch = X.dtype, M, N, self.B
-        cs.out, cs.out_bs, cs.accumulate = out_ptr, out_bs, 0
+        cs.out, cs.out_bs, cs.accumulate = out_ptr, out_bs, 1      # target pre-zeroed by the plan
         plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
 
     def _wgrad(self, plan: Plan, name: str, dtype: int, Mc: int, N: int, N_pad: int, gseg: L.Seg,
@@ -468,6 +469,7 @@ class DecoderPlan:
         impl, NL, w, T = self.impl, self.NL, self.w, self.T
         pk = self.pk
         plan.add(L.OP_SOFTMAX_NLL, self._softmax(True, nll_scale), "softmax_grad", TAG_LOSS)
+        plan.zero(self.ws, p + "colsum_fg")
         # ---- post network
         if ps.has(p + "post2.bias"):
             self._colsum(plan, self.dlogits, w, Q, ps.ptr(p + "post2.bias", True), label="db.post2")
@@ -488,6 +490,7 @@ class DecoderPlan:
         Cc = Clc + self.Gc
         dx_next: Optional[Mat] = None
         bufs = [self.dxa, self.dxb]
+        colsum_tbl = CopyTableBuilder(self.ws, p + "tbl.colsum")
         for l in range(NL - 1, -1, -1):
             lg = g.layers[l]
             last = l == NL - 1
@@ -507,12 +510,19 @@ class DecoderPlan:
             gp, gs, gn = self._wgrad(plan, f"skp{l}", BF, w, S, Sp, self.dskp.seg(Sp),
                                      [self.z[l].seg(Dp, row_off=lg.skip_lead)], TAG_WG_RS)
             pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
-            self._colsum(plan, self.dfg[l], P_l, 2 * Dp, self.colsum_fg.data_ptr() + 4 * l * 2 * Dp,
-                         out_bs=NL * 2 * Dp, label=f"colsum.dfg{l}")
             x = self.x[l]
             gp, gs, gn = self._wgrad(plan, f"fg{l}", BF, P_l, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp),
                                      [x.seg(Rp), x.seg(Rp, row_off=d), self.cond.seg(Cp, row_off=lg.cond_lead)],
                                      TAG_WG_FG)
+            spb = gn // B if (gn % B == 0 and gn >= B) else 0     # slabs per batch (0: batch folded)
+            if self.R < Rp and spb > 0:
+                # x carries a constant 1.0 in pad channel R (base_gather ones_channel), so column R
+                # of this wgrad is sum_t dfg[t][n]: gather it per batch for the bias / speaker grads
+                colsum_tbl.add(gp + 4 * R, self.colsum_fg.data_ptr() + 4 * l * 2 * Dp, [B, 2 * Dp],
+                               [spb * gs, Kfg], [NL * 2 * Dp, 1], F3, F3, red_n=spb, red_stride=gs)
+            else:
+                self._colsum(plan, self.dfg[l], P_l, 2 * Dp, self.colsum_fg.data_ptr() + 4 * l * 2 * Dp,
+                             out_bs=NL * 2 * Dp, label=f"colsum.dfg{l}")
             for gate, nm in ((0, "signal"), (1, "gate")):
                 for co0, ng, gl in _gate_groups(D):
                     row0 = (co0 // 16) * 32 + 16 * gate
@@ -539,6 +549,7 @@ class DecoderPlan:
         plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT.ptr, out0=self.dcond.view(),
                                        impl=impl), "dcond", TAG_DCOND)
         # ---- speaker / gated-bias gradients
+        colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)")
         sbw = L.SpkBwd()
         self._fill_spk(sbw)
         sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
@@ -653,7 +664,7 @@ class EncoderPlan:
             cs = L.Colsum()
             cs.x = dpre.seg(64)
             cs.dtype, cs.M, cs.N, cs.batch = F3, Lo, E, B
-            cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 0
+            cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 1
             plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
             t = make_tn(F3, Lo, B, E, Ep, dpre.seg(64), [X.seg(cinp, row_step=s, row_off=k) for k in range(f)],
                         impl=impl)

@@ -34,8 +34,9 @@ class TrainEngine:
 
     def __init__(self, hps, B: int, device, n_mel: Optional[int] = None, loss_mode: str = "intended",
                  take_compat: bool = False, update_codebook_every_step: bool = True, impl: int = 0,
-                 n_win: Optional[int] = None):
+                 n_win: Optional[int] = None, use_graphs: bool = True):
         self.hps, self.B, self.impl = hps, B, impl
+        self.use_graphs = use_graphs
         self.kind = hps.global_model
         self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
         self.loss_mode, self.take_compat = loss_mode, take_compat
@@ -236,7 +237,7 @@ class TrainEngine:
                 cs = L.Colsum()
                 cs.x = self.dlin.seg(64)
                 cs.dtype, cs.M, cs.N, cs.batch = F3, g.embed_len, self.d, B
-                cs.out, cs.out_bs, cs.accumulate = ps.ptr("bottleneck.linear.bias", True), 0, 0
+                cs.out, cs.out_bs, cs.accumulate = ps.ptr("bottleneck.linear.bias", True), 0, 1
                 bw.add(L.OP_COLSUM, cs, "db.bn", TAG_VQ)
             # linear wgrad / dgrad
             t = make_tn(F3, g.embed_len, B, self.nlin, self.nlin_p, self.dlin.seg(64), [y9.seg(Ep)], impl=impl)
@@ -330,19 +331,27 @@ class TrainEngine:
         arr = self.fwd_b.array()
         arr[self._red_index].u.red.post_scale[1] = float(a)
         self.bwd.array()[self._vae_bwd_index].u.vae.kl_coef = float(a)
+        self.fwd_b.invalidate_graph()
+        self.bwd.invalidate_graph()
 
-    def forward(self, ema_allreduce=None):
-        s = self._stream()
-        self.fwd_a.run(s)
+    def _run(self, plan, timing=False):
+        if self.use_graphs and not timing:
+            plan.run_graph(self._stream())
+        else:
+            plan.run(self._stream())
+
+    def forward(self, ema_allreduce=None, timing=False):
+        """timing=True forces eager launches (the per-op event timing needs them)."""
+        self._run(self.fwd_a, timing)
         if ema_allreduce is not None and self.bn_type == "vqvae-ema":
             ema_allreduce(self.z_sum, self.n_sum)
-        self.fwd_b.run(s)
+        self._run(self.fwd_b, timing)
         return self.loss_buf[0]
 
-    def backward(self):
-        self.bwd.run(self._stream())
+    def backward(self, timing=False):
+        self._run(self.bwd, timing)
         if self.bn_type == "vqvae-ema" and self.update_codebook_every_step:
-            self.cb.run(self._stream())
+            self._run(self.cb, timing)
 
     def update_codebook(self):
         self.cb.run(self._stream())

@@ -114,6 +114,7 @@ class Plan:
         self.ops: List[L.Op] = []
         self.labels: List[str] = []
         self._arr = None
+        self._graph = None            # hipGraphExec handle (lazy)
         self.keep: list = []          # device tables etc. that must outlive the plan
 
     def add(self, kind: int, payload, label: str, tag: int = 0) -> L.Op:
@@ -141,6 +142,27 @@ class Plan:
         if self._arr is None:
             self._arr = (L.Op * len(self.ops))(*self.ops)
         return self._arr
+
+    def invalidate_graph(self):
+        """Call after mutating an op inside array(): the captured graph froze the old values."""
+        if self._graph is not None:
+            L.load().aew_graph_destroy(self._graph)
+            self._graph = None
+
+    def run_graph(self, stream: int = 0):
+        """Replay the plan as a hipGraph (captured on first use)."""
+        if not self.ops:
+            return
+        lib = L.load()
+        if self._graph is None:
+            h = C.c_void_p()
+            fail = C.c_int(-1)
+            rc = lib.aew_graph_capture(C.cast(self.array(), C.c_void_p), len(self.ops), C.byref(h), C.byref(fail))
+            if rc != 0:
+                lab = self.labels[fail.value] if 0 <= fail.value < len(self.labels) else "?"
+                L.check(rc, f"graph capture of plan '{self.name}' (op '{lab}')", fail.value)
+            self._graph = h
+        L.check(lib.aew_graph_launch(self._graph, C.c_void_p(stream)), f"graph launch '{self.name}'")
 
     def run(self, stream: int = 0):
         if not self.ops:

@@ -161,8 +161,8 @@ def main():
         lib.aew_timing_enable(1)
         n_t = 3
         for _ in range(n_t):
-            eng.forward(None)
-            eng.backward()
+            eng.forward(None, timing=True)
+            eng.backward(timing=True)
             eng.adam_step(args.lr, gscale)
         cap = 1 << 16
         ms = (C.c_float * cap)()

@@ -244,6 +244,10 @@ typedef struct {                 /* base layer as a column gather (wavenet.py:34
     uint16_t* x; int64_t x_bs; int32_t x_pitch;             /* bf16 [B][T][R_pad]             */
     uint16_t* onehot; int64_t oh_bs; int32_t oh_pitch;      /* optional bf16 [B][T][Q_pad]    */
     int32_t Q_pad;
+    int32_t ones_channel;        /* 1: write 1.0 into pad channel R (requires R < R_pad).  The padded
+                                    weight rows/cols are zero, so the constant propagates through the
+                                    residual adds untouched and column R of every gated-layer wgrad
+                                    GEMM equals the column sums of dfg (= the gated bias gradients)   */
 } aew_base_gather_t;
 
 typedef struct {                 /* fused log-softmax + NLL (+ gradient)  wavenet.py:543-547  */
@@ -332,6 +336,12 @@ int aew_sizeof(int which);      /* 0 op, 1 gemm_nt, 2 gemm_tn, 3 seg, 4 view, 5 
  * writes the failing index to *fail_index if non-NULL. */
 int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index);
 
+/* hipGraph form of a plan: capture once (on a private stream; pointers and scalars inside the
+ * ops are frozen), replay with one launch per step on any stream.  `exec` is an opaque handle. */
+int aew_graph_capture(const aew_op_t* ops, int n, void** exec, int* fail_index);
+int aew_graph_launch(void* exec, void* stream);
+int aew_graph_destroy(void* exec);
+
 /* Per-op timing: while enabled, aew_run_plan brackets every op with HIP events on `stream`;
  * aew_timing_read synchronises the stream and returns elapsed ms per executed op (in
  * execution order since the last enable) and its tag. */
@@ -340,6 +350,10 @@ int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
 
 /* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */
 int aew_tn_slabs(const aew_gemm_tn_t* g);
+/* 1 if the op's batch loop is folded into one slab per split (short contractions). */
+int aew_tn_fold(const aew_gemm_tn_t* g);
+/* Contraction length (rows x batch) up to which TN ops fold the batch; default 4096. */
+int aew_set_tn_fold_rows(int rows);
 /* 1: read TN fragments with a scalar LDS gather instead of ds_read_b64_tr_b16 (debug aid). */
 int aew_set_tn_safe(int on);
 

@@ -143,7 +143,7 @@ class Emu:
         # the split/fold heuristic only changes how partial sums are distributed over slabs;
         # the emulator writes the per-batch sum into slab b (or everything into slab 0 when the
         # library folds the batch) and zero elsewhere
-        fold = slabs < t.batch or (t.Mc * t.batch <= 4096)
+        fold = bool(L.load().aew_tn_fold(C.byref(t)))
         region = out[ooff: ooff + slabs * t.out_batch_stride]
         region.zero_()
         for b in range(t.batch):
@@ -326,6 +326,8 @@ class Emu:
         x[:, :, :p.R] = W.t()[q]
         if p.bias:
             x[:, :, :p.R] += self.rd(p.bias, torch.arange(p.R))[None, None, :]
+        if p.ones_channel:
+            x[:, :, p.R] = 1.0
         idx = (torch.arange(p.B)[:, None, None] * p.x_bs + torch.arange(p.T)[None, :, None] * p.x_pitch
                + torch.arange(p.R_pad)[None, None, :])
         self.wr(p.x, idx, x)

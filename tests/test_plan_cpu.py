@@ -137,6 +137,29 @@ def test_autoencoder_vqema_plan(golden_dir, mode, jk, loss_mode, gtag, ltag):
     np.testing.assert_allclose(cnt / numel, z["enc_frac_zero"], atol=1e-9)
 
 
+def test_unfolded_wgrad_and_ones_channel_colsum(golden_dir, monkeypatch):
+    """Force the per-batch (non-folded) wgrad layout on the toy nets: exercises multi-slab gradient
+    unpacking and the bias gradients taken from the constant-one pad channel of x."""
+    monkeypatch.setitem(PL.TORCH_DT, L.BF16, torch.float32)
+    monkeypatch.setitem(PL.ESIZE, L.BF16, 4)
+    lib = L.load()
+    lib.aew_set_tn_fold_rows(0)
+    try:
+        z = load(golden_dir, "mi_tiny_jitter.npz")
+        hps, eng = make_engine(z, "mfcc_inverter", 7)
+        assert any(lab.startswith("colsum.dfg (from wgrad") for lab in eng.bwd.labels)
+        run(eng, z)
+        check_grads(eng, z, "grad", "wide")
+        z = load(golden_dir, "ae_tiny_vqvae-ema_random.npz")
+        hps, eng = make_engine(z, "autoencoder", None)
+        eng.emb.copy_(torch.from_numpy(z["emb0"]))
+        eng.init_ema_from_emb()
+        run(eng, z)
+        check_grads(eng, z, "gint", "wide")
+    finally:
+        lib.aew_set_tn_fold_rows(4096)
+
+
 def test_autoencoder_vae_plan(golden_dir, mode):
     z = load(golden_dir, "ae_tiny_vae_random.npz")
     hps, eng = make_engine(z, "autoencoder", None)
