@@ -38,30 +38,68 @@ __device__ __forceinline__ void unpack4_bf16(uint2 r, float v[4]) {
     v[3] = __uint_as_float(r.y & 0xffff0000u);
 }
 
-// ---- view access on quads of 4 consecutive channels ---------------------------------------
+// ---- view access: W (4 or 8) consecutive channels of one row ---------------------------------
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    // v_cvt_pk_bf16_f32 (round-to-nearest-even, same as torch .to(bfloat16))
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+}
+
 __device__ __forceinline__ bool view_row(const aew_view_t& v, int m, int64_t& row) {
     row = (int64_t)m * v.row_step + v.row_off;
     return row >= v.row_lo && row < v.row_hi;
 }
-__device__ __forceinline__ void view_load4(const aew_view_t& v, int b, int m, int n, float out[4]) {
+
+// byte pointer to channel 0 of the view row that GEMM row m maps to; nullptr if the row does not
+// exist (loads then read zero, stores are dropped)
+__device__ __forceinline__ char* view_rowptr(const aew_view_t& v, int b, int m) {
     int64_t row;
-    if (!view_row(v, m, row)) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
-    const int64_t idx = (int64_t)b * v.batch_stride + row * v.row_pitch + n;
-    if (v.dtype == AEW_BF16) {
-        unpack4_bf16(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(v.ptr) + idx), out);
+    if (!v.ptr || !view_row(v, m, row)) return nullptr;
+    return reinterpret_cast<char*>(v.ptr) +
+           ((int64_t)b * v.batch_stride + row * v.row_pitch) * (v.dtype == AEW_BF16 ? 2 : 4);
+}
+
+template <int W>
+__device__ __forceinline__ void row_load(const char* rp, int dtype, int n, float out[W]) {
+    if (!rp) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) out[r] = 0.f;
+        return;
+    }
+    if (dtype == AEW_BF16) {
+        uint32_t w[W / 2];
+        if (W == 8) { const uint4 t = *reinterpret_cast<const uint4*>(rp + n * 2); w[0] = t.x; w[1] = t.y; w[W / 2 - 2] = t.z; w[W / 2 - 1] = t.w; }
+        else { const uint2 t = *reinterpret_cast<const uint2*>(rp + n * 2); w[0] = t.x; w[1] = t.y; }
+#pragma unroll
+        for (int r = 0; r < W / 2; ++r) {
+            out[2 * r] = __uint_as_float(w[r] << 16);
+            out[2 * r + 1] = __uint_as_float(w[r] & 0xffff0000u);
+        }
     } else {
-        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(v.ptr) + idx);
-        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(rp + (n + 4 * q) * 4);
+            out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+        }
     }
 }
-__device__ __forceinline__ void view_store4(const aew_view_t& v, int b, int m, int n, const float val[4]) {
-    int64_t row;
-    if (!view_row(v, m, row)) return;
-    const int64_t idx = (int64_t)b * v.batch_stride + row * v.row_pitch + n;
-    if (v.dtype == AEW_BF16) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(v.ptr) + idx) = pack4_bf16(val);
+
+template <int W>
+__device__ __forceinline__ void row_store(char* rp, int dtype, int n, const float v[W]) {
+    if (!rp) return;
+    if (dtype == AEW_BF16) {
+        if (W == 8) {
+            *reinterpret_cast<uint4*>(rp + n * 2) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
+                                                               pack2_bf16(v[W - 4], v[W - 3]), pack2_bf16(v[W - 2], v[W - 1]));
+        } else {
+            *reinterpret_cast<uint2*>(rp + n * 2) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+        }
     } else {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(v.ptr) + idx) = make_float4(val[0], val[1], val[2], val[3]);
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q)
+            *reinterpret_cast<float4*>(rp + (n + 4 * q) * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 }
 
@@ -81,9 +119,12 @@ __device__ __forceinline__ float tanh_f(float x) {
 // wave-uniform LDS address, so bank-conflict swizzles are applied on the per-lane SOURCE
 // address and mirrored on the fragment read (cdna_hip_programming.md §5.4 rule 21).
 
-// NT tiles: 128-byte rows (8 chunks).  chunk' = chunk ^ (row & 7): the 16 rows x 1 chunk of a
-// ds_read_b128 MFMA fragment then land on 16 distinct 16-byte slots of the 256-byte bank row.
+// NT tiles, fp32 kernel: 128-byte rows (8 chunks).  chunk' = chunk ^ (row & 7).
 __device__ __forceinline__ int nt_swz(int row, int chunk) { return chunk ^ (row & 7); }
+// NT tiles, bf16 kernel: 64-byte rows (4 chunks = 32 bf16 = one MFMA K step).  A 256-byte bank
+// row holds 4 LDS rows; chunk' = chunk ^ ((row >> 2) & 3) puts the 16 rows x 1 chunk of a
+// ds_read_b128 fragment on 16 distinct 16-byte slots (conflict-free).
+__device__ __forceinline__ int nt_swz64(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
 // TN tiles: 256-byte rows (16 chunks); fragments are read with ds_read_b64_tr_b16 (bf16) whose
 // 16-lane group touches 4 rows x 32 B.  XOR the 32-byte group index with

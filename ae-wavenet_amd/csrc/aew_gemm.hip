@@ -14,118 +14,139 @@
 #include "aew_common.h"
 
 // =============================================================================================
-// epilogues (operate on 4 consecutive channels n..n+3 of row m; shared by MFMA and check kernels)
+// epilogues: W consecutive channels n..n+W-1 of one output row (W = 8 in the bf16 MFMA kernel,
+// 4 in the fp32 and check kernels).  Row pointers of the views are resolved once per row.
 // =============================================================================================
-__device__ __forceinline__ void epi_store4(const aew_gemm_nt_t& g, int b, int m, int n, float v[4],
-                                           unsigned& zero_count) {
+struct EpiRow {                                      // per output row m: view row pointers
+    char* o0; char* o1; char* o2;
+    const char* a0; const char* a1;
+};
+
+__device__ __forceinline__ EpiRow epi_row(const aew_gemm_nt_t& g, int b, int m) {
+    EpiRow R;
+    R.o0 = view_rowptr(g.out0, b, m); R.o1 = view_rowptr(g.out1, b, m); R.o2 = view_rowptr(g.out2, b, m);
+    R.a0 = view_rowptr(g.aux0, b, m); R.a1 = view_rowptr(g.aux1, b, m);
+    return R;
+}
+
+template <int W>
+__device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiRow& R, int b, int n, float v[W],
+                                          unsigned& zero_count) {
     const unsigned fl = g.flags;
     if (fl & AEW_EF_BIAS) {
-        const float4 bb = *reinterpret_cast<const float4*>(g.bias + (int64_t)b * g.bias_bs + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        const float* bp = g.bias + (int64_t)b * g.bias_bs + n;
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(bp + 4 * q);
+            v[4 * q] += bb.x; v[4 * q + 1] += bb.y; v[4 * q + 2] += bb.z; v[4 * q + 3] += bb.w;
+        }
     }
     if (fl & AEW_EF_RELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        for (int r = 0; r < W; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
     }
-    if (fl & AEW_EF_OUT1_PRE) view_store4(g.out1, b, m, n, v);
+    if (fl & AEW_EF_OUT1_PRE) row_store<W>(R.o1, g.out1.dtype, n, v);
     if (fl & AEW_EF_ADD_AUX0) {
-        float a[4];
-        view_load4(g.aux0, b, m, n, a);
+        float a[W];
+        row_load<W>(R.a0, g.aux0.dtype, n, a);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] + a[r];
+        for (int r = 0; r < W; ++r) v[r] = v[r] + a[r];
     }
     if (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)) {
-        float a[4], w[4];
-        view_load4(g.aux1, b, m, n, a);
+        float a[W], w[W];
+        row_load<W>(R.a1, g.aux1.dtype, n, a);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = a[r] > 0.f ? v[r] : 0.f;
-        if (fl & AEW_EF_OUT1_POS1) view_store4(g.out1, b, m, n, w);
+        for (int r = 0; r < W; ++r) w[r] = a[r] > 0.f ? v[r] : 0.f;
+        if (fl & AEW_EF_OUT1_POS1) row_store<W>(R.o1, g.out1.dtype, n, w);
         if (fl & AEW_EF_MUL_POS1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = w[r];
+            for (int r = 0; r < W; ++r) v[r] = w[r];
         }
     }
-    if (fl & AEW_EF_COUNT_ZERO) {
+    if ((fl & AEW_EF_COUNT_ZERO) && R.o0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zero_count += (n + r < g.N && v[r] == 0.f) ? 1u : 0u;
+        for (int r = 0; r < W; ++r) zero_count += (n + r < g.N && v[r] == 0.f) ? 1u : 0u;
     }
-    view_store4(g.out0, b, m, n, v);
+    row_store<W>(R.o0, g.out0.dtype, n, v);
 }
 
-// filt/gate quads of the same 4 channels `ch`
-__device__ __forceinline__ void epi_gated4(const aew_gemm_nt_t& g, int b, int m, int np_f, int ch,
-                                           float f[4], float gt[4]) {
-    const float* bias = g.bias + (int64_t)b * g.bias_bs;
-    const float4 bf = *reinterpret_cast<const float4*>(bias + np_f);
-    const float4 bg = *reinterpret_cast<const float4*>(bias + np_f + 16);
-    float a[4], s[4], z[4], pf[4], pg[4];
-    if (g.reserved & 512) {                            // ablation: no transcendental math
+// filt / gate values of the same W channels ch..ch+W-1; np_f = packed column of filt channel ch
+// (the W channels lie inside one 16-channel group, so their packed columns are contiguous)
+template <int W>
+__device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& R, int b, int np_f, int ch,
+                                          const float f[W], const float gt[W]) {
+    const float* bias = g.bias + (int64_t)b * g.bias_bs + np_f;
+    float z[W], pf[W], pg[W];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { z[r] = f[r] + bf.x; pf[r] = gt[r] + bg.x; pg[r] = f[r] - gt[r]; }
-        view_store4(g.out0, b, m, ch, z);
-        view_store4(g.out1, b, m, ch, pf);
-        view_store4(g.out2, b, m, ch, pg);
-        return;
-    }
-    a[0] = tanh_f(f[0] + bf.x); a[1] = tanh_f(f[1] + bf.y); a[2] = tanh_f(f[2] + bf.z); a[3] = tanh_f(f[3] + bf.w);
-    s[0] = sigmoid_f(gt[0] + bg.x); s[1] = sigmoid_f(gt[1] + bg.y);
-    s[2] = sigmoid_f(gt[2] + bg.z); s[3] = sigmoid_f(gt[3] + bg.w);
-    // store z and the two local derivatives dz/dfilt, dz/dgate (computed in fp32, so the
-    // saturated-tanh factor 1-a^2 does not suffer bf16 cancellation in backward)
+    for (int q = 0; q < W / 4; ++q) {
+        const float4 bf = *reinterpret_cast<const float4*>(bias + 4 * q);
+        const float4 bg = *reinterpret_cast<const float4*>(bias + 16 + 4 * q);
+        const float fb[4] = {bf.x, bf.y, bf.z, bf.w}, gb[4] = {bg.x, bg.y, bg.z, bg.w};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        z[r] = a[r] * s[r];
-        pf[r] = s[r] * (1.0f - a[r] * a[r]);
-        pg[r] = z[r] * (1.0f - s[r]);
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * q + r;
+            if (g.reserved & 512) { z[e] = f[e] + fb[r]; pf[e] = gt[e] + gb[r]; pg[e] = f[e] - gt[e]; continue; }  // ablation
+            const float a = tanh_f(f[e] + fb[r]);
+            const float s = sigmoid_f(gt[e] + gb[r]);
+            // z and the two local derivatives dz/dfilt, dz/dgate, all from the fp32 factors (the
+            // saturated-tanh factor 1-a^2 would suffer bf16 cancellation if formed in backward)
+            z[e] = a * s;
+            pf[e] = s * (1.0f - a * a);
+            pg[e] = z[e] * (1.0f - s);
+        }
     }
     if (g.reserved & 256) {                            // ablation: math but no stores
-        asm volatile("" ::"v"(z[0] + pf[1] + pg[2] + z[3] + pf[0] + pg[1] + z[2] + pf[3] + pg[0] + z[1] + pf[2] + pg[3]));
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < W; ++e) t += z[e] + pf[e] + pg[e];
+        asm volatile("" ::"v"(t));
         return;
     }
-    view_store4(g.out0, b, m, ch, z);
-    view_store4(g.out1, b, m, ch, pf);
-    view_store4(g.out2, b, m, ch, pg);
+    row_store<W>(R.o0, AEW_BF16, ch, z);
+    row_store<W>(R.o1, AEW_BF16, ch, pf);
+    row_store<W>(R.o2, AEW_BF16, ch, pg);
 }
 
-__device__ __forceinline__ void epi_res_skip4(const aew_gemm_nt_t& g, int b, int m, int n, float v[4]) {
+template <int W>
+__device__ __forceinline__ void epi_res_skip(const aew_gemm_nt_t& g, const EpiRow& R, int n, float v[W]) {
     if (n < g.n_split) {
-        float a[4];
-        view_load4(g.aux0, b, m, n, a);
+        float a[W];
+        row_load<W>(R.a0, g.aux0.dtype, n, a);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += a[r];
-        view_store4(g.out0, b, m, n, v);
+        for (int r = 0; r < W; ++r) v[r] += a[r];
+        row_store<W>(R.o0, g.out0.dtype, n, v);
     } else {
         const int c = n - g.n_split;
-        int64_t row;
-        if (!view_row(g.out1, m, row)) return;
+        if (!R.o1) return;
         if (g.flags & AEW_EF_ACCUM) {
-            float a[4];
-            view_load4(g.out1, b, m, c, a);
+            float a[W];
+            row_load<W>(R.o1, g.out1.dtype, c, a);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += a[r];
+            for (int r = 0; r < W; ++r) v[r] += a[r];
         }
-        view_store4(g.out1, b, m, c, v);
+        row_store<W>(R.o1, g.out1.dtype, c, v);
         if (g.flags & AEW_EF_OUT2_RELU) {
-            float w[4];
+            float w[W];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = v[r] > 0.f ? v[r] : 0.f;
-            view_store4(g.out2, b, m, c, w);
+            for (int r = 0; r < W; ++r) w[r] = v[r] > 0.f ? v[r] : 0.f;
+            row_store<W>(R.o2, g.out2.dtype, c, w);
         }
     }
 }
 
-__device__ __forceinline__ void epi_dfg4(const aew_gemm_nt_t& g, int b, int m, int n, const float dz[4]) {
-    float pf[4], pg[4], df[4], dg[4];
-    view_load4(g.aux0, b, m, n, pf);
-    view_load4(g.aux1, b, m, n, pg);
+template <int W>
+__device__ __forceinline__ void epi_dfg(const aew_gemm_nt_t& g, const EpiRow& R, int n, const float dz[W]) {
+    float pf[W], pg[W], df[W], dg[W];
+    row_load<W>(R.a0, g.aux0.dtype, n, pf);
+    row_load<W>(R.a1, g.aux1.dtype, n, pg);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < W; ++r) {
         df[r] = dz[r] * pf[r];
         dg[r] = dz[r] * pg[r];
     }
-    const int np = (n >> 4) * 32 + (n & 15);
-    view_store4(g.out0, b, m, np, df);
-    view_store4(g.out0, b, m, np + 16, dg);
+    const int np = (n >> 4) * 32 + (n & 15);           // W channels stay inside one 16-group
+    row_store<W>(R.o0, g.out0.dtype, np, df);
+    row_store<W>(R.o0, g.out0.dtype, np + 16, dg);
 }
 
 // =============================================================================================
@@ -141,19 +162,20 @@ struct KIter {
 };
 
 // =============================================================================================
-// NT kernel, bf16: block tile 256 (rows m) x 128 (channels n), BK = 64, 8 waves as 4(m) x 2(n),
+// NT kernel, bf16: block tile 256 (rows m) x 128 (channels n), BK = 32, 8 waves as 4(m) x 2(n),
 // each wave 64 x 64 (4x4 MFMA 16x16x32 tiles).  Operand tiles go global -> LDS by 16-byte LDS-DMA
-// into a 3-stage ring (3 x 48 KiB); tile t+2 is issued while tile t is computed, and the wait
+// into a 3-stage ring (3 x 24 KiB = 72 KiB, so TWO blocks are resident per CU and cover each
+// other's barrier / epilogue stalls); tile t+2 is issued while tile t is computed, and the wait
 // before the per-step barrier is a COUNTED vmcnt that leaves tile t+1's loads in flight
 // (cdna_hip_programming.md T3+T4).  One raw s_barrier per K step.
 // =============================================================================================
 #define NT_BM 256
 #define NT_BN 128
-#define NT_BK 64
-#define NT_ROWB 128                                 // bytes per staged row (64 bf16)
+#define NT_BK 32
+#define NT_ROWB 64                                  // bytes per staged row (32 bf16)
 #define NT_STAGES 3
-#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 48 KiB
-#define NT_LDS_BYTES (NT_STAGES * NT_STAGE_BYTES)   // 144 KiB
+#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 24 KiB
+#define NT_LDS_BYTES (NT_STAGES * NT_STAGE_BYTES)   // 72 KiB
 #define NT_THREADS 512
 
 __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, int m, int esize) {
@@ -162,49 +184,58 @@ __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, in
     return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
 }
 
-// Per-lane source pointers of the 4 X pieces + 2 W pieces (8 rows x 128 B each) a wave stages per
+// Per-lane source pointers of the 2 X pieces + 1 W piece (16 rows x 64 B each) a wave stages per
 // K tile.  Computed once per segment (X) / once per kernel (W) and advanced by one K tile per
 // issue, so the K loop carries no address arithmetic beyond 64-bit adds.
 struct NtPtrs {
-    const char* x[4];
-    const char* w[2];
-    int xinc[4];
+    const char* x[2];
+    const char* w;
+    int xinc[2];
 };
 
 __device__ __forceinline__ void nt_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
                                            NtPtrs& P) {
     const aew_seg_t& s = g.seg[seg];
-    const int lr = lane >> 3, pc = lane & 7;
+    const int lr = lane >> 2, pc = lane & 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 8 + lr;                       // 32 pieces of 8 rows
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 16 + lr;                      // 16 pieces of 16 rows
         const char* src = seg_row_ptr(s, b, m0 + r, 2);
-        P.x[j] = src ? src + (nt_swz(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
+        P.x[j] = src ? src + (nt_swz64(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
         P.xinc[j] = src ? NT_BK * 2 : 0;
     }
 }
 
+// LDS row rho (0..63 inside a wave's 64-column slab) <- W row perm(rho).  With MFMA tile i = rho>>4
+// and MFMA row q = rho&15 a lane (q>>2 = its 16-lane group) ends up holding, across the tile pair
+// (2u, 2u+1), EIGHT consecutive channels: 16-byte epilogue accesses instead of 8-byte ones.
+//   plain  : channel = u*32 + (q>>2)*8 + (i&1)*4 + (q&3)                       (u = i>>1)
+//   gated  : tiles 0,1 = filt, tiles 2,3 = gate of channel c = (q>>2)*8 + (i&1)*4 + (q&3) in the
+//            (16 filt | 16 gate)-interleaved packed order: (c>>4)*32 + (c&15) + 16*(i>>1)
+template <int EPI>
+__device__ __forceinline__ int nt_wperm(int rho) {
+    const int i = rho >> 4, q = rho & 15;
+    const int c = (q >> 2) * 8 + (i & 1) * 4 + (q & 3);
+    if (EPI == AEW_EPI_GATED) return (c >> 4) * 32 + (c & 15) + 16 * (i >> 1);
+    return (i >> 1) * 32 + c;
+}
+
+template <int EPI>
 __device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int wave, int lane, NtPtrs& P) {
-    const int lr = lane >> 3, pc = lane & 7;
-    const char* wbase = reinterpret_cast<const char*>(g.W);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave * 2 + j) * 8 + lr;                       // 16 pieces of 8 rows
-        P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 2 + (nt_swz(r, pc) << 4);
-    }
+    const int lr = lane >> 2, pc = lane & 3;
+    const int r = wave * 16 + lr;                                    // 8 pieces of 16 rows
+    const int src_row = (r & ~63) + nt_wperm<EPI>(r & 63);
+    P.w = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + src_row) * g.K_total * 2 + (nt_swz64(r, pc) << 4);
 }
 
 __device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs& P) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        glds16(P.x[j], stage + (wave * 4 + j) * 1024);
+    for (int j = 0; j < 2; ++j) {
+        glds16(P.x[j], stage + (wave * 2 + j) * 1024);
         P.x[j] += P.xinc[j];
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        glds16(P.w[j], stage + NT_BM * NT_ROWB + (wave * 2 + j) * 1024);
-        P.w[j] += NT_BK * 2;
-    }
+    glds16(P.w, stage + NT_BM * NT_ROWB + wave * 1024);
+    P.w += NT_BK * 2;
 }
 
 struct NtIssue {                                    // walks K tiles across the segment table
@@ -212,7 +243,7 @@ struct NtIssue {                                    // walks K tiles across the 
 };
 
 template <int EPI>
-__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+__global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
@@ -241,7 +272,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
 
     NtPtrs P;
     NtIssue is = {0, 0, 0};
-    nt_setup_w(g, n0, wave, lane, P);
+    nt_setup_w<EPI>(g, n0, wave, lane, P);
     nt_setup_x(g, 0, b, m0, wave, lane, P);
     auto issue_next = [&]() {
         if (is.issued > 0 && !(abl & 128)) {
@@ -259,34 +290,30 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
     if (nkt > 1) issue_next();
     const int fi = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (constant over the K loop)
-    int woff[4][2], xoff[4][2];
+    int woff[4], xoff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rw = wn * 64 + i * 16 + fi, rx = wm * 64 + i * 16 + fi;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            woff[i][kk] = NT_BM * NT_ROWB + rw * NT_ROWB + (nt_swz(rw, kk * 4 + fg) << 4);
-            xoff[i][kk] = rx * NT_ROWB + (nt_swz(rx, kk * 4 + fg) << 4);
-        }
+        woff[i] = NT_BM * NT_ROWB + rw * NT_ROWB + (nt_swz64(rw, fg) << 4);
+        xoff[i] = rx * NT_ROWB + (nt_swz64(rx, fg) << 4);
     }
     int stage = 0;
     for (int t = 0; t < nkt; ++t) {
-        // tile t has landed once at most the 6 loads of tile t+1 are outstanding
-        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // tile t has landed once at most the 3 loads of tile t+1 are outstanding
+        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(abl & 64)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 2 < nkt) issue_next();                 // into the stage computed at step t-1
         const char* st = smem + stage * NT_STAGE_BYTES;
         stage = (stage + 1 == NT_STAGES) ? 0 : stage + 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        {
             bf16x8_t wf[4], xf[4];
             if (!(abl & 2)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i][kk]);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j][kk]);
+                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { wf[i] = __builtin_bit_cast(bf16x8_t, (s16x8_t){1, 2, 3, 4, 5, 6, 7, (short)t}); xf[i] = wf[i]; }
@@ -310,30 +337,34 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_bf16(const aew_gemm_n
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- epilogue: acc[i][j][r] = C[m = m0+wm*64+j*16+fi][n = n0+wn*64+i*16+4*fg+r]
+    // ---- epilogue.  With the staging permutation nt_wperm, lane (fi, fg) holds for row
+    // m = m0 + wm*64 + j*16 + fi the 8 consecutive channels base + fg*8 + {0..7}:
+    // registers acc[2u][j][0..3] ++ acc[2u+1][j][0..3].
     unsigned zc = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + fi;
-        const bool mok = m < g.M;
+        if (m >= g.M) continue;
+        const EpiRow R = epi_row(g, b, m);
         if (EPI == AEW_EPI_GATED) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int np_f = n0 + wn * 64 + p * 32 + 4 * fg;          // packed column of the filt quad
-                const int ch = (np_f >> 5) * 16 + 4 * fg;
-                float f[4] = {acc[2 * p][j][0], acc[2 * p][j][1], acc[2 * p][j][2], acc[2 * p][j][3]};
-                float q[4] = {acc[2 * p + 1][j][0], acc[2 * p + 1][j][1], acc[2 * p + 1][j][2], acc[2 * p + 1][j][3]};
-                if (mok && ch < g.N) epi_gated4(g, b, m, np_f, ch, f, q);
-            }
+            // wave slab = 64 packed columns = 32 channels; tiles 0,1 filt / 2,3 gate
+            const int ch = ((n0 + wn * 64) >> 1) + 8 * fg;
+            const int np_f = (ch >> 4) * 32 + (ch & 15);
+            const float f[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3],
+                                acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+            const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
+                                acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+            if (ch < g.N) epi_gated<8>(g, R, b, np_f, ch, f, q);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 64 + i * 16 + 4 * fg;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (mok && n < g.N) {
-                    if (EPI == AEW_EPI_STORE) epi_store4(g, b, m, n, v, zc);
-                    else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip4(g, b, m, n, v);
-                    else epi_dfg4(g, b, m, n, v);
+            for (int u = 0; u < 2; ++u) {
+                const int n = n0 + wn * 64 + u * 32 + 8 * fg;
+                float v[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
+                              acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
+                if (n < g.N) {
+                    if (EPI == AEW_EPI_STORE) epi_store<8>(g, R, b, n, v, zc);
+                    else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(g, R, n, v);
+                    else epi_dfg<8>(g, R, n, v);
                 }
             }
         }
@@ -432,7 +463,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
         const int m = m0 + j * 16 + fi;
         const int n = n0 + wave * 16 + 4 * kq;
         float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-        if (m < g.M && n < g.N) epi_store4(g, b, m, n, v, zc);
+        if (m < g.M && n < g.N) {
+            const EpiRow R = epi_row(g, b, m);
+            epi_store<4>(g, R, b, n, v, zc);
+        }
     }
     if (g.flags & AEW_EF_COUNT_ZERO) {
         zc = (unsigned)wave_sum((float)zc);
@@ -484,11 +518,12 @@ __global__ void k_gemm_nt_check(const aew_gemm_nt_t g) {
         kglob += sg.k_len;
     }
     unsigned zc = 0;
-    if (g.epi == AEW_EPI_GATED) { if (ch < g.N) epi_gated4(g, b, m, n_f, ch, a0, a1); }
+    const EpiRow R = epi_row(g, b, m);
+    if (g.epi == AEW_EPI_GATED) { if (ch < g.N) epi_gated<4>(g, R, b, n_f, ch, a0, a1); }
     else if (n_f < g.N) {
-        if (g.epi == AEW_EPI_STORE) epi_store4(g, b, m, n_f, a0, zc);
-        else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip4(g, b, m, n_f, a0);
-        else epi_dfg4(g, b, m, n_f, a0);
+        if (g.epi == AEW_EPI_STORE) epi_store<4>(g, R, b, n_f, a0, zc);
+        else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip<4>(g, R, n_f, a0);
+        else epi_dfg<4>(g, R, n_f, a0);
     }
     if ((g.flags & AEW_EF_COUNT_ZERO) && zc) atomicAdd(g.counter, (unsigned long long)zc);
 }
@@ -825,7 +860,7 @@ static int check_seg(const aew_seg_t& s, int esize, int ktile) {
 static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.M <= 0 || g.batch <= 0 || !g.W) return AEW_E_ARG;
     const int es = g.dtype == AEW_BF16 ? 2 : 4;
-    const int kt = g.dtype == AEW_BF16 ? NT_BK : NF_BK;
+    const int kt = g.dtype == AEW_BF16 ? 64 : NF_BK;        // ABI contract: bf16 segments are 64-aligned
     const int ntile = g.dtype == AEW_BF16 ? NT_BN : NF_BN;
     int ksum = 0;
     for (int s = 0; s < g.n_segs; ++s) {
@@ -833,7 +868,7 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         if (rc) return rc;
         ksum += g.seg[s].k_len;
     }
-    if (ksum != g.K_total || g.N_pad % ntile || g.N > g.N_pad || (g.N & 3)) return AEW_E_ARG;
+    if (ksum != g.K_total || g.N_pad % ntile || g.N > g.N_pad || (g.N & (g.dtype == AEW_BF16 ? 7 : 3))) return AEW_E_ARG;
     if (g.epi == AEW_EPI_RES_SKIP && (g.n_split % ntile)) return AEW_E_ARG;
     if (g.epi != AEW_EPI_STORE && g.dtype != AEW_BF16) return AEW_E_UNSUP;
     if (g.impl == 1) {

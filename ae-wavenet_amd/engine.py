@@ -580,7 +580,7 @@ class DecoderPlan:
                                  [self.lcj.seg(Lp, row_off=t) for t in range(3)], TAG_UPS)
         pk.rec(p + "lc_conv.weight", 0, [nin * 3, 3, 1], [Clc, nin, 3], None, 0, [3 * Lp, 1, Lp],
                g_ptr=gp, slabs=gn, slab_stride=gs)
-        plan.add(L.OP_GEMM_NT, make_nt(BF, self.Ne, ru(nin, 4), Lp, B,
+        plan.add(L.OP_GEMM_NT, make_nt(BF, self.Ne, ru(nin, 8), Lp, B,
                                        [dlc1.seg(Cp, row_off=-t) for t in range(3)], self.WlcT.ptr,
                                        out0=self.dlcj.view(), impl=impl), "d.lc_conv", TAG_UPS)
         # ---- jitter scatter back to the LC source

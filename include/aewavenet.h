@@ -104,7 +104,7 @@ typedef struct {
     int32_t dtype;               /* operand type AEW_BF16 | AEW_F32 */
     int32_t impl;                /* 0 = MFMA kernel, 1 = scalar check kernel (same math)      */
     int32_t M;                   /* output rows per batch                                     */
-    int32_t N;                   /* real output columns                                       */
+    int32_t N;                   /* output columns to store: multiple of 8 (bf16) / 4 (f32)   */
     int32_t N_pad;               /* rows of W (multiple of 128 for bf16, 64 for f32)          */
     int32_t batch;
     int32_t n_segs;

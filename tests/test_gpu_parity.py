@@ -81,7 +81,7 @@ def _nt_case(ws, dtype, epi, impl):
     bias = ws.get("bias")
     kw = dict(impl=impl)
     if epi == L.EPI_STORE:
-        return make_nt(dtype, M_, 252, N_pad, B, segs, Wm.ptr, flags=L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE
+        return make_nt(dtype, M_, 248, N_pad, B, segs, Wm.ptr, flags=L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE
                        | L.EF_ADD_AUX0, out0=O0.view(row_off=3, row_step=1), out1=O1.view(),
                        aux0=X0.view(row_off=-2), bias_ptr=bias.data_ptr(), bias_bs=256, **kw)
     if epi == "mask":
