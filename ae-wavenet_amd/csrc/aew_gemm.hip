@@ -534,8 +534,8 @@ __global__ void k_gemm_nt_check(const aew_gemm_nt_t g) {
 // acc[ki][ni][r] = dW[n = n0+wn*64+ni*16+q][k = k0+wk*64+ki*16+4g+r]
 // =============================================================================================
 #define TN_BT 128
-#define TN_RC 64                                    // contraction rows per stage
-#define TN_STAGE_BYTES (2 * TN_RC * 256)            // 32 KiB
+#define TN_RC 32                                    // contraction rows per stage (one MFMA K step)
+#define TN_STAGE_BYTES (2 * TN_RC * 256)            // 16 KiB
 
 struct TnTile { int seg, kin, koff; };              // which segment / column offset this block owns
 
@@ -629,17 +629,18 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
 }
 
 #define TN_STAGES 3
-#define TN_LDS_BYTES (TN_STAGES * TN_STAGE_BYTES)    // 96 KiB
-#define TN_THREADS 512
+#define TN_LDS_BYTES (TN_STAGES * TN_STAGE_BYTES)    // 48 KiB: two (VGPR-limited) blocks per CU
+#define TN_THREADS 256
 
-// 8 waves as 4 (k) x 2 (n): each wave owns 32 (k cols of the A segment) x 64 (n cols of G) of the
-// 128 x 128 output tile.  3-stage LDS ring with counted vmcnt like the NT kernel.
+// 4 waves as 2 (k) x 2 (n): each wave owns 64 (k cols of the A segment) x 64 (n cols of G) of the
+// 128 x 128 output tile (4x4 MFMA tiles -> one transpose-read per MFMA).  3-stage LDS ring with
+// counted vmcnt like the NT kernel.
 template <int SAFE>
 __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits,
                                                                 int rows_per_split, int fold_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wk = wave & 1, wn = wave >> 1;
     const int nkt = g.K_total / TN_BT;
     // XCD-aware order: the output tiles that contract over the same (batch, row chunk) are
     // consecutive on ONE XCD, so the G / A rows of that chunk are fetched into its L2 once.
@@ -653,9 +654,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     const int n0 = nt * TN_BT;
     const int sp = chunk % splits, bz = chunk / splits;
     const TnTile tt = tn_locate(g, kt, TN_BT);
-    f32x4_t acc[2][4];
+    f32x4_t acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int b_lo = fold_batch ? 0 : bz, b_hi = fold_batch ? g.batch : bz + 1;
@@ -686,19 +687,16 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
         const char* gs = smem + stage * TN_STAGE_BYTES;
         const char* as = gs + TN_RC * 256;
         stage = (stage + 1 == TN_STAGES) ? 0 : stage + 1;
+        bf16x8_t af[4], gf[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[2], gf[4];
+        for (int i = 0; i < 4; ++i) af[i] = tn_frag_bf16<SAFE>(as, 0, wk * 64 + i * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = tn_frag_bf16<SAFE>(as, kk * 32, wk * 32 + i * 16, lane);
+        for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16<SAFE>(gs, 0, wn * 64 + j * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16<SAFE>(gs, kk * 32, wn * 64 + j * 16, lane);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
-        }
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
     }
     const int slab = fold_batch ? sp : (bz * splits + sp);
     float* out = g.out + (int64_t)slab * g.out_batch_stride;
@@ -707,8 +705,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + q;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = tt.koff + wk * 32 + i * 16 + 4 * gq;
+        for (int i = 0; i < 4; ++i) {
+            const int k = tt.koff + wk * 64 + i * 16 + 4 * gq;
             *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }

@@ -71,11 +71,11 @@ extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_
             e0 = ev_get(2 * g_ev_used);
             e1 = ev_get(2 * g_ev_used + 1);
             if (!e0 || !e1) return (int)hipErrorOutOfMemory;
-            hipEventRecord(e0, st);
+            (void)hipEventRecord(e0, st);
         }
         const int rc = dispatch(ops[i], st);
         if (g_timing) {
-            hipEventRecord(e1, st);
+            (void)hipEventRecord(e1, st);
             if (g_ev_tag.size() <= g_ev_used) g_ev_tag.resize(g_ev_used + 1);
             g_ev_tag[g_ev_used] = ops[i].tag;
             ++g_ev_used;
@@ -111,11 +111,11 @@ extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, in
     }
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(g_cap_stream, &graph);
-    if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return (int)e;
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return (int)e;
     *exec_out = (void*)exec;
     return 0;
