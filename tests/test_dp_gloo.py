@@ -1,0 +1,80 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  Covers the sampler sharding rule, the
+bucketed gradient all-reduce, the EMA-statistics all-reduce and the parameter broadcast of
+ae_wavenet_amd.dp (the GPU run uses the same code over RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ae_wavenet_amd import config, dp, model as M
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hps = config.make_hps("vqvae-ema", n_res=8, n_dil=8, n_skp=8, n_post=8, n_lc_out=8, n_global_embed=2,
+                              n_speakers=3, n_blocks=1, n_block_layers=2, enc_n_out=8, bn_n_out=4,
+                              bn_vq_n_embed=16, n_win_batch=5)
+        eng = M.TrainEngine(hps, B=1, device="cpu", n_mel=5)          # plans only; buffers on CPU
+        d = dp.DataParallel(bucket_mb=0.001)                           # tiny buckets -> several all-reduces
+        n = eng.ps.numel
+        torch.manual_seed(100 + rank)
+        eng.ps.params[:n].normal_()
+        eng.emb.normal_()
+        d.broadcast_params(eng, src=0)
+        p_sum = eng.ps.params[:n].sum().item()
+        eng.ps.grads[:n].copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        d.allreduce_grads(eng)
+        eng.z_sum.fill_(rank + 1.0)
+        eng.n_sum.fill_(2.0 * (rank + 1))
+        d.allreduce_ema(eng.z_sum, eng.n_sum)
+        q.put((rank, p_sum, eng.ps.grads[:n].tolist(), eng.z_sum[0, 0].item(), eng.n_sum[0].item(),
+               eng.emb.sum().item(), d.grad_scale(True), d.grad_scale(False)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ps0, g0, z0, n0, e0, gm0, gs0), (r1, ps1, g1, z1, n1, e1, gm1, gs1) = res
+    assert ps0 == ps1 and e0 == e1                       # broadcast made the replicas identical
+    assert g0 == g1 and g0 == [3.0 * i for i in range(len(g0))]      # SUM over ranks, every bucket
+    assert z0 == z1 == 3.0 and n0 == n1 == 6.0            # EMA statistics summed over ranks
+    assert gm0 == 0.5 and gs0 == 1.0                      # mean-type losses scale by 1/world
+
+
+def test_shard_indices_match_reference_rule():
+    """data.py:100-106: rank r of W takes range(r, n, W) permuted with seed epoch*W + r."""
+    n, W = 23, 4
+    seen = []
+    for r in range(W):
+        idx = dp.shard_indices(n, r, W, epoch=3)
+        g = torch.Generator().manual_seed(3 * W + r)
+        vals = list(range(r, n, W))
+        perm = torch.randperm(len(vals), generator=g).tolist()
+        assert idx == [vals[i] for i in perm]
+        seen += idx
+    assert sorted(seen) == list(range(n))                 # the shards partition the dataset
