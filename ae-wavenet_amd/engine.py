@@ -216,7 +216,6 @@ class DecoderPlan:
         # local derivatives dz/dfilt, dz/dgate saved by the gated epilogue for backward
         self.pf = [M(f"pf{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
         self.pg = [M(f"pg{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
-        self.skp = M("skp", self.w, self.Sp, F3)
         self.h0 = M("h0", self.w, self.Sp, BF)
         self.h1 = M("h1", self.w, self.Pp, BF)
         self.logits = M("logits", self.w, self.Qp, F3)
@@ -269,6 +268,7 @@ class DecoderPlan:
         self.gbuf: Dict[str, Tuple[int, int, int]] = {}  # name -> (ptr, slab stride, slabs)
         Kfg = 2 * Rp + Cp
         self.VfgT = self._wmat("VfgT", Cp, NL * 2 * Dp)
+        self.Wskp = self._wmat("skp_all", Sp, NL * Dp)
         for l in range(NL):
             last = l == NL - 1
             q = p + f"conv_layers.{l}."
@@ -288,15 +288,17 @@ class DecoderPlan:
                            Wfg, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1])
                     pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
                            self.VfgT, l * 2 * Dp + row0, [32, 1, NL * 2 * Dp])
+            # residual 1x1 (forward) and [res | skip]^T (backward dz); the skip 1x1s of ALL layers
+            # form one matrix Wskp [Sp][NL*Dp] for the deferred skip GEMM (wavenet.py:103,357)
             Nrs = Sp if last else Rp + Sp
-            Wrs = self._wmat(f"rs{l}", Nrs, Dp)
+            Wrs = None if last else self._wmat(f"rs{l}", Rp, Dp)
             WrsT = self._wmat(f"rsT{l}", Dp, Nrs)
             self.Wrs.append(Wrs); self.WrsT.append(WrsT)
             so = 0 if last else Rp
             if not last:
                 pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], Wrs, 0, [Dp, 1])
                 pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], WrsT, 0, [1, Nrs])
-            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], Wrs, so * Dp, [Dp, 1])
+            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], self.Wskp, l * Dp, [NL * Dp, 1])
             pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], WrsT, so, [1, Nrs])
         # post network
         self.Wp1, self.Wp1T = self._wmat("p1", Pp, Sp), self._wmat("p1T", Sp, Pp)
@@ -402,15 +404,16 @@ class DecoderPlan:
                 out0=self.z[l].view(), out1=self.pf[l].view(), out2=self.pg[l].view(),
                 bias_ptr=self.bias_bl.data_ptr() + 4 * l * 2 * Dp, bias_bs=NL * 2 * Dp, impl=impl),
                 f"G1.{l}", TAG_G1)
-            flags = (L.EF_ACCUM if l > 0 else 0) | (L.EF_OUT2_RELU if last else 0)
-            skv = self.skp.view(row_off=-lg.skip_lead)
-            plan.add(L.OP_GEMM_NT, make_nt(
-                BF, P_l, Sp if last else Rp + Sp, Sp if last else Rp + Sp, B, [self.z[l].seg(Dp)],
-                self.Wrs[l].ptr, epi=L.EPI_RES_SKIP, flags=flags,
-                out0=null_view() if last else self.x[l + 1].view(),
-                aux0=null_view() if last else x.view(row_off=lg.dil),
-                out1=skv, out2=self.h0.view(row_off=-lg.skip_lead) if last else null_view(),
-                n_split=0 if last else Rp, impl=impl), f"G2.{l}", TAG_G2)
+            if not last:
+                # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
+                plan.add(L.OP_GEMM_NT, make_nt(
+                    BF, P_l, Rp, Rp, B, [self.z[l].seg(Dp)], self.Wrs[l].ptr, flags=L.EF_ADD_AUX0,
+                    out0=self.x[l + 1].view(), aux0=x.view(row_off=lg.dil), impl=impl), f"G2.{l}", TAG_G2)
+        # skip path of all layers as ONE GEMM: relu(sum_l Wk_l . z_l[u + skip_lead_l]) -> h0
+        # (wavenet.py:103,355-359).  K = NL*256; the fp32 skip sum never touches HBM.
+        segs = [self.z[l].seg(Dp, row_off=lg.skip_lead) for l, lg in enumerate(g.layers)]
+        plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp.ptr, flags=L.EF_RELU,
+                                       out0=self.h0.view(), impl=impl), "skip_all", TAG_G2)
         # 7. post network (wavenet.py:359-360)
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Pp, Pp, B, [self.h0.seg(Sp)], self.Wp1.ptr,
                                        flags=L.EF_BIAS | L.EF_RELU, out0=self.h1.view(),

@@ -228,6 +228,10 @@ class CopyTableBuilder:
         dims, ss, ds = list(dims), list(ss), list(ds)
         while len(dims) < 4:
             dims.insert(0, 1); ss.insert(0, 0); ds.insert(0, 0)
+        # thread index runs fastest over the LAST dim: order dims so that it is the one with the
+        # smallest source stride (coalesced reads; the read side carries the slab reduction)
+        order = sorted(range(4), key=lambda i: (0, 0) if dims[i] == 1 else (1, -abs(ss[i])))
+        dims, ss, ds = [dims[i] for i in order], [ss[i] for i in order], [ds[i] for i in order]
         r = L.CopyRec()
         r.src, r.dst = src_ptr, dst_ptr
         for i in range(4):
