@@ -72,7 +72,7 @@ __device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiRow& 
 
 // filt / gate values of the same W channels ch..ch+W-1; np_f = packed column of filt channel ch
 // (the W channels lie inside one 16-channel group, so their packed columns are contiguous)
-template <int W>
+template <int W, bool ABL = false>
 __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& R, int b, int np_f, int ch,
                                           const float f[W], const float gt[W]) {
     const float* bias = g.bias + (int64_t)b * g.bias_bs + np_f;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * q + r;
-            if (g.reserved & 512) { z[e] = f[e] + fb[r]; pf[e] = gt[e] + gb[r]; pg[e] = f[e] - gt[e]; continue; }  // ablation
+            if (ABL && (g.reserved & 512)) { z[e] = f[e] + fb[r]; pf[e] = gt[e] + gb[r]; pg[e] = f[e] - gt[e]; continue; }  // ablation
             const float a = tanh_f(f[e] + fb[r]);
             const float s = sigmoid_f(gt[e] + gb[r]);
             // z and the two local derivatives dz/dfilt, dz/dgate, all from the fp32 factors (the
@@ -95,7 +95,7 @@ __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& 
             pg[e] = z[e] * (1.0f - s);
         }
     }
-    if (g.reserved & 256) {                            // ablation: math but no stores
+    if (ABL && (g.reserved & 256)) {                   // ablation: math but no stores
         float t = 0.f;
 #pragma unroll
         for (int e = 0; e < W; ++e) t += z[e] + pf[e] + pg[e];
@@ -242,7 +242,9 @@ struct NtIssue {                                    // walks K tiles across the 
     int seg, kin, issued;
 };
 
-template <int EPI>
+// ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved);
+// the production instantiations (ABL = false) contain none of that code.
+template <int EPI, bool ABL = false>
 __global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_n
         if (last < g.out1.row_lo) return;
     }
     const int nkt = g.K_total / NT_BK;
-    const int abl = g.reserved;                        // ablation switches (tools/ablate_gemm.py); 0 in production
+    const int abl = ABL ? g.reserved : 0;              // ablation switches (tools/ablate_gemm.py)
     if (abl & 32) return;                              // launch cost only
     f32x4_t acc[4][4];
 #pragma unroll
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_n
                                 acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
             const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
                                 acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-            if (ch < g.N) epi_gated<8>(g, R, b, np_f, ch, f, q);
+            if (ch < g.N) epi_gated<8, ABL>(g, R, b, np_f, ch, f, q);
         } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -838,6 +840,7 @@ static int ensure_big_lds() {
     if (e != hipSuccess) return (int)e;
     AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_STORE>, NT_LDS_BYTES)
     AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_GATED>, NT_LDS_BYTES)
+    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true>), NT_LDS_BYTES)
     AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, NT_LDS_BYTES)
     AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_DFG>, NT_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
@@ -881,7 +884,10 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / NT_BN));
         switch (g.epi) {
             case AEW_EPI_STORE: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_STORE>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
-            case AEW_EPI_GATED: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
+            case AEW_EPI_GATED:
+                if (g.reserved) hipLaunchKernelGGL((k_gemm_nt_bf16<AEW_EPI_GATED, true>), grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g);
+                else hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g);
+                break;
             case AEW_EPI_RES_SKIP: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
             case AEW_EPI_DFG: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_DFG>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
             default: return AEW_E_UNSUP;

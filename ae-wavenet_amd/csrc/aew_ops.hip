@@ -7,18 +7,40 @@
 __global__ void k_copy_table(const aew_copy_table_t t) {
     const int rec_i = t.block_rec[blockIdx.x];
     const aew_copy_rec_t r = t.recs[rec_i];
-    const int64_t total = (int64_t)r.dims[0] * r.dims[1] * r.dims[2] * r.dims[3];
+    // vector form: 4 consecutive elements of the last dim per thread when the fp32 source is
+    // contiguous there (the gradient-unpack records: float4 loads over every slab)
+    const bool vec = r.src_dtype == AEW_F32 && r.ss[3] == 1 && (r.dims[3] & 3) == 0 &&
+                     (((uintptr_t)r.src | (uintptr_t)(r.ss[2] * 4) | (uintptr_t)(r.ss[1] * 4) |
+                       (uintptr_t)(r.ss[0] * 4) | (uintptr_t)(r.red_stride * 4)) & 15) == 0;
+    const int d3 = vec ? r.dims[3] >> 2 : r.dims[3];
+    const int64_t total = (int64_t)r.dims[0] * r.dims[1] * r.dims[2] * d3;
     const int64_t base = (int64_t)(blockIdx.x - r.first_block) * 1024;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         int64_t e = base + u * 256 + threadIdx.x;
         if (e >= total) return;
-        const int i3 = (int)(e % r.dims[3]); e /= r.dims[3];
+        const int i3 = (int)(e % d3) * (vec ? 4 : 1); e /= d3;
         const int i2 = (int)(e % r.dims[2]); e /= r.dims[2];
         const int i1 = (int)(e % r.dims[1]); e /= r.dims[1];
         const int i0 = (int)e;
         const int64_t so = i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3];
         const int64_t dof = i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
+        if (vec) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < r.red_n; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(r.src) + so + q * r.red_stride);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            const float a4[4] = {acc.x * r.scale, acc.y * r.scale, acc.z * r.scale, acc.w * r.scale};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t d = dof + c * r.ds[3];
+                if (r.dst_dtype == AEW_BF16) reinterpret_cast<uint16_t*>(r.dst)[d] = f2bf(a4[c]);
+                else if (r.accumulate) reinterpret_cast<float*>(r.dst)[d] += a4[c];
+                else reinterpret_cast<float*>(r.dst)[d] = a4[c];
+            }
+            continue;
+        }
         float acc = 0.f;
         for (int q = 0; q < r.red_n; ++q) {
             const int64_t si = so + q * r.red_stride;

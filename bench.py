@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +178,16 @@ def main():
             cls_ms[c] = cls_ms.get(c, 0.0) + ms[i] / n_t
             cls_n[c] = cls_n.get(c, 0) + 1
             kern[tags[i]] = kern.get(tags[i], 0.0) + ms[i] / n_t
+        if args.per_op:
+            labels = eng.fwd_a.labels + eng.fwd_b.labels + eng.bwd.labels + \
+                (eng.cb.labels if hasattr(eng, "cb") else []) + eng.opt.labels
+            per = {}
+            for i in range(min(cnt.value, cap)):
+                lab = labels[i % len(labels)]
+                per[lab] = per.get(lab, 0.0) + ms[i] / n_t
+            with open(args.per_op, "w") as fh:
+                for lab, v in sorted(per.items(), key=lambda kv: -kv[1]):
+                    fh.write(f"{v:9.4f}  {lab}\n")
         fl = eng.flops_per_step()
         # forward + dgrad of the gated stack / post network run on the bf16 NT kernel,
         # wgrad on the bf16 TN kernel  (90.4 MFLOP per output sample per step)
