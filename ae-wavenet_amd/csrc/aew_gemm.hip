@@ -177,6 +177,9 @@ struct KIter {
 #define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 24 KiB
 #define NT_LDS_BYTES (NT_STAGES * NT_STAGE_BYTES)   // 72 KiB
 #define NT_THREADS 512
+#ifndef AEW_NT_SETPRIO
+#define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
+#endif
 
 __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, int m, int esize) {
     const int64_t row = (int64_t)m * s.row_step + s.row_off;
@@ -321,11 +324,13 @@ __global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_n
                 for (int i = 0; i < 4; ++i) { wf[i] = __builtin_bit_cast(bf16x8_t, (s16x8_t){1, 2, 3, 4, 5, 6, 7, (short)t}); xf[i] = wf[i]; }
             }
             if (!(abl & 1)) {
+                if (AEW_NT_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                if (AEW_NT_SETPRIO) __builtin_amdgcn_s_setprio(0);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]), "v"(xf[i]));
@@ -378,33 +383,38 @@ __global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_n
 }
 
 // =============================================================================================
-// NT kernel, fp32 (exact fmaf chain): block tile 32 (rows m) x 64 (channels n), BK = 32 floats,
-// 4 waves each 16 channels x 32 rows.  One accumulator per output, K strictly ascending.
+// NT kernel, fp32 (exact fmaf chain): block tile 16 (rows m) x 64 (channels n), BK = 32 floats,
+// 4 waves each 16 channels x 16 rows = ONE accumulator tile: the dependent MFMA chain over K is
+// the critical path of this weight-bandwidth-bound path (M = B*N_e is tiny), so the work is
+// spread over as many waves as possible.  One accumulator per output, K strictly ascending.
 // =============================================================================================
-#define NF_BM 32
+#define NF_BM 16
 #define NF_BN 64
 #define NF_BK 32
-#define NF_STAGE_BYTES ((NF_BM + NF_BN) * 128)      // 12 KiB
+#define NF_STAGES 3
+#define NF_STAGE_BYTES ((NF_BM + NF_BN) * 128)      // 10 KiB
 
 struct NfPtrs {
-    const char* x;
+    const char* x;                                   // waves 0,1 stage the two X pieces
     const char* w[2];
     int xinc;
 };
 
 __device__ __forceinline__ void nf_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
                                            NfPtrs& P) {
-    // 96 staged rows = 12 pieces of 8 rows: pieces 0..3 = X (one per wave), 4..11 = W
+    // 80 staged rows = 10 pieces of 8 rows: pieces 0,1 = X (waves 0,1), 2..9 = W (two per wave)
     const int lr = lane >> 3, pc = lane & 7;
-    const int r = wave * 8 + lr;
+    const int r = (wave & 1) * 8 + lr;
     const char* src = seg_row_ptr(g.seg[seg], b, m0 + r, 4);
     P.x = src ? src + (nt_swz(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
     P.xinc = src ? NF_BK * 4 : 0;
 }
 
 __device__ __forceinline__ void nf_issue(char* stage, int wave, NfPtrs& P) {
-    glds16(P.x, stage + wave * 1024);
-    P.x += P.xinc;
+    if (wave < 2) {
+        glds16(P.x, stage + wave * 1024);
+        P.x += P.xinc;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         glds16(P.w[j], stage + NF_BM * 128 + (wave + 4 * j) * 1024);
@@ -417,9 +427,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * NF_BM, n0 = blockIdx.y * NF_BN, b = blockIdx.z;
     const int nkt = g.K_total / NF_BK;
-    f32x4_t acc[2];
-    acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     NfPtrs P;
     {
         const int lr = lane >> 3, pc = lane & 7;
@@ -430,41 +438,50 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
             P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 4 + (nt_swz(r, pc) << 4);
         }
     }
-    int seg = 0, kin = 0;
+    int seg = 0, kin = 0, issued = 0;
     nf_setup_x(g, 0, b, m0, wave, lane, P);
-    nf_issue(smem, wave, P);
-    const int fi = lane & 15, kq = lane >> 4;
-    const int rw = wave * 16 + fi;
-    for (int t = 0; t < nkt; ++t) {
-        wait_vm0();
-        __syncthreads();
-        if (t + 1 < nkt) {
+    auto issue_next = [&]() {
+        if (issued > 0) {
             kin += NF_BK;
             if (kin >= g.seg[seg].k_len) {
                 ++seg; kin = 0;
                 nf_setup_x(g, seg, b, m0, wave, lane, P);
             }
-            nf_issue(smem + ((t + 1) & 1) * NF_STAGE_BYTES, wave, P);
         }
-        const char* xs = smem + (t & 1) * NF_STAGE_BYTES;
+        nf_issue(smem + (issued % NF_STAGES) * NF_STAGE_BYTES, wave, P);
+        ++issued;
+    };
+    issue_next();
+    if (nkt > 1) issue_next();
+    const int fi = lane & 15, kq = lane >> 4;
+    const int rw = wave * 16 + fi;
+    int stage = 0;
+    for (int t = 0; t < nkt; ++t) {
+        // waves 0,1 have 3 loads per tile in flight, waves 2,3 have 2
+        if (t + 1 < nkt) {
+            if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nkt) issue_next();
+        const char* xs = smem + stage * NF_STAGE_BYTES;
         const char* ws = xs + NF_BM * 128;
+        stage = (stage + 1 == NF_STAGES) ? 0 : stage + 1;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const float wv = *reinterpret_cast<const float*>(ws + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int rx = j * 16 + fi;
-                const float xv = *reinterpret_cast<const float*>(xs + rx * 128 + (nt_swz(rx, ks) << 4) + kq * 4);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[j], 0, 0, 0);
-            }
+            const float xv = *reinterpret_cast<const float*>(xs + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc, 0, 0, 0);
         }
     }
     unsigned zc = 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + j * 16 + fi;
+    {
+        const int m = m0 + fi;
         const int n = n0 + wave * 16 + 4 * kq;
-        float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
         if (m < g.M && n < g.N) {
             const EpiRow R = epi_row(g, b, m);
             epi_store<4>(g, R, b, n, v, zc);
@@ -894,7 +911,7 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         }
     } else {
         dim3 grid((g.M + NF_BM - 1) / NF_BM, g.N_pad / NF_BN, g.batch);
-        hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), 2 * NF_STAGE_BYTES, st, g);
+        hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), NF_STAGES * NF_STAGE_BYTES, st, g);
     }
     return (int)hipGetLastError();
 }

@@ -408,6 +408,85 @@ def test_full_width_step_vs_oracle():
     print("worst gradient max-normalised error:", worst)
 
 
+def test_mfcc_inverter_full_width_vs_reference_golden(golden_dir):
+    """BASELINE configs[0] shape (mfcc-inverter, B=2, w=100, full width, 13.5 M parameters):
+    the GPU path against tensors captured from the UNMODIFIED reference MfccInverter.run
+    (tests/golden/mi_full.npz; weights regenerated from the recorded seed)."""
+    z = load(golden_dir, "mi_full.npz")
+    hps = config.make_hps("mi", n_win_batch=100)
+    eng = M.TrainEngine(hps, B=2, device=DEV, n_mel=39, take_compat=True)
+    shapes = json.loads(str(z["param_names"]))
+    assert shapes == {k: list(eng.ps.shape[k]) for k in eng.ps.names()}
+    wts = np_weights(shapes, int(z["seed"]))
+    for k, v in wts.items():
+        eng.ps.view(k).copy_(torch.from_numpy(v))
+    eng.set_inputs(*[torch.from_numpy(z[k]).to(DEV) for k in ("wav", "mel", "voice", "jitter")])
+    loss = eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) / float(z["loss"]) - 1) < 5e-3, (float(loss), float(z["loss"]))
+    pred = eng.logits()[:, :-1, :].permute(0, 2, 1)[:, :, ::9].cpu().numpy()
+    assert np.abs(pred - z["pred_sub"]).max() <= 0.06
+    tgt = eng.in_wav[:, eng.geom.wav_out_off + 1: eng.geom.wav_out_off + 100].cpu().numpy()
+    assert np.array_equal(tgt, z["target"])
+    mg = eng.dec.dlc_src.tensor()[:, :, :39].permute(0, 2, 1).cpu().numpy()
+    cos = (mg * z["mel_grad"]).sum() / (np.linalg.norm(mg) * np.linalg.norm(z["mel_grad"]))
+    assert cos > 0.99, cos
+    for k in z:
+        if k.startswith("grad."):
+            got, ref = eng.ps.view(k[5:], grad=True).cpu().numpy(), z[k]
+        elif k.startswith("gradslice."):
+            got, ref = eng.ps.view(k[10:], grad=True).cpu().numpy()[:8, :8], z[k]
+        else:
+            continue
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        assert err < 0.15, (k, err)
+
+
+def test_vae_and_deep_configs_full_size():
+    """BASELINE configs[3] (VAE bottleneck, jitter on, B=8, w=5000) and configs[4] per-GPU
+    shape (30 layers x 512 residual channels, 64k-sample windows, B=4 per GPU): the step runs,
+    is finite, and is reproducible."""
+    from ae_wavenet_amd import config as C_
+    rs = np.random.RandomState(0)
+    for arch, B, w, kw in (("vae", 8, 5000, {}), ("deep", 4, 65536, {})):
+        hps = C_.make_hps(arch, n_win_batch=w, **kw)
+        eng = M.TrainEngine(hps, B=B, device=DEV, n_mel=39, update_codebook_every_step=False)
+        gen = torch.Generator().manual_seed(1)
+        for k in eng.ps.names():
+            t = torch.empty(eng.ps.shape[k])
+            if t.dim() >= 2:
+                torch.nn.init.xavier_uniform_(t, generator=gen)
+            else:
+                t.zero_()
+            eng.ps.view(k).copy_(t)
+        g = eng.geom
+        if arch == "deep":
+            assert (g.enc_in_len, g.embed_len, g.dec_in_len) == (73520, 222, 68605)      # SURVEY A.2
+            eng.emb.normal_(generator=None)
+            eng.init_ema_from_emb()
+        wav = torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float().to(DEV)
+        mel = torch.randn(B, 39, g.mel_len, generator=gen).to(DEV)
+        voice = torch.randint(0, 40, (B,), generator=gen).to(DEV)
+        j = np.arange(g.embed_len)[None, :] + rs.randint(-1, 2, size=(B, g.embed_len))      # jitter on
+        jitter = torch.from_numpy(np.clip(j, 0, g.embed_len - 1)).to(DEV)
+        eps = torch.randn(B, g.embed_len, hps.bn_n_out, generator=gen).to(DEV) if arch == "vae" else None
+        if arch == "vae":
+            eng.set_anneal_weight(0.3)
+        eng.set_inputs(wav, mel, voice, jitter, eps=eps)
+        l0 = float(eng.forward())
+        eng.backward()
+        g0 = eng.ps.grads[:eng.ps.numel].clone()
+        assert np.isfinite(l0) and torch.isfinite(g0).all() and g0.abs().max() > 0
+        eng.set_inputs(wav, mel, voice, jitter, eps=eps)
+        if arch == "deep":
+            eng.init_ema_from_emb()
+        l1 = float(eng.forward())
+        assert l1 == l0
+        del eng
+        torch.cuda.empty_cache()
+
+
 def test_module_surface_trains():
     """Drop-in surface: run() -> loss.backward() -> FusedAdam.step() reduces the loss on a
     fixed batch; torch.optim.Adam on the same parameters gives the same first update."""
