@@ -90,6 +90,24 @@ def cpu_baseline(hps, eng, seconds_budget=40.0):
                       f"({best:.2f} s/step)"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_pmc_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH doubled per MI355X_MICROARCH.md).  bench.py cannot collect PMCs itself."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
+    try:
+        import csv
+        n = tot = 0.0
+        for r in csv.DictReader(open(path)):
+            if r["kernel"].startswith("k_gemm_nt_bf16"):
+                k = float(r["launches"])
+                n += k
+                tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
+        return {"bytes_per_launch": round(tot / n), "source": "profiles/r01_pmc_hbm_traffic.csv"} if n else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,7 +213,7 @@ def main():
         n_launch = max(cls_n.get(1, 0) // n_t, 1)
         achieved = nt_flops / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "k_gemm_nt_bf16", "achieved": round(achieved, 2), "peak": 2500.0,
-                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": pmc_traffic(),
                 "launches_per_step": n_launch, "avg_launch_ms": round(nt_ms / n_launch, 5),
                 "alg_flops_per_launch": nt_flops / n_launch,
                 "tn_bf16": {"achieved": round((fl["step"] / 3.0) / (cls_ms.get(2, 1e9) * 1e-3) / 1e12, 2),
