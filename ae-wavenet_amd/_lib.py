@@ -163,7 +163,7 @@ class _OpU(C.Union):
 
 
 class Op(C.Structure):
-    _fields_ = [("kind", i32), ("tag", i32), ("u", _OpU)]
+    _fields_ = [("kind", i32), ("tag", i32), ("lane", i32), ("join", i32), ("u", _OpU)]
 
 
 OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEAREST: "vqn",
@@ -205,7 +205,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 1:
+    if lib.aew_abi_version() != 2:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -226,4 +226,5 @@ def tn_slabs(tn: GemmTN) -> int:
 
 EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe",
-           "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows")
+           "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
+           "aew_set_lanes")

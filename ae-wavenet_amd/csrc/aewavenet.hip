@@ -62,30 +62,83 @@ extern "C" int aew_sizeof(int which) {
     }
 }
 
-extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index) {
-    if (!ops || n < 0) return AEW_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    for (int i = 0; i < n; ++i) {
+// ---------------------------------------------------------------------------------------------
+// plan execution.  Lane-1 ops go to a private side stream; fork/join edges are HIP events, which
+// inside a stream capture become graph dependencies (the side stream joins the capture by
+// waiting on an event recorded in the capturing stream).
+// ---------------------------------------------------------------------------------------------
+static int g_lanes = 1;
+static hipStream_t g_side_stream = nullptr;
+static std::vector<hipEvent_t> g_lane_ev;
+static size_t g_lane_ev_next = 0;
+
+extern "C" int aew_set_lanes(int on) { g_lanes = on ? 1 : 0; return 0; }
+
+static hipEvent_t lane_event() {
+    const size_t POOL = 64;
+    if (g_lane_ev.size() < POOL) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        g_lane_ev.push_back(e);
+        return e;
+    }
+    return g_lane_ev[g_lane_ev_next++ % POOL];
+}
+
+static int edge(hipStream_t from, hipStream_t to) {          // `to` continues after `from`'s work so far
+    hipEvent_t e = lane_event();
+    if (!e) return (int)hipErrorOutOfMemory;
+    hipError_t rc = hipEventRecord(e, from);
+    if (rc != hipSuccess) return (int)rc;
+    return (int)hipStreamWaitEvent(to, e, 0);
+}
+
+static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, bool timing) {
+    const bool lanes = g_lanes && !timing;
+    bool main_ahead = true;          // main has work the side stream has not been ordered after
+    bool side_open = false;          // side has work main has not joined
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_timing) {
+        hipStream_t target = st;
+        if (lanes && ops[i].lane == 1) {
+            if (!g_side_stream) {
+                hipError_t e = hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking);
+                if (e != hipSuccess) { rc = (int)e; break; }
+            }
+            if (main_ahead) { rc = edge(st, g_side_stream); main_ahead = false; }
+            target = g_side_stream;
+            side_open = true;
+        } else {
+            if (ops[i].join && side_open) { rc = edge(g_side_stream, st); side_open = false; }
+            main_ahead = true;
+        }
+        if (rc != 0) { if (fail_index) *fail_index = i; break; }
+        if (timing) {
             e0 = ev_get(2 * g_ev_used);
             e1 = ev_get(2 * g_ev_used + 1);
             if (!e0 || !e1) return (int)hipErrorOutOfMemory;
             (void)hipEventRecord(e0, st);
         }
-        const int rc = dispatch(ops[i], st);
-        if (g_timing) {
+        rc = dispatch(ops[i], target);
+        if (timing) {
             (void)hipEventRecord(e1, st);
             if (g_ev_tag.size() <= g_ev_used) g_ev_tag.resize(g_ev_used + 1);
             g_ev_tag[g_ev_used] = ops[i].tag;
             ++g_ev_used;
         }
-        if (rc != 0) {
-            if (fail_index) *fail_index = i;
-            return rc;
-        }
+        if (rc != 0 && fail_index) *fail_index = i;
     }
-    return 0;
+    if (side_open) {                                         // implicit join (also on the error path,
+        const int jr = edge(g_side_stream, st);              // so a capture is never left forked)
+        if (rc == 0) rc = jr;
+    }
+    return rc;
+}
+
+extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index) {
+    if (!ops || n < 0) return AEW_E_ARG;
+    return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -105,10 +158,7 @@ extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, in
     }
     e = hipStreamBeginCapture(g_cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return (int)e;
-    for (int i = 0; i < n && rc == 0; ++i) {
-        rc = dispatch(ops[i], g_cap_stream);
-        if (rc != 0 && fail_index) *fail_index = i;
-    }
+    rc = run_ops(ops, n, g_cap_stream, fail_index, false);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(g_cap_stream, &graph);
     if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }

@@ -226,8 +226,9 @@ class DecoderPlan:
         self.dlogits = M("dlogits", self.w, self.Qp, BF)
         self.dh1 = M("dh1", self.w, self.Pp, BF)
         self.dskp = M("dskp", self.w, self.Sp, BF)
-        self.dxa = M("dxa", self.T, self.Rp, BF)
-        self.dxb = M("dxb", self.T, self.Rp, BF)
+        # one dx buffer per layer (not a ping-pong pair): the res / base wgrads that read dx_{l+1} run
+        # on the side lane and may lag the dx chain by several layers
+        self.dx = [M(f"dx{l}", g.layers[l].in_len, self.Rp, BF) for l in range(self.NL)]
         self.dfg = [M(f"dfg{l}", lg.out_len, 2 * self.Dp, BF) for l, lg in enumerate(g.layers)]
         self.colsum_fg = ws.alloc(p + "colsum_fg", B * self.NL * 2 * self.Dp, torch.float32)
         self.dcond = M("dcond", self.T, self.Cp, BF)
@@ -451,7 +452,8 @@ class DecoderPlan:
         cs.x = X.seg(128, row_off=row_off)
         cs.dtype, cs.M, cs.N, cs.batch = X.dtype, M, N, self.B
         cs.out, cs.out_bs, cs.accumulate = out_ptr, out_bs, 1      # target pre-zeroed by the plan
-        plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
+        with plan.side():
+            plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
 
     def _wgrad(self, plan: Plan, name: str, dtype: int, Mc: int, N: int, N_pad: int, gseg: L.Seg,
                segs: Sequence[L.Seg], tag: int) -> Tuple[int, int, int]:
@@ -459,7 +461,8 @@ class DecoderPlan:
         slabs = L.tn_slabs(t)
         ptr, stride = self._gslab(name, N_pad, t.K_total, slabs)
         t.out, t.out_batch_stride = ptr, stride
-        plan.add(L.OP_GEMM_TN, t, "wgrad." + name, tag)
+        with plan.side():                                          # off the dgrad chain
+            plan.add(L.OP_GEMM_TN, t, "wgrad." + name, tag)
         self.gbuf[name] = (ptr, stride, slabs)
         return ptr, stride, slabs
 
@@ -492,7 +495,6 @@ class DecoderPlan:
         Kfg = 2 * Rp + Cp
         Cc = Clc + self.Gc
         dx_next: Optional[Mat] = None
-        bufs = [self.dxa, self.dxb]
         colsum_tbl = CopyTableBuilder(self.ws, p + "tbl.colsum")
         for l in range(NL - 1, -1, -1):
             lg = g.layers[l]
@@ -533,7 +535,7 @@ class DecoderPlan:
                            None, row0 * Kfg, [32 * Kfg, Kfg, 1, Rp], g_ptr=gp, slabs=gn, slab_stride=gs)
                     pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
                            None, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
-            dx = bufs[l & 1]
+            dx = self.dx[l]
             segs = [self.dfg[l].seg(2 * Dp), self.dfg[l].seg(2 * Dp, row_off=-d)]
             plan.add(L.OP_GEMM_NT, make_nt(
                 BF, lg.in_len, Rp, Rp, B, segs, self.WfgT[l].ptr,
@@ -552,11 +554,12 @@ class DecoderPlan:
         plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT.ptr, out0=self.dcond.view(),
                                        impl=impl), "dcond", TAG_DCOND)
         # ---- speaker / gated-bias gradients
-        colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)")
         sbw = L.SpkBwd()
         self._fill_spk(sbw)
         sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
-        plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC)
+        with plan.side():                                          # reads the side lane's wgrad slabs
+            colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)")
+            plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC)
         # ---- upsamplers, last stage first (wavenet.py:154)
         n_ups = len(hps.lc_upsample_strides)
         for i in range(n_ups - 1, -1, -1):
@@ -668,13 +671,15 @@ class EncoderPlan:
             cs.x = dpre.seg(64)
             cs.dtype, cs.M, cs.N, cs.batch = F3, Lo, E, B
             cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 1
-            plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
+            with plan.side():
+                plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
             t = make_tn(F3, Lo, B, E, Ep, dpre.seg(64), [X.seg(cinp, row_step=s, row_off=k) for k in range(f)],
                         impl=impl)
             slabs = L.tn_slabs(t)
             gt = self.ws.alloc(f"enc.wg.{i}", slabs * Ep * t.K_total, torch.float32)
             t.out, t.out_batch_stride = gt.data_ptr(), Ep * t.K_total
-            plan.add(L.OP_GEMM_TN, t, f"wgrad.enc{i}", TAG_ENC)
+            with plan.side():
+                plan.add(L.OP_GEMM_TN, t, f"wgrad.enc{i}", TAG_ENC)
             pk.rec(f"encoder.net.{i}.conv.weight", 0, [cin * f, f, 1], [E, cin, f], None, 0,
                    [f * cinp, 1, cinp], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=Ep * t.K_total)
             if i == 0 and not need_input_grad:

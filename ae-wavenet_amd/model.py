@@ -238,13 +238,15 @@ class TrainEngine:
                 cs.x = self.dlin.seg(64)
                 cs.dtype, cs.M, cs.N, cs.batch = F3, g.embed_len, self.d, B
                 cs.out, cs.out_bs, cs.accumulate = ps.ptr("bottleneck.linear.bias", True), 0, 1
-                bw.add(L.OP_COLSUM, cs, "db.bn", TAG_VQ)
+                with bw.side():
+                    bw.add(L.OP_COLSUM, cs, "db.bn", TAG_VQ)
             # linear wgrad / dgrad
             t = make_tn(F3, g.embed_len, B, self.nlin, self.nlin_p, self.dlin.seg(64), [y9.seg(Ep)], impl=impl)
             slabs = L.tn_slabs(t)
             gt = ws.alloc("bn.wg.lin", slabs * self.nlin_p * Ep, torch.float32)
             t.out, t.out_batch_stride = gt.data_ptr(), self.nlin_p * Ep
-            bw.add(L.OP_GEMM_TN, t, "wgrad.bn.linear", TAG_VQ)
+            with bw.side():
+                bw.add(L.OP_GEMM_TN, t, "wgrad.bn.linear", TAG_VQ)
             self.pk.rec("bottleneck.linear.weight", 0, [hps.enc_n_out, 1], [self.nlin, hps.enc_n_out], None, 0,
                         [Ep, 1], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=self.nlin_p * Ep)
             bw.add(L.OP_GEMM_NT, make_nt(F3, g.embed_len, hps.enc_n_out, Ep, B, [self.dlin.seg(self.nlin_p)],
@@ -252,7 +254,7 @@ class TrainEngine:
                                          out1=self.enc.dpre[9].view(), aux1=self.enc.r[9].view(), impl=impl),
                    "d.bn.linear", TAG_VQ)
             self.enc.build_backward(bw, need_input_grad=True)
-        self.unpack_tbl.emit(bw, "unpack grads")
+        self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads every side-lane wgrad slab
         if bn == "vqvae-ema":
             # deferred codebook refresh (vqema_bn.py:216-222)
             self.cb = Plan("codebook")

@@ -116,8 +116,21 @@ class Plan:
         self._arr = None
         self._graph = None            # hipGraphExec handle (lazy)
         self.keep: list = []          # device tables etc. that must outlive the plan
+        self.lane = 0                 # lane given to ops added next (see aew_op_t in aewavenet.h)
 
-    def add(self, kind: int, payload, label: str, tag: int = 0) -> L.Op:
+    def side(self):
+        """`with plan.side():` — ops added inside are off the critical chain (lane 1)."""
+        plan = self
+
+        class _Side:
+            def __enter__(self):
+                self.prev, plan.lane = plan.lane, 1
+
+            def __exit__(self, *a):
+                plan.lane = self.prev
+        return _Side()
+
+    def add(self, kind: int, payload, label: str, tag: int = 0, join: bool = False) -> L.Op:
         op = L.Op()
         # tag = semantic tag + 100 * kernel class (1 NT bf16, 2 TN bf16, 3 NT f32, 4 TN f32)
         cls = 0
@@ -126,6 +139,7 @@ class Plan:
         elif kind == L.OP_GEMM_TN:
             cls = 2 if payload.dtype == L.BF16 else 4
         op.kind, op.tag = kind, tag + 100 * cls
+        op.lane, op.join = self.lane, int(join)
         setattr(op.u, L.OP_FIELD[kind], payload)
         self.ops.append(op)
         self.labels.append(label)
@@ -240,7 +254,7 @@ class CopyTableBuilder:
         r.accumulate, r.scale = int(accumulate), scale
         self.recs.append(r)
 
-    def emit(self, plan: Plan, label: str):
+    def emit(self, plan: Plan, label: str, join: bool = False):
         if not self.recs:
             return
         block_rec: List[int] = []
@@ -257,4 +271,4 @@ class CopyTableBuilder:
         t = L.CopyTable()
         t.recs, t.block_rec = rec_t.data_ptr(), blk_t.data_ptr()
         t.n_blocks, t.n_recs = len(block_rec), len(self.recs)
-        plan.add(L.OP_COPY_TABLE, t, label)
+        plan.add(L.OP_COPY_TABLE, t, label, join=join)

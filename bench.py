@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--lanes", type=int, default=1, help="0: serial plan order (no side-lane overlap)")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
@@ -136,6 +137,7 @@ def main():
 
     from ae_wavenet_amd import _lib as L
     lib = L.load()
+    lib.aew_set_lanes(args.lanes)
     hps, eng = build_engine(args, device)
     if dp is not None:
         dp.broadcast_params(eng)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 1
+#define AEW_ABI_VERSION 2
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -315,9 +315,20 @@ enum {
     AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM
 };
 
+/* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
+ * critical chain (weight gradients, bias column sums, weight packing) so that they execute on a
+ * second HIP stream / a parallel hipGraph branch and fill the tail of the chain's kernels:
+ *   lane 0 (main)  runs after the preceding lane-0 ops; it waits for preceding lane-1 ops only
+ *                  if `join` != 0.  The end of the plan is an implicit join.
+ *   lane 1 (side)  runs after ALL ops that precede it in the plan (both lanes).
+ * Any serial execution in plan order is a valid schedule (that is what the timing mode and
+ * aew_set_lanes(0) do), so a lane assignment is correct iff no lane-0 op without `join` reads or
+ * overwrites what an earlier, un-joined lane-1 op writes or reads. */
 typedef struct {
     int32_t kind;
     int32_t tag;                 /* caller-defined label, reported by the timing interface    */
+    int32_t lane;                /* 0 main, 1 side                                             */
+    int32_t join;                /* lane-0 op: wait for every preceding lane-1 op first        */
     union {
         aew_gemm_nt_t nt; aew_gemm_tn_t tn; aew_copy_table_t copy; aew_vq_nearest_t vqn;
         aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;
@@ -347,6 +358,9 @@ int aew_graph_destroy(void* exec);
  * execution order since the last enable) and its tag. */
 int aew_timing_enable(int on);
 int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
+
+/* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
+int aew_set_lanes(int on);
 
 /* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */
 int aew_tn_slabs(const aew_gemm_tn_t* g);

@@ -560,3 +560,42 @@ def test_full_size_properties():
     eng.set_inputs(wav2, mel, voice, jitter)
     eng.forward()
     assert torch.equal(eng.logits(), lg0)
+
+
+def test_two_lane_schedule_is_bit_identical_to_serial():
+    """The side-lane assignment (wgrads / column sums off the dgrad chain, aew_op_t.lane) must not
+    change any result: serial plan order is the reference schedule.  Replayed several times in graph
+    and eager form so a missing dependency shows as a mismatch."""
+    hps, eng, wts, emb, inp = seeded_full_engine(B=8, w=5000, seed=11)
+    wav, mel, voice, jitter = [t.to(DEV) for t in inp]
+    eng.set_inputs(wav, mel, voice, jitter)
+    lib = L.load()
+
+    def step():
+        eng.init_ema_from_emb()
+        loss = float(eng.forward())
+        eng.backward()
+        torch.cuda.synchronize()
+        return loss, eng.ps.grads[:eng.ps.numel].clone()
+
+    def recapture():
+        for pl in (eng.fwd_a, eng.fwd_b, eng.bwd):
+            pl.invalidate_graph()
+
+    assert any(op.lane == 1 for op in eng.bwd.ops) and any(op.join for op in eng.bwd.ops)
+    try:
+        lib.aew_set_lanes(0)
+        recapture()
+        l_ref, g_ref = step()
+        lib.aew_set_lanes(1)
+        recapture()
+        for _ in range(4):
+            l, g = step()
+            assert l == l_ref and torch.equal(g, g_ref)
+        eng.use_graphs = False                      # eager: two real streams + events
+        for _ in range(2):
+            l, g = step()
+            assert l == l_ref and torch.equal(g, g_ref)
+    finally:
+        eng.use_graphs = True
+        lib.aew_set_lanes(1)
