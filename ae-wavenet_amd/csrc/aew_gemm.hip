@@ -29,10 +29,22 @@ __device__ __forceinline__ EpiRow epi_row(const aew_gemm_nt_t& g, int b, int m) 
     return R;
 }
 
+// wave-uniform descriptor fields the epilogues need, read once (they live in kernarg memory)
+struct EpiUni {
+    unsigned fl;
+    int N, n_split, dt_o0, dt_o1, dt_o2, dt_a0, dt_a1;
+};
+__device__ __forceinline__ EpiUni epi_uni(const aew_gemm_nt_t& g) {
+    EpiUni u;
+    u.fl = g.flags; u.N = g.N; u.n_split = g.n_split;
+    u.dt_o0 = g.out0.dtype; u.dt_o1 = g.out1.dtype; u.dt_o2 = g.out2.dtype;
+    u.dt_a0 = g.aux0.dtype; u.dt_a1 = g.aux1.dtype;
+    return u;
+}
+
 template <int W>
-__device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiRow& R, int b, int n, float v[W],
-                                          unsigned& zero_count) {
-    const unsigned fl = g.flags;
+__device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiUni& U, const EpiRow& R, int b, int n,
+                                          float v[W], unsigned& zero_count, unsigned fl) {
     if (fl & AEW_EF_BIAS) {
         const float* bp = g.bias + (int64_t)b * g.bias_bs + n;
 #pragma unroll
@@ -45,19 +57,19 @@ __device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiRow& 
 #pragma unroll
         for (int r = 0; r < W; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
     }
-    if (fl & AEW_EF_OUT1_PRE) row_store<W>(R.o1, g.out1.dtype, n, v);
+    if (fl & AEW_EF_OUT1_PRE) row_store<W>(R.o1, U.dt_o1, n, v);
     if (fl & AEW_EF_ADD_AUX0) {
         float a[W];
-        row_load<W>(R.a0, g.aux0.dtype, n, a);
+        row_load<W>(R.a0, U.dt_a0, n, a);
 #pragma unroll
         for (int r = 0; r < W; ++r) v[r] = v[r] + a[r];
     }
     if (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)) {
         float a[W], w[W];
-        row_load<W>(R.a1, g.aux1.dtype, n, a);
+        row_load<W>(R.a1, U.dt_a1, n, a);
 #pragma unroll
         for (int r = 0; r < W; ++r) w[r] = a[r] > 0.f ? v[r] : 0.f;
-        if (fl & AEW_EF_OUT1_POS1) row_store<W>(R.o1, g.out1.dtype, n, w);
+        if (fl & AEW_EF_OUT1_POS1) row_store<W>(R.o1, U.dt_o1, n, w);
         if (fl & AEW_EF_MUL_POS1) {
 #pragma unroll
             for (int r = 0; r < W; ++r) v[r] = w[r];
@@ -65,29 +77,26 @@ __device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiRow& 
     }
     if ((fl & AEW_EF_COUNT_ZERO) && R.o0) {
 #pragma unroll
-        for (int r = 0; r < W; ++r) zero_count += (n + r < g.N && v[r] == 0.f) ? 1u : 0u;
+        for (int r = 0; r < W; ++r) zero_count += (n + r < U.N && v[r] == 0.f) ? 1u : 0u;
     }
-    row_store<W>(R.o0, g.out0.dtype, n, v);
+    row_store<W>(R.o0, U.dt_o0, n, v);
 }
 
 // filt / gate values of the same W channels ch..ch+W-1; np_f = packed column of filt channel ch
 // (the W channels lie inside one 16-channel group, so their packed columns are contiguous)
+// fbias / gbias: the W filt / gate biases of channels ch..ch+W-1 (loaded once per wave by the caller)
 template <int W, bool ABL = false>
-__device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& R, int b, int np_f, int ch,
-                                          const float f[W], const float gt[W]) {
-    const float* bias = g.bias + (int64_t)b * g.bias_bs + np_f;
+__device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& R, int ch, const float f[W],
+                                          const float gt[W], const float fbias[W], const float gbias[W]) {
     float z[W], pf[W], pg[W];
 #pragma unroll
     for (int q = 0; q < W / 4; ++q) {
-        const float4 bf = *reinterpret_cast<const float4*>(bias + 4 * q);
-        const float4 bg = *reinterpret_cast<const float4*>(bias + 16 + 4 * q);
-        const float fb[4] = {bf.x, bf.y, bf.z, bf.w}, gb[4] = {bg.x, bg.y, bg.z, bg.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * q + r;
-            if (ABL && (g.reserved & 512)) { z[e] = f[e] + fb[r]; pf[e] = gt[e] + gb[r]; pg[e] = f[e] - gt[e]; continue; }  // ablation
-            const float a = tanh_f(f[e] + fb[r]);
-            const float s = sigmoid_f(gt[e] + gb[r]);
+            if (ABL && (g.reserved & 512)) { z[e] = f[e] + fbias[e]; pf[e] = gt[e] + gbias[e]; pg[e] = f[e] - gt[e]; continue; }  // ablation
+            const float a = tanh_f(f[e] + fbias[e]);
+            const float s = sigmoid_f(gt[e] + gbias[e]);
             // z and the two local derivatives dz/dfilt, dz/dgate, all from the fp32 factors (the
             // saturated-tanh factor 1-a^2 would suffer bf16 cancellation if formed in backward)
             z[e] = a * s;
@@ -108,45 +117,45 @@ __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& 
 }
 
 template <int W>
-__device__ __forceinline__ void epi_res_skip(const aew_gemm_nt_t& g, const EpiRow& R, int n, float v[W]) {
-    if (n < g.n_split) {
+__device__ __forceinline__ void epi_res_skip(const EpiUni& U, const EpiRow& R, int n, float v[W]) {
+    if (n < U.n_split) {
         float a[W];
-        row_load<W>(R.a0, g.aux0.dtype, n, a);
+        row_load<W>(R.a0, U.dt_a0, n, a);
 #pragma unroll
         for (int r = 0; r < W; ++r) v[r] += a[r];
-        row_store<W>(R.o0, g.out0.dtype, n, v);
+        row_store<W>(R.o0, U.dt_o0, n, v);
     } else {
-        const int c = n - g.n_split;
+        const int c = n - U.n_split;
         if (!R.o1) return;
-        if (g.flags & AEW_EF_ACCUM) {
+        if (U.fl & AEW_EF_ACCUM) {
             float a[W];
-            row_load<W>(R.o1, g.out1.dtype, c, a);
+            row_load<W>(R.o1, U.dt_o1, c, a);
 #pragma unroll
             for (int r = 0; r < W; ++r) v[r] += a[r];
         }
-        row_store<W>(R.o1, g.out1.dtype, c, v);
-        if (g.flags & AEW_EF_OUT2_RELU) {
+        row_store<W>(R.o1, U.dt_o1, c, v);
+        if (U.fl & AEW_EF_OUT2_RELU) {
             float w[W];
 #pragma unroll
             for (int r = 0; r < W; ++r) w[r] = v[r] > 0.f ? v[r] : 0.f;
-            row_store<W>(R.o2, g.out2.dtype, c, w);
+            row_store<W>(R.o2, U.dt_o2, c, w);
         }
     }
 }
 
 template <int W>
-__device__ __forceinline__ void epi_dfg(const aew_gemm_nt_t& g, const EpiRow& R, int n, const float dz[W]) {
+__device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n, const float dz[W]) {
     float pf[W], pg[W], df[W], dg[W];
-    row_load<W>(R.a0, g.aux0.dtype, n, pf);
-    row_load<W>(R.a1, g.aux1.dtype, n, pg);
+    row_load<W>(R.a0, U.dt_a0, n, pf);
+    row_load<W>(R.a1, U.dt_a1, n, pg);
 #pragma unroll
     for (int r = 0; r < W; ++r) {
         df[r] = dz[r] * pf[r];
         dg[r] = dz[r] * pg[r];
     }
     const int np = (n >> 4) * 32 + (n & 15);           // W channels stay inside one 16-group
-    row_store<W>(R.o0, g.out0.dtype, np, df);
-    row_store<W>(R.o0, g.out0.dtype, np + 16, dg);
+    row_store<W>(R.o0, U.dt_o0, np, df);
+    row_store<W>(R.o0, U.dt_o0, np + 16, dg);
 }
 
 // =============================================================================================
@@ -162,24 +171,44 @@ struct KIter {
 };
 
 // =============================================================================================
-// NT kernel, bf16: block tile 256 (rows m) x 128 (channels n), BK = 32, 8 waves as 4(m) x 2(n),
-// each wave 64 x 64 (4x4 MFMA 16x16x32 tiles).  Operand tiles go global -> LDS by 16-byte LDS-DMA
-// into a 3-stage ring (3 x 24 KiB = 72 KiB, so TWO blocks are resident per CU and cover each
-// other's barrier / epilogue stalls); tile t+2 is issued while tile t is computed, and the wait
-// before the per-step barrier is a COUNTED vmcnt that leaves tile t+1's loads in flight
-// (cdna_hip_programming.md T3+T4).  One raw s_barrier per K step.
+// NT kernel, bf16: block tile 256 (rows m) x 128 (channels n), BK = 32.  Operand tiles go
+// global -> LDS by 16-byte LDS-DMA into a 3-stage ring (3 x 24 KiB = 72 KiB, so TWO blocks are
+// resident per CU and cover each other's barrier / epilogue stalls); tile t+2 is issued while
+// tile t is computed, and the wait before the per-step barrier is a COUNTED vmcnt that leaves
+// tile t+1's loads in flight (cdna_hip_programming.md T3+T4).  One raw s_barrier per K step.
+//
+// Two wave shapes (template MT = 16-row MFMA tiles per wave along m):
+//   MT = 8  ("fat", default): 4 waves as 2(m) x 2(n), each 128 x 64 = 8x4 MFMA 16x16x32 tiles,
+//           128 accumulator VGPRs, up to 256 VGPRs per wave (2 waves per SIMD over the two resident
+//           blocks).  12 ds_read_b128 feed 32 MFMAs per K step: LDS fragment traffic per flop is
+//           3/4 of the thin shape's, and the wide register budget lets all fragments of a step be
+//           in flight before the first MFMA (the LDS array, not the MFMA pipe, was the co-critical
+//           resource of the thin shape: 128 KiB of fragment reads + 48 KiB of DMA writes per K step
+//           and CU against ~1100 MFMA cycles).
+//   MT = 4  ("thin"): 8 waves as 4 x 2, each 64 x 64, 128 VGPRs per wave.
 // =============================================================================================
 #define NT_BM 256
 #define NT_BN 128
 #define NT_BK 32
 #define NT_ROWB 64                                  // bytes per staged row (32 bf16)
 #define NT_STAGES 3
-#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)  // 24 KiB
-#define NT_LDS_BYTES (NT_STAGES * NT_STAGE_BYTES)   // 72 KiB
-#define NT_THREADS 512
 #ifndef AEW_NT_SETPRIO
 #define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
 #endif
+
+template <int MT, int NB = 1>                           // NB = block columns / 128
+struct NtCfg {
+    static constexpr int BN = 128 * NB;
+    static constexpr int WAVES_M = NT_BM / (16 * MT);   // 4 (thin) or 2 (fat)
+    static constexpr int WAVES_N = 2 * NB;
+    static constexpr int NWAVES = WAVES_M * WAVES_N;
+    static constexpr int THREADS = 64 * NWAVES;
+    static constexpr int XP = 16 / NWAVES;              // X pieces (16 rows x 64 B) a wave stages per K tile
+    static constexpr int WP = 8 * NB / NWAVES;          // W pieces
+    static constexpr int MINW = MT == 8 ? 2 : 4;        // waves per SIMD the register budget must allow
+    static constexpr int STAGE_BYTES = (NT_BM + BN) * NT_ROWB;
+    static constexpr int LDS_BYTES = NT_STAGES * STAGE_BYTES;
+};
 
 __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, int m, int esize) {
     const int64_t row = (int64_t)m * s.row_step + s.row_off;
@@ -187,25 +216,47 @@ __device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, in
     return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
 }
 
-// Per-lane source pointers of the 2 X pieces + 1 W piece (16 rows x 64 B each) a wave stages per
-// K tile.  Computed once per segment (X) / once per kernel (W) and advanced by one K tile per
-// issue, so the K loop carries no address arithmetic beyond 64-bit adds.
+// Per-lane source pointers of the X and W pieces a wave stages per K tile.  Computed once per
+// segment (X) / once per kernel (W) and advanced by one K tile per issue, so the K loop carries no
+// address arithmetic beyond 64-bit adds.
+template <int MT, int NB = 1>
 struct NtPtrs {
-    const char* x[2];
-    const char* w;
-    int xinc[2];
+    const char* x[NtCfg<MT, NB>::XP];
+    const char* w[NtCfg<MT, NB>::WP];
+    int xinc[NtCfg<MT, NB>::XP];
+    int winc;
 };
 
+// after the last real K tile: the (uniform) loop keeps issuing, from the zero page, into stages
+// nobody reads any more
+template <int MT, int NB>
+__device__ __forceinline__ void nt_setup_idle(NtPtrs<MT, NB>& P) {
+#pragma unroll
+    for (int j = 0; j < NtCfg<MT, NB>::XP; ++j) { P.x[j] = reinterpret_cast<const char*>(aew_zero_page); P.xinc[j] = 0; }
+#pragma unroll
+    for (int j = 0; j < NtCfg<MT, NB>::WP; ++j) P.w[j] = reinterpret_cast<const char*>(aew_zero_page);
+    P.winc = 0;
+}
+
+// branch-free: the segment record is read with one batch of scalar loads, masked rows are selects
+__device__ __forceinline__ const char* seg_row_ptr_sel(const aew_seg_t& s, int b, int m, int esize, bool& ok) {
+    const int64_t row = (int64_t)m * s.row_step + s.row_off;
+    ok = row >= s.row_lo && row < s.row_hi;
+    return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
+}
+
+template <int MT, int NB>
 __device__ __forceinline__ void nt_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
-                                           NtPtrs& P) {
-    const aew_seg_t& s = g.seg[seg];
+                                           NtPtrs<MT, NB>& P) {
+    const aew_seg_t s = g.seg[seg];
     const int lr = lane >> 2, pc = lane & 3;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave * 2 + j) * 16 + lr;                      // 16 pieces of 16 rows
-        const char* src = seg_row_ptr(s, b, m0 + r, 2);
-        P.x[j] = src ? src + (nt_swz64(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
-        P.xinc[j] = src ? NT_BK * 2 : 0;
+    for (int j = 0; j < NtCfg<MT, NB>::XP; ++j) {
+        const int r = (wave * NtCfg<MT, NB>::XP + j) * 16 + lr;          // 16 pieces of 16 rows
+        bool ok;
+        const char* src = seg_row_ptr_sel(s, b, m0 + r, 2, ok) + (nt_swz64(r, pc) << 4);
+        P.x[j] = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
+        P.xinc[j] = ok ? NT_BK * 2 : 0;
     }
 }
 
@@ -223,44 +274,173 @@ __device__ __forceinline__ int nt_wperm(int rho) {
     return (i >> 1) * 32 + c;
 }
 
-template <int EPI>
-__device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int wave, int lane, NtPtrs& P) {
+template <int EPI, int MT, int NB>
+__device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int wave, int lane, NtPtrs<MT, NB>& P) {
     const int lr = lane >> 2, pc = lane & 3;
-    const int r = wave * 16 + lr;                                    // 8 pieces of 16 rows
-    const int src_row = (r & ~63) + nt_wperm<EPI>(r & 63);
-    P.w = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + src_row) * g.K_total * 2 + (nt_swz64(r, pc) << 4);
+#pragma unroll
+    for (int j = 0; j < NtCfg<MT, NB>::WP; ++j) {
+        const int r = (wave * NtCfg<MT, NB>::WP + j) * 16 + lr;          // 8 pieces of 16 rows
+        const int src_row = (r & ~63) + nt_wperm<EPI>(r & 63);
+        P.w[j] = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + src_row) * g.K_total * 2 + (nt_swz64(r, pc) << 4);
+    }
+    P.winc = NT_BK * 2;
 }
 
-__device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs& P) {
+template <int MT, int NB>
+__device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs<MT, NB>& P) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        glds16(P.x[j], stage + (wave * 2 + j) * 1024);
+    for (int j = 0; j < NtCfg<MT, NB>::XP; ++j) {
+        glds16(P.x[j], stage + (wave * NtCfg<MT, NB>::XP + j) * 1024);
         P.x[j] += P.xinc[j];
     }
-    glds16(P.w, stage + NT_BM * NT_ROWB + wave * 1024);
-    P.w += NT_BK * 2;
+#pragma unroll
+    for (int j = 0; j < NtCfg<MT, NB>::WP; ++j) {
+        glds16(P.w[j], stage + NT_BM * NT_ROWB + (wave * NtCfg<MT, NB>::WP + j) * 1024);
+        P.w[j] += P.winc;
+    }
 }
 
 struct NtIssue {                                    // walks K tiles across the segment table
-    int seg, kin, issued;
+    int seg, left, issued, slot;                    // left = K tiles still to issue from segment `seg`
 };
+
+// ---- epilogue of the bf16 NT kernels.  With the staging permutation nt_wperm, lane (fi, fg) holds
+// for row m = m0 + wm*16*MT + j*16 + fi the 8 consecutive channels base + fg*8 + {0..7}:
+// registers acc[2u][j][0..3] ++ acc[2u+1][j][0..3].
+//
+// Everything that does not depend on j is resolved ONCE per wave (EpiCtx): the descriptor lives in
+// kernarg memory, and re-deriving the five view row pointers per 16-row group cost 54 serialized
+// scalar-load round trips per wave = 25-32k cycles, 30 % of a block's lifetime (s_memtime phase
+// clock, profiles/r02_notes.md).  Row j's pointer is then base + j * (16-row stride), and the
+// biases of the lane's 8 (GATED: 8 + 8) channels are registers.
+struct EpiViewCtx {
+    char* p;                     // lane's pointer for j = 0, nullptr if the view is absent
+    int row;                     // lane's view row for j = 0
+    int64_t inc;                 // bytes per 16 GEMM rows           (wave-uniform)
+    int dstep, lo, hi;           // view rows per 16 GEMM rows, range (wave-uniform)
+};
+
+__device__ __forceinline__ EpiViewCtx epi_view_ctx(const aew_view_t& vref, int b, int m) {
+    const aew_view_t v = vref;                                // one batch of scalar loads, no branches below
+    EpiViewCtx c;
+    const int es = v.dtype == AEW_BF16 ? 2 : 4;
+    const int64_t row = (int64_t)m * v.row_step + v.row_off;
+    c.row = (int)row;
+    char* q = reinterpret_cast<char*>(v.ptr) + ((int64_t)b * v.batch_stride + row * v.row_pitch) * es;
+    c.p = v.ptr ? q : nullptr;
+    c.inc = (int64_t)16 * v.row_step * v.row_pitch * es;
+    c.dstep = 16 * v.row_step;
+    c.lo = (int)v.row_lo;
+    c.hi = (int)v.row_hi;
+    return c;
+}
+
+__device__ __forceinline__ char* epi_view_row(const EpiViewCtx& c, int j) {
+    const int row = c.row + j * c.dstep;
+    return (c.p && row >= c.lo && row < c.hi) ? c.p + j * c.inc : nullptr;
+}
+
+template <int EPI, bool ABL, int MT>
+__device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&acc)[4][MT], int b, int m0, int n0,
+                                            int wm, int wn, int lane) {
+    const int fi = lane & 15, fg = lane >> 4;
+    const int mbase = m0 + wm * (16 * MT) + fi;
+    // views each epilogue touches: GATED o0 o1 o2 | RES_SKIP o0 o1 o2 a0 | DFG o0 a0 a1 | STORE o0 o1 a0 a1
+    const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase);
+    EpiViewCtx c1 = c0, c2 = c0, ca0 = c0, ca1 = c0;
+    if (EPI != AEW_EPI_DFG) c1 = epi_view_ctx(g.out1, b, mbase);
+    if (EPI == AEW_EPI_GATED || EPI == AEW_EPI_RES_SKIP) c2 = epi_view_ctx(g.out2, b, mbase);
+    if (EPI != AEW_EPI_GATED) ca0 = epi_view_ctx(g.aux0, b, mbase);
+    if (EPI == AEW_EPI_DFG || EPI == AEW_EPI_STORE) ca1 = epi_view_ctx(g.aux1, b, mbase);
+    const EpiUni U = epi_uni(g);
+    const unsigned fl = U.fl;
+    unsigned zc = 0;
+    // ---- biases of this lane's channels
+    float bias_a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bias_b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int ch = ((n0 + wn * 64) >> 1) + 8 * fg;            // GATED: first of the lane's 8 channels
+    if (EPI == AEW_EPI_GATED) {
+        const int np_f = (ch >> 4) * 32 + (ch & 15);           // packed column of the filt half
+        const float* bp = g.bias + (int64_t)b * g.bias_bs + np_f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 bf = *reinterpret_cast<const float4*>(bp + 4 * q);
+            const float4 bg = *reinterpret_cast<const float4*>(bp + 16 + 4 * q);
+            bias_a[4 * q] = bf.x; bias_a[4 * q + 1] = bf.y; bias_a[4 * q + 2] = bf.z; bias_a[4 * q + 3] = bf.w;
+            bias_b[4 * q] = bg.x; bias_b[4 * q + 1] = bg.y; bias_b[4 * q + 2] = bg.z; bias_b[4 * q + 3] = bg.w;
+        }
+    } else if (EPI == AEW_EPI_STORE && (fl & AEW_EF_BIAS)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn * 64 + u * 32 + 8 * fg;
+            if (n < U.N) {
+                const float* bp = g.bias + (int64_t)b * g.bias_bs + n;
+                float* dst = u ? bias_b : bias_a;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bp + 4 * q);
+                    dst[4 * q] = bb.x; dst[4 * q + 1] = bb.y; dst[4 * q + 2] = bb.z; dst[4 * q + 3] = bb.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        if (mbase + j * 16 >= g.M) continue;
+        EpiRow R;
+        R.o0 = epi_view_row(c0, j);
+        R.o1 = (EPI != AEW_EPI_DFG) ? epi_view_row(c1, j) : nullptr;
+        R.o2 = (EPI == AEW_EPI_GATED || EPI == AEW_EPI_RES_SKIP) ? epi_view_row(c2, j) : nullptr;
+        R.a0 = (EPI != AEW_EPI_GATED) ? epi_view_row(ca0, j) : nullptr;
+        R.a1 = (EPI == AEW_EPI_DFG || EPI == AEW_EPI_STORE) ? epi_view_row(ca1, j) : nullptr;
+        if (EPI == AEW_EPI_GATED) {
+            // wave slab = 64 packed columns = 32 channels; tiles 0,1 filt / 2,3 gate
+            const float f[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3],
+                                acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+            const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
+                                acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+            if (ch < U.N) epi_gated<8, ABL>(g, R, ch, f, q, bias_a, bias_b);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = n0 + wn * 64 + u * 32 + 8 * fg;
+                float v[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
+                              acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
+                if (n < U.N) {
+                    if (EPI == AEW_EPI_STORE) {
+                        if (fl & AEW_EF_BIAS) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += u ? bias_b[r] : bias_a[r];
+                        }
+                        epi_store<8>(g, U, R, b, n, v, zc, fl & ~(unsigned)AEW_EF_BIAS);
+                    } else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(U, R, n, v);
+                    else epi_dfg<8>(U, R, n, v);
+                }
+            }
+        }
+    }
+    if (EPI == AEW_EPI_STORE && (fl & AEW_EF_COUNT_ZERO)) {
+        zc = (unsigned)wave_sum((float)zc);
+        if (lane == 0 && zc) atomicAdd(g.counter, (unsigned long long)zc);
+    }
+}
 
 // ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved);
 // the production instantiations (ABL = false) contain none of that code.
-template <int EPI, bool ABL = false>
-__global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+template <int EPI, bool ABL = false, int MT = 8, int NB = 1>
+__global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+    typedef NtCfg<MT, NB> Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;
+    const int wn = wave % Cfg::WAVES_N, wm = wave / Cfg::WAVES_N;
     // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (observed dispatch rule; used for
     // speed only).  All N tiles of one (batch, row-tile) are consecutive on ONE XCD, so the
     // activation tile is fetched from HBM into that XCD's L2 once and re-hit by the others.
-    const int n_mt = (g.M + NT_BM - 1) / NT_BM, n_nt = g.N_pad / NT_BN;
+    const int n_mt = (g.M + NT_BM - 1) / NT_BM, n_nt = g.N_pad / Cfg::BN;
     const int L = blockIdx.x, seq = L >> 3;
     const int rt = (seq / n_nt) * 8 + (L & 7);
     if (rt >= n_mt * g.batch) return;
     const int b = rt / n_mt;
-    const int m0 = (rt - b * n_mt) * NT_BM, n0 = (seq % n_nt) * NT_BN;
+    const int m0 = (rt - b * n_mt) * NT_BM, n0 = (seq % n_nt) * Cfg::BN;
     // RES_SKIP: skip-part tiles that lie entirely before the skip window do nothing
     if (EPI == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
         const int64_t last = (int64_t)(min(m0 + NT_BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
@@ -269,117 +449,489 @@ __global__ __launch_bounds__(NT_THREADS, 4) void k_gemm_nt_bf16(const aew_gemm_n
     const int nkt = g.K_total / NT_BK;
     const int abl = ABL ? g.reserved : 0;              // ablation switches (tools/ablate_gemm.py)
     if (abl & 32) return;                              // launch cost only
-    f32x4_t acc[4][4];
+    // abl & 1024: s_memtime phase clock -> g.counter[0..5] = cycles in {prologue, vmcnt wait, barrier,
+    // LDS fragment wait, MFMA + DMA issue, epilogue}, [6] = blocks (wave 0 of every block adds its sums)
+    const bool clk = ABL && (abl & 1024);
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clk ? __builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int k) {
+        if (!clk) return;
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tk[k] += now - t_prev;
+        t_prev = now;
+    };
+    f32x4_t acc[4][MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    NtPtrs P;
-    NtIssue is = {0, 0, 0};
-    nt_setup_w<EPI>(g, n0, wave, lane, P);
-    nt_setup_x(g, 0, b, m0, wave, lane, P);
-    auto issue_next = [&]() {
-        if (is.issued > 0 && !(abl & 128)) {
-            is.kin += NT_BK;
-            if (is.kin >= g.seg[is.seg].k_len) {      // wave-uniform: next segment
-                ++is.seg; is.kin = 0;
-                nt_setup_x(g, is.seg, b, m0, wave, lane, P);
+    NtPtrs<MT, NB> P;
+    NtIssue is = {0, g.seg[0].k_len / NT_BK, 0, 0};
+    nt_setup_w<EPI, MT, NB>(g, n0, wave, lane, P);
+    nt_setup_x<MT, NB>(g, 0, b, m0, wave, lane, P);
+    // One K tile is issued per loop step, unconditionally, so the loop body is a single basic block
+    // that the scheduler directives below can shape; `advance` runs after a tile has been issued
+    // and points P at the next one (next segment, or the zero page once K is exhausted).
+    auto advance = [&]() {
+        --is.left;
+        ++is.issued;
+        is.slot = (is.slot + 1 == NT_STAGES) ? 0 : is.slot + 1;
+        if (is.left == 0 && !(abl & 128)) {            // wave-uniform and rare: scalar loads only here
+            if (is.issued >= nkt) {
+                nt_setup_idle<MT, NB>(P);
+                is.left = 1 << 30;
+            } else {
+                ++is.seg;
+                is.left = g.seg[is.seg].k_len / NT_BK;
+                nt_setup_x<MT, NB>(g, is.seg, b, m0, wave, lane, P);
             }
         }
-        if (!(abl & 4)) nt_issue_bf16(smem + (is.issued % NT_STAGES) * NT_STAGE_BYTES, wave, P);
-        ++is.issued;
     };
     if (abl & 16) return;                              // launch + pointer setup
-    issue_next();
-    if (nkt > 1) issue_next();
+    if (!(abl & 4)) nt_issue_bf16<MT, NB>(smem, wave, P);
+    advance();
+    if (!(abl & 4)) nt_issue_bf16<MT, NB>(smem + Cfg::STAGE_BYTES, wave, P);
+    advance();
     const int fi = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (constant over the K loop)
-    int woff[4], xoff[4];
+    int woff[4], xoff[MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int rw = wn * 64 + i * 16 + fi, rx = wm * 64 + i * 16 + fi;
+        const int rw = wn * 64 + i * 16 + fi;
         woff[i] = NT_BM * NT_ROWB + rw * NT_ROWB + (nt_swz64(rw, fg) << 4);
-        xoff[i] = rx * NT_ROWB + (nt_swz64(rx, fg) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int rx = wm * (16 * MT) + j * 16 + fi;
+        xoff[j] = rx * NT_ROWB + (nt_swz64(rx, fg) << 4);
     }
     int stage = 0;
+    lap(0);
     for (int t = 0; t < nkt; ++t) {
-        // tile t has landed once at most the 3 loads of tile t+1 are outstanding
-        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile t has landed once at most the loads of tile t+1 (XP + WP per wave) are outstanding
+        if (Cfg::XP + Cfg::WP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (Cfg::XP + Cfg::WP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        lap(1);
         if (!(abl & 64)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < nkt) issue_next();                 // into the stage computed at step t-1
-        const char* st = smem + stage * NT_STAGE_BYTES;
+        lap(2);
+        const char* st = smem + stage * Cfg::STAGE_BYTES;
         stage = (stage + 1 == NT_STAGES) ? 0 : stage + 1;
         {
-            bf16x8_t wf[4], xf[4];
+            bf16x8_t wf[4], xf[MT];
             if (!(abl & 2)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j]);
+                for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff[j]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { wf[i] = __builtin_bit_cast(bf16x8_t, (s16x8_t){1, 2, 3, 4, 5, 6, 7, (short)t}); xf[i] = wf[i]; }
+                for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, (s16x8_t){1, 2, 3, 4, 5, 6, 7, (short)t});
+#pragma unroll
+                for (int j = 0; j < MT; ++j) xf[j] = wf[j & 3];
             }
+            if (clk) {                                 // force the fragment reads to complete here
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[i]));
+#pragma unroll
+                for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(xf[j]));
+                lap(3);
+            }
+            // tile t+2 goes into the stage that was computed at step t-1 (every wave is past it: barrier)
+            if (!(abl & 4)) nt_issue_bf16<MT, NB>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
             if (!(abl & 1)) {
                 if (AEW_NT_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < MT; ++j)           // j outer: X fragments are consumed in arrival order
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int i = 0; i < 4; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                 if (AEW_NT_SETPRIO) __builtin_amdgcn_s_setprio(0);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]), "v"(xf[i]));
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+                for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(xf[j]));
+            }
+            if (!ABL) {
+                // shape of the step: every fragment read in flight first, then the MFMAs with the
+                // LDS-DMA pieces of tile t+2 threaded between them (one piece per 4 MFMAs)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + MT, 0);            // DS reads
+#pragma unroll
+                for (int q = 0; q < Cfg::XP + Cfg::WP; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);             // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);             // VMEM (LDS-DMA)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 4 * (Cfg::XP + Cfg::WP), 0);
             }
         }
+        advance();
+        lap(4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the idle-tail LDS-DMA must land before the LDS is released
+    if (clk) {
+        lap(5);                                        // drain of the idle-tail DMA
+        nt_epilogue<EPI, ABL, MT>(g, acc, b, m0, n0, wm, wn, lane);
+        lap(6);                                        // epilogue instructions issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(7);                                        // stores retired
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(g.counter + k, tk[k]);
+            atomicAdd(g.counter + 8, 1ull);
+        }
+        return;
     }
     if (abl & 8) {                                     // keep the accumulators live, skip the epilogue
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- epilogue.  With the staging permutation nt_wperm, lane (fi, fg) holds for row
-    // m = m0 + wm*64 + j*16 + fi the 8 consecutive channels base + fg*8 + {0..7}:
-    // registers acc[2u][j][0..3] ++ acc[2u+1][j][0..3].
-    unsigned zc = 0;
+    nt_epilogue<EPI, ABL, MT>(g, acc, b, m0, n0, wm, wn, lane);
+}
+
+// =============================================================================================
+// Software-pipelined form of the fat-wave kernel ("pipe"): same tiles, waves, LDS ring and results
+// as k_gemm_nt_bf16<.., 8, NB>, but the K loop is hand-scheduled:
+//   * fragments are DOUBLE-BUFFERED IN REGISTERS (2 x 48 VGPRs): the 12 ds_read_b128 of tile t+1 are
+//     issued right after the step barrier and land under the 32 MFMAs of tile t, so the post-barrier
+//     burst in which every wave of the CU reads its fragments at once (96-128 KiB at 256 B/clk) no
+//     longer idles the MFMA pipe;
+//   * an LDS stage is free as soon as its tile is in registers, so the 3-stage ring carries a
+//     prefetch distance of 3 tiles (tile t+3 is issued during step t);
+//   * reads, LDS-DMA pieces and MFMAs are inline asm in exactly the order written (one DMA piece per
+//     4 MFMAs); the only waits are one counted vmcnt + lgkmcnt(0) at the top of a step.
+// K_total is a multiple of 64 (ABI), so the step count is even and the loop is unrolled by two
+// (register sets A and B swap roles).
+// =============================================================================================
+__device__ __forceinline__ bf16x8_t lds_read16(uint32_t addr, int off_is_imm_dummy = 0) {
+    bf16x8_t r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+#define AEW_DS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+#define AEW_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+template <int MT>
+__device__ __forceinline__ void nt_read_frags(uint32_t wa, uint32_t xa, bf16x8_t (&wf)[4], bf16x8_t (&xf)[MT]) {
+    static_assert(MT == 8, "fat waves only");
+    AEW_DS_READ16(wf[0], wa, 0);    AEW_DS_READ16(xf[0], xa, 0);
+    AEW_DS_READ16(wf[1], wa, 1024); AEW_DS_READ16(wf[2], wa, 2048); AEW_DS_READ16(wf[3], wa, 3072);
+    AEW_DS_READ16(xf[1], xa, 1024); AEW_DS_READ16(xf[2], xa, 2048); AEW_DS_READ16(xf[3], xa, 3072);
+    AEW_DS_READ16(xf[4], xa, 4096); AEW_DS_READ16(xf[5], xa, 5120); AEW_DS_READ16(xf[6], xa, 6144);
+    AEW_DS_READ16(xf[7], xa, 7168);
+}
+
+// all 12 fragment registers of a set are valid after this (ties the asm reads to the MFMAs below)
+__device__ __forceinline__ void nt_frags_ready(bf16x8_t (&wf)[4], bf16x8_t (&xf)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]),
+                   "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]), "+v"(xf[6]), "+v"(xf[7]));
+}
+
+template <int EPI, int NB>
+__global__ __launch_bounds__((NtCfg<8, NB>::THREADS), 2) void k_gemm_nt_bf16_pipe(const aew_gemm_nt_t g) {
+    constexpr int MT = 8;
+    typedef NtCfg<MT, NB> Cfg;
+    constexpr int PIECES = Cfg::XP + Cfg::WP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % Cfg::WAVES_N, wm = wave / Cfg::WAVES_N;
+    const int n_mt = (g.M + NT_BM - 1) / NT_BM, n_nt = g.N_pad / Cfg::BN;
+    const int L = blockIdx.x, seq = L >> 3;                  // XCD-aware order, see k_gemm_nt_bf16
+    const int rt = (seq / n_nt) * 8 + (L & 7);
+    if (rt >= n_mt * g.batch) return;
+    const int b = rt / n_mt;
+    const int m0 = (rt - b * n_mt) * NT_BM, n0 = (seq % n_nt) * Cfg::BN;
+    if (EPI == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
+        const int64_t last = (int64_t)(min(m0 + NT_BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
+        if (last < g.out1.row_lo) return;
+    }
+    const int nkt = g.K_total / NT_BK;                       // even
+    f32x4_t acc[4][MT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fi;
-        if (m >= g.M) continue;
-        const EpiRow R = epi_row(g, b, m);
-        if (EPI == AEW_EPI_GATED) {
-            // wave slab = 64 packed columns = 32 channels; tiles 0,1 filt / 2,3 gate
-            const int ch = ((n0 + wn * 64) >> 1) + 8 * fg;
-            const int np_f = (ch >> 4) * 32 + (ch & 15);
-            const float f[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3],
-                                acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
-            const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
-                                acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-            if (ch < g.N) epi_gated<8, ABL>(g, R, b, np_f, ch, f, q);
-        } else {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int n = n0 + wn * 64 + u * 32 + 8 * fg;
-                float v[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
-                              acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
-                if (n < g.N) {
-                    if (EPI == AEW_EPI_STORE) epi_store<8>(g, R, b, n, v, zc);
-                    else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(g, R, n, v);
-                    else epi_dfg<8>(g, R, n, v);
-                }
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    NtPtrs<MT, NB> P;
+    NtIssue is = {0, g.seg[0].k_len / NT_BK, 0, 0};
+    nt_setup_w<EPI, MT, NB>(g, n0, wave, lane, P);
+    nt_setup_x<MT, NB>(g, 0, b, m0, wave, lane, P);
+    auto advance = [&]() {
+        --is.left;
+        ++is.issued;
+        is.slot = (is.slot + 1 == NT_STAGES) ? 0 : is.slot + 1;
+        if (is.left == 0) {                                  // wave-uniform and rare
+            if (is.issued >= nkt) {
+                nt_setup_idle<MT, NB>(P);
+                is.left = 1 << 30;
+            } else {
+                ++is.seg;
+                is.left = g.seg[is.seg].k_len / NT_BK;
+                nt_setup_x<MT, NB>(g, is.seg, b, m0, wave, lane, P);
             }
         }
+    };
+    // prologue: tiles 0, 1, 2 in flight; tile 0 into register set A
+#pragma unroll
+    for (int q = 0; q < NT_STAGES; ++q) {
+        nt_issue_bf16<MT, NB>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
+        advance();
     }
-    if (EPI == AEW_EPI_STORE && (g.flags & AEW_EF_COUNT_ZERO)) {
-        zc = (unsigned)wave_sum((float)zc);
-        if (lane == 0 && zc) atomicAdd(g.counter, (unsigned long long)zc);
+    const int fi = lane & 15, fg = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem);
+    const int rw = wn * 64 + fi, rx = wm * (16 * MT) + fi;   // tile i / j adds i*16 rows = i*1024 bytes, same swizzle
+    const uint32_t wlane = lds0 + NT_BM * NT_ROWB + rw * NT_ROWB + (nt_swz64(rw, fg) << 4);
+    const uint32_t xlane = lds0 + rx * NT_ROWB + (nt_swz64(rx, fg) << 4);
+    bf16x8_t wA[4], xA[MT], wB[4], xB[MT];
+    if (PIECES == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    nt_read_frags<MT>(wlane, xlane, wA, xA);
+    uint32_t rd = Cfg::STAGE_BYTES;                           // byte offset of the stage holding tile t+1
+
+#define AEW_PIPE_STEP(WC, XC, WN_, XN_)                                                                    \
+    do {                                                                                                   \
+        /* tile t+1 has landed (mine): only tile t+2's pieces may still be in flight */                    \
+        if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                  \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                              \
+        nt_frags_ready(WC, XC);                               /* tile t is in registers */                 \
+        __builtin_amdgcn_s_barrier();                         /* everyone's: t+1 visible, stage of t free */ \
+        nt_read_frags<MT>(wlane + rd, xlane + rd, WN_, XN_);                                               \
+        rd = (rd + Cfg::STAGE_BYTES == NT_STAGES * Cfg::STAGE_BYTES) ? 0u : rd + Cfg::STAGE_BYTES;        \
+        char* dst = smem + is.slot * Cfg::STAGE_BYTES;        /* tile t+3 -> the stage tile t came from */ \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) AEW_MFMA_BF16(acc[i][j], WC[i], XC[j]);          \
+            if (j < Cfg::XP) {                                                                             \
+                glds16(P.x[j], dst + (wave * Cfg::XP + j) * 1024);                                         \
+                P.x[j] += P.xinc[j];                                                                       \
+            } else if (j < PIECES) {                                                                       \
+                glds16(P.w[j - Cfg::XP], dst + NT_BM * NT_ROWB + (wave * Cfg::WP + (j - Cfg::XP)) * 1024); \
+                P.w[j - Cfg::XP] += P.winc;                                                                \
+            }                                                                                              \
+        }                                                                                                  \
+        advance();                                                                                         \
+    } while (0)
+
+    for (int t = 0; t < nkt; t += 2) {
+        AEW_PIPE_STEP(wA, xA, wB, xB);
+        AEW_PIPE_STEP(wB, xB, wA, xA);
     }
+#undef AEW_PIPE_STEP
+    // drain: idle-tail DMA and the unused last fragment reads must land before LDS / registers are
+    // reused; the asm MFMAs are invisible to the compiler's hazard logic, so pad before reading acc
+    nt_frags_ready(wA, xA);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    nt_epilogue<EPI, false, MT>(g, acc, b, m0, n0, wm, wn, lane);
+}
+
+// =============================================================================================
+// "p64": the software-pipelined kernel with K tiles of 64 (LDS rows of 128 B = ONE FULL L2 LINE per
+// operand row and tile).  With 64-byte rows every 128-byte line is pulled from L2 twice, by two
+// consecutive K steps, because a step of both resident blocks stages 96 KiB of lines through a 32 KiB
+// vector L1: the staging traffic at L2 was 2x the operand bytes and L2 bandwidth, not MFMA or LDS,
+// bounded the K loop (DMA-only ablation 38-48 us vs 27 us of MFMA for a gated layer;
+// profiles/r02_notes.md).
+//   tile 256 x 256, 8 fat waves (2 x 4, each 128 x 64), one block per CU, 2 LDS stages of 64 KiB
+//   a tile = two K sub-steps of 32 (register sets A / B); reads of the next sub-step are issued
+//   before the MFMAs of the current one; ONE barrier per tile; the DMA of tile T+2 is issued under
+//   the MFMAs of sub-step T.b into the stage tile T just left.
+//   LDS row swizzle: 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7).
+// =============================================================================================
+template <int MT, int WM, int WN>
+struct P64Cfg {
+    static constexpr int BM = WM * 16 * MT, BN = WN * 64, NW = WM * WN, THREADS = 64 * NW;
+    static constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW, PIECES = XP + WP;   // 8-row pieces per wave and tile
+    static constexpr int STAGE_BYTES = (BM + BN) * 128, LDS_BYTES = 2 * STAGE_BYTES;
+    static_assert(PIECES % MT == 0 || MT % PIECES == 0, "pieces are threaded evenly between the MFMA groups");
+};
+
+template <int EPI>
+__device__ __forceinline__ int p64_wpiece_row(int p) {       // W source row offset of 8-row piece p (0..7) in a 64-row slab
+    if (EPI == AEW_EPI_GATED) return (p & 1) * 32 + (p >> 2) * 16 + ((p >> 1) & 1) * 4;
+    return (p >> 2) * 32 + (p & 1) * 16 + ((p >> 1) & 1) * 4;
+}
+
+template <int XP>
+struct P64Ptrs {
+    const char* x[XP];                                       // per-lane source of the wave's X pieces
+    const char* w;                                           // per-lane W base; piece j adds woff[j] (wave-uniform)
+};
+
+template <int XP>
+__device__ __forceinline__ void p64_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
+                                            P64Ptrs<XP>& P) {
+    const aew_seg_t s = g.seg[seg];
+    const int lr = lane >> 3, pos = lane & 7;
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+        const int r = (wave * XP + j) * 8 + lr;                      // pieces of 8 rows
+        bool ok;
+        const char* src = seg_row_ptr_sel(s, b, m0 + r, 2, ok) + ((pos ^ ((r >> 1) & 7)) << 4);
+        P.x[j] = ok ? src : reinterpret_cast<const char*>(aew_zero_region);
+    }
+}
+
+#define P64_READ4(WF, XF, WA_, XA_)                                                                         \
+    do {                                                                                                    \
+        AEW_DS_READ16(WF[0], WA_, 0);    AEW_DS_READ16(XF[0], XA_, 0);                                      \
+        AEW_DS_READ16(WF[1], WA_, 2048); AEW_DS_READ16(WF[2], WA_, 4096); AEW_DS_READ16(WF[3], WA_, 6144);  \
+        AEW_DS_READ16(XF[1], XA_, 2048); AEW_DS_READ16(XF[2], XA_, 4096); AEW_DS_READ16(XF[3], XA_, 6144);  \
+    } while (0)
+#define P64_READ8(WF, XF, WA_, XA_)                                                                         \
+    do {                                                                                                    \
+        P64_READ4(WF, XF, WA_, XA_);                                                                        \
+        AEW_DS_READ16(XF[4], XA_, 8192); AEW_DS_READ16(XF[5], XA_, 10240); AEW_DS_READ16(XF[6], XA_, 12288); \
+        AEW_DS_READ16(XF[7], XA_, 14336);                                                                   \
+    } while (0)
+
+template <int MT>
+__device__ __forceinline__ void p64_frags_ready(bf16x8_t (&wf)[4], bf16x8_t (&xf)[MT]) {
+    if constexpr (MT == 8) nt_frags_ready(wf, xf);
+    else asm volatile("s_waitcnt lgkmcnt(0)"
+                      : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
+}
+
+// MT x WM x WN:  8 x 2 x 4 = 256 x 256 tile, 8 fat waves, one block per CU (long-K ops)
+//                4 x 2 x 2 = 128 x 128 tile, 4 waves of 64 x 64, two blocks per CU (default)
+template <int EPI, int MT, int WM, int WN>
+__global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf16_p64(const aew_gemm_nt_t g) {
+    typedef P64Cfg<MT, WM, WN> Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    const int n_mt = (g.M + Cfg::BM - 1) / Cfg::BM, n_nt = g.N_pad / Cfg::BN;
+    const int L = blockIdx.x, seq = L >> 3;                  // XCD-aware order, see k_gemm_nt_bf16
+    const int rt = (seq / n_nt) * 8 + (L & 7);
+    if (rt >= n_mt * g.batch) return;
+    const int b = rt / n_mt;
+    const int m0 = (rt - b * n_mt) * Cfg::BM, n0 = (seq % n_nt) * Cfg::BN;
+    if (EPI == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
+        const int64_t last = (int64_t)(min(m0 + Cfg::BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
+        if (last < g.out1.row_lo) return;
+    }
+    const int n_tiles = g.K_total / 64;
+    f32x4_t acc[4][MT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging pointers.  W pieces of wave w: p = w + NW*j (same row parity for all, so one
+    // per-lane base serves them); piece p covers LDS rows 8p..8p+7 of the W region.
+    P64Ptrs<Cfg::XP> P;
+    int64_t woff[Cfg::WP];
+    {
+        const int lr = lane >> 3, pos = lane & 7;
+        const int lanerow = (lr >> 2) * 8 + (lr & 3);                 // lane part of nt_wperm for 8-row pieces
+        const int r0 = wave * 8 + lr;                                 // LDS row of piece j = 0 (swizzle is the same for j > 0)
+        P.w = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + lanerow) * g.K_total * 2 + ((pos ^ ((r0 >> 1) & 7)) << 4);
+#pragma unroll
+        for (int j = 0; j < Cfg::WP; ++j) {
+            const int p = wave + Cfg::NW * j;                         // slab = p >> 3, piece in slab = p & 7
+            woff[j] = (int64_t)((p >> 3) * 64 + p64_wpiece_row<EPI>(p & 7)) * g.K_total * 2;
+        }
+    }
+    static_assert(Cfg::NW % 2 == 0, "W pieces of a wave must share the row parity");
+    int seg = 0, left = g.seg[0].k_len / 64, issued = 0;
+    p64_setup_x<Cfg::XP>(g, 0, b, m0, wave, lane, P);
+    bool idle = false;
+    auto issue_piece = [&](char* stage, int j) {                     // j < XP: X piece, else W piece
+        if (j < Cfg::XP) {
+            glds16(P.x[j], stage + (wave * Cfg::XP + j) * 1024);
+            P.x[j] += 128;
+        } else {
+            const int q = j - Cfg::XP;
+            glds16(idle ? P.w : P.w + woff[q], stage + Cfg::BM * 128 + (wave + Cfg::NW * q) * 1024);
+        }
+    };
+    auto advance = [&]() {                                           // after a whole tile has been issued
+        P.w += 128;
+        --left;
+        ++issued;
+        if (left == 0) {                                             // wave-uniform and rare
+            if (issued >= n_tiles) {
+                idle = true;
+#pragma unroll
+                for (int j = 0; j < Cfg::XP; ++j) P.x[j] = reinterpret_cast<const char*>(aew_zero_region);
+                P.w = reinterpret_cast<const char*>(aew_zero_region);
+                left = 1 << 30;
+            } else {
+                ++seg;
+                left = g.seg[seg].k_len / 64;
+                p64_setup_x<Cfg::XP>(g, seg, b, m0, wave, lane, P);
+            }
+        }
+    };
+    // prologue: tiles 0 and 1 in flight
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int j = 0; j < Cfg::PIECES; ++j) issue_piece(smem + q * Cfg::STAGE_BYTES, j);
+        advance();
+    }
+    const int fi = lane & 15, fg = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem);
+    const int rw = wn * 64 + fi, rx = wm * (16 * MT) + fi;   // tile i / j adds 16 rows = 2048 bytes, same swizzle
+    // sub-step 0 reads chunk fg, sub-step 1 chunk fg + 4: (fg + 4s) ^ z = (fg ^ z) ^ 4s  ->  address ^ 64
+    const uint32_t wlane = lds0 + Cfg::BM * 128 + rw * 128 + ((fg ^ ((rw >> 1) & 7)) << 4);
+    const uint32_t xlane = lds0 + rx * 128 + ((fg ^ ((rx >> 1) & 7)) << 4);
+    bf16x8_t wA[4], xA[MT], wB[4], xB[MT];
+#define P64_READ(WF, XF, WA_, XA_)                     \
+    do {                                               \
+        if constexpr (MT == 8) P64_READ8(WF, XF, WA_, XA_); \
+        else P64_READ4(WF, XF, WA_, XA_);              \
+    } while (0)
+
+    if (Cfg::PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tile 0 (mine) landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    P64_READ(wA, xA, wlane, xlane);
+    uint32_t cur = 0;                                          // byte offset of the stage holding tile T
+    for (int T = 0; T < n_tiles; ++T) {
+        // ---- sub-step a: MFMA(T.a) from A under the reads of T.b
+        p64_frags_ready<MT>(wA, xA);
+        {
+            const uint32_t wa = (wlane + cur) ^ 64u, xa = (xlane + cur) ^ 64u;
+            P64_READ(wB, xB, wa, xa);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) AEW_MFMA_BF16(acc[i][j], wA[i], xA[j]);
+        // ---- sub-step b: tile T+1 has landed, tile T is entirely in registers -> its stage is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p64_frags_ready<MT>(wB, xB);
+        __builtin_amdgcn_s_barrier();
+        char* freed = smem + cur;
+        cur = cur ? 0u : (uint32_t)Cfg::STAGE_BYTES;
+        P64_READ(wA, xA, wlane + cur, xlane + cur);           // (T+1).a
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) AEW_MFMA_BF16(acc[i][j], wB[i], xB[j]);
+#pragma unroll
+            for (int q = 0; q < Cfg::PIECES / MT; ++q)        // tile T+2, threaded between the MFMA groups
+                issue_piece(freed, j * (Cfg::PIECES / MT) + q);
+        }
+        advance();
+    }
+#undef P64_READ
+    p64_frags_ready<MT>(wA, xA);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    nt_epilogue<EPI, false, MT>(g, acc, b, m0, n0, wm, wn, lane);
 }
 
 // =============================================================================================
@@ -405,9 +957,11 @@ __device__ __forceinline__ void nf_setup_x(const aew_gemm_nt_t& g, int seg, int 
     // 80 staged rows = 10 pieces of 8 rows: pieces 0,1 = X (waves 0,1), 2..9 = W (two per wave)
     const int lr = lane >> 3, pc = lane & 7;
     const int r = (wave & 1) * 8 + lr;
-    const char* src = seg_row_ptr(g.seg[seg], b, m0 + r, 4);
-    P.x = src ? src + (nt_swz(r, pc) << 4) : reinterpret_cast<const char*>(aew_zero_page);
-    P.xinc = src ? NF_BK * 4 : 0;
+    const aew_seg_t s = g.seg[seg];
+    bool ok;
+    const char* src = seg_row_ptr_sel(s, b, m0 + r, 4, ok) + (nt_swz(r, pc) << 4);
+    P.x = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
+    P.xinc = ok ? NF_BK * 4 : 0;
 }
 
 __device__ __forceinline__ void nf_issue(char* stage, int wave, NfPtrs& P) {
@@ -438,18 +992,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
             P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 4 + (nt_swz(r, pc) << 4);
         }
     }
-    int seg = 0, kin = 0, issued = 0;
+    int seg = 0, left = g.seg[0].k_len / NF_BK, slot = 0;      // left = K tiles still to issue from `seg`
     nf_setup_x(g, 0, b, m0, wave, lane, P);
     auto issue_next = [&]() {
-        if (issued > 0) {
-            kin += NF_BK;
-            if (kin >= g.seg[seg].k_len) {
-                ++seg; kin = 0;
-                nf_setup_x(g, seg, b, m0, wave, lane, P);
-            }
+        if (left == 0) {                                       // the only scalar loads of the K loop
+            ++seg;
+            left = g.seg[seg].k_len / NF_BK;
+            nf_setup_x(g, seg, b, m0, wave, lane, P);
         }
-        nf_issue(smem + (issued % NF_STAGES) * NF_STAGE_BYTES, wave, P);
-        ++issued;
+        nf_issue(smem + slot * NF_STAGE_BYTES, wave, P);
+        slot = (slot + 1 == NF_STAGES) ? 0 : slot + 1;
+        --left;
     };
     issue_next();
     if (nkt > 1) issue_next();
@@ -484,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
         float v[4] = {acc[0], acc[1], acc[2], acc[3]};
         if (m < g.M && n < g.N) {
             const EpiRow R = epi_row(g, b, m);
-            epi_store<4>(g, R, b, n, v, zc);
+            epi_store<4>(g, epi_uni(g), R, b, n, v, zc, g.flags);
         }
     }
     if (g.flags & AEW_EF_COUNT_ZERO) {
@@ -538,11 +1091,16 @@ __global__ void k_gemm_nt_check(const aew_gemm_nt_t g) {
     }
     unsigned zc = 0;
     const EpiRow R = epi_row(g, b, m);
-    if (g.epi == AEW_EPI_GATED) { if (ch < g.N) epi_gated<4>(g, R, b, n_f, ch, a0, a1); }
-    else if (n_f < g.N) {
-        if (g.epi == AEW_EPI_STORE) epi_store<4>(g, R, b, n_f, a0, zc);
-        else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip<4>(g, R, n_f, a0);
-        else epi_dfg<4>(g, R, n_f, a0);
+    if (g.epi == AEW_EPI_GATED) {
+        if (ch < g.N) {
+            const float* bp = g.bias + (int64_t)b * g.bias_bs + n_f;
+            const float fb[4] = {bp[0], bp[1], bp[2], bp[3]}, gb[4] = {bp[16], bp[17], bp[18], bp[19]};
+            epi_gated<4>(g, R, ch, a0, a1, fb, gb);
+        }
+    } else if (n_f < g.N) {
+        if (g.epi == AEW_EPI_STORE) epi_store<4>(g, epi_uni(g), R, b, n_f, a0, zc, g.flags);
+        else if (g.epi == AEW_EPI_RES_SKIP) epi_res_skip<4>(epi_uni(g), R, n_f, a0);
+        else epi_dfg<4>(epi_uni(g), R, n_f, a0);
     }
     if ((g.flags & AEW_EF_COUNT_ZERO) && zc) atomicAdd(g.counter, (unsigned long long)zc);
 }
@@ -575,27 +1133,29 @@ struct TnPtrs {
     int grow[NP], arow[NP], m[NP];
     int64_t ginc, ainc;
     int gstep, astep;
+    int glo, ghi, alo, ahi;      // row ranges, copied out of the descriptor once (no scalar loads per stage)
 };
 
 template <int NP, int ESIZE, int RC>
 __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& tt, int b, int r_lo, int n0,
                                          int wave, int lane, TnPtrs<NP>& P) {
-    const aew_seg_t& sa = g.seg[tt.seg];
+    const aew_seg_t sa = g.seg[tt.seg], sg = g.g;             // one batch of scalar loads
     const int lr = lane >> 4, pc = lane & 15;
     constexpr int EPC = 16 / ESIZE;
-    P.gstep = RC * g.g.row_step; P.astep = RC * sa.row_step;
-    P.ginc = (int64_t)P.gstep * g.g.row_pitch * ESIZE;
+    P.gstep = RC * sg.row_step; P.astep = RC * sa.row_step;
+    P.ginc = (int64_t)P.gstep * sg.row_pitch * ESIZE;
     P.ainc = (int64_t)P.astep * sa.row_pitch * ESIZE;
+    P.glo = (int)sg.row_lo; P.ghi = (int)sg.row_hi; P.alo = (int)sa.row_lo; P.ahi = (int)sa.row_hi;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int r = (wave * NP + j) * 4 + lr;
         const int c = ESIZE == 2 ? tn_swz_bf16(r, pc) : tn_swz_f32(r, pc);
         const int m = r_lo + r;
         P.m[j] = m;
-        P.grow[j] = m * g.g.row_step + g.g.row_off;
+        P.grow[j] = m * sg.row_step + sg.row_off;
         P.arow[j] = m * sa.row_step + sa.row_off;
-        P.g[j] = reinterpret_cast<const char*>(g.g.ptr) +
-                 ((int64_t)b * g.g.batch_stride + (int64_t)P.grow[j] * g.g.row_pitch + n0 + c * EPC) * ESIZE;
+        P.g[j] = reinterpret_cast<const char*>(sg.ptr) +
+                 ((int64_t)b * sg.batch_stride + (int64_t)P.grow[j] * sg.row_pitch + n0 + c * EPC) * ESIZE;
         P.a[j] = reinterpret_cast<const char*>(sa.ptr) +
                  ((int64_t)b * sa.batch_stride + (int64_t)P.arow[j] * sa.row_pitch + tt.kin + c * EPC) * ESIZE;
     }
@@ -604,13 +1164,12 @@ __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& t
 template <int NP, int RC>
 __device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, const TnTile& tt, char* stage, int r_end,
                                          int wave, TnPtrs<NP>& P) {
-    const aew_seg_t& sa = g.seg[tt.seg];
     const char* zp = reinterpret_cast<const char*>(aew_zero_page);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const bool in = P.m[j] < r_end;
-        const bool gok = in && P.grow[j] >= g.g.row_lo && P.grow[j] < g.g.row_hi;
-        const bool aok = in && P.arow[j] >= sa.row_lo && P.arow[j] < sa.row_hi;
+        const bool gok = in && P.grow[j] >= P.glo && P.grow[j] < P.ghi;
+        const bool aok = in && P.arow[j] >= P.alo && P.arow[j] < P.ahi;
         glds16(gok ? P.g[j] : zp, stage + (wave * NP + j) * 1024);
         glds16(aok ? P.a[j] : zp, stage + RC * 256 + (wave * NP + j) * 1024);
         P.g[j] += P.ginc; P.a[j] += P.ainc;
@@ -846,6 +1405,9 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 // host-side launchers
 // =============================================================================================
 static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
+static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kernel
+static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 128 = 4 fat waves (128x64), both on
+                                   // 256x128 tiles; 256 = 8 fat waves on 256x256 tiles where N_pad allows
 
 // kernels using more than 64 KiB of dynamic LDS must opt in once per process
 static int ensure_big_lds() {
@@ -855,11 +1417,23 @@ static int ensure_big_lds() {
 #define AEW_SET_LDS(fn, bytes)                                                                       \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
     if (e != hipSuccess) return (int)e;
-    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_STORE>, NT_LDS_BYTES)
-    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_GATED>, NT_LDS_BYTES)
-    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true>), NT_LDS_BYTES)
-    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, NT_LDS_BYTES)
-    AEW_SET_LDS(k_gemm_nt_bf16<AEW_EPI_DFG>, NT_LDS_BYTES)
+#define NT_LDS_BYTES (NtCfg<4, 1>::LDS_BYTES)
+#define AEW_SET_NT(EPI)                                                   \
+    AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), (P64Cfg<8, 2, 4>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), (P64Cfg<4, 2, 2>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 1>), (NtCfg<8, 1>::LDS_BYTES))      \
+    AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8, 2>), (NtCfg<8, 2>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4>), NT_LDS_BYTES)
+    AEW_SET_NT(AEW_EPI_STORE)
+    AEW_SET_NT(AEW_EPI_GATED)
+    AEW_SET_NT(AEW_EPI_RES_SKIP)
+    AEW_SET_NT(AEW_EPI_DFG)
+    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8>), NT_LDS_BYTES)
+    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8, 2>), (NtCfg<8, 2>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
+#undef AEW_SET_NT
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
 #undef AEW_SET_LDS
@@ -897,18 +1471,42 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     } else if (g.dtype == AEW_BF16) {
         const int rc = ensure_big_lds();
         if (rc) return rc;
-        const int row_tiles = ((g.M + NT_BM - 1) / NT_BM) * g.batch;
-        dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / NT_BN));
+        bool zspan = true;                                   // masked rows stream from aew_zero_region
+        for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
+        const bool wide = g_nt_wave_rows == 256 && g.N_pad % 256 == 0 && !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
+        const bool p64 = wide && g_nt_pipe == 2 && zspan;    // 256 x 256 tiles, K tiles of 64
+        const bool p128 = g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64 (default)
+        const int bm = p128 ? 128 : NT_BM, bn = p128 ? 128 : (wide ? 256 : NT_BN);
+        const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
+        dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
+#define AEW_NT_GO(EPI, ABL)                                                                                   \
+    do {                                                                                                      \
+        if (!ABL && p128)                                                                                      \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), grid, dim3(256), (P64Cfg<4, 2, 2>::LDS_BYTES), st, g); \
+        else if (!ABL && p64)                                                                                  \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), grid, dim3(512), (P64Cfg<8, 2, 4>::LDS_BYTES), st, g); \
+        else if (!ABL && g_nt_pipe && wide)                                                                   \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_pipe<EPI, 2>), grid, dim3((NtCfg<8, 2>::THREADS)), (NtCfg<8, 2>::LDS_BYTES), st, g); \
+        else if (!ABL && g_nt_pipe && g_nt_wave_rows == 128)                                                  \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_pipe<EPI, 1>), grid, dim3((NtCfg<8, 1>::THREADS)), (NtCfg<8, 1>::LDS_BYTES), st, g); \
+        else if (wide)                                                                                        \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 8, 2>), grid, dim3((NtCfg<8, 2>::THREADS)), (NtCfg<8, 2>::LDS_BYTES), st, g); \
+        else if (g_nt_wave_rows == 128)                                                                       \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 8>), grid, dim3(NtCfg<8>::THREADS), NT_LDS_BYTES, st, g); \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 4>), grid, dim3(NtCfg<4>::THREADS), NT_LDS_BYTES, st, g); \
+    } while (0)
         switch (g.epi) {
-            case AEW_EPI_STORE: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_STORE>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
+            case AEW_EPI_STORE: AEW_NT_GO(AEW_EPI_STORE, false); break;
             case AEW_EPI_GATED:
-                if (g.reserved) hipLaunchKernelGGL((k_gemm_nt_bf16<AEW_EPI_GATED, true>), grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g);
-                else hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_GATED>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g);
+                if (g.reserved) AEW_NT_GO(AEW_EPI_GATED, true);
+                else AEW_NT_GO(AEW_EPI_GATED, false);
                 break;
-            case AEW_EPI_RES_SKIP: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_RES_SKIP>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
-            case AEW_EPI_DFG: hipLaunchKernelGGL(k_gemm_nt_bf16<AEW_EPI_DFG>, grid, dim3(NT_THREADS), NT_LDS_BYTES, st, g); break;
+            case AEW_EPI_RES_SKIP: AEW_NT_GO(AEW_EPI_RES_SKIP, false); break;
+            case AEW_EPI_DFG: AEW_NT_GO(AEW_EPI_DFG, false); break;
             default: return AEW_E_UNSUP;
         }
+#undef AEW_NT_GO
     } else {
         dim3 grid((g.M + NF_BM - 1) / NF_BM, g.N_pad / NF_BN, g.batch);
         hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), NF_STAGES * NF_STAGE_BYTES, st, g);

@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--lanes", type=int, default=1, help="0: serial plan order (no side-lane overlap)")
+    ap.add_argument("--nt-wave-rows", dest="nt_wave_rows", type=int, default=64, help="bf16 NT shape (64|128|256)")
+    ap.add_argument("--nt-pipe", dest="nt_pipe", type=int, default=1, help="0 plain loop, 1 pipelined, 2 pipelined K=64 tiles")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
@@ -138,6 +140,8 @@ def main():
     from ae_wavenet_amd import _lib as L
     lib = L.load()
     lib.aew_set_lanes(args.lanes)
+    lib.aew_set_nt_wave_rows(args.nt_wave_rows)
+    lib.aew_set_nt_pipe(args.nt_pipe)
     hps, eng = build_engine(args, device)
     if dp is not None:
         dp.broadcast_params(eng)

@@ -359,6 +359,11 @@ int aew_graph_destroy(void* exec);
 int aew_timing_enable(int on);
 int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
 
+/* Wave shape of the bf16 NT kernel: 128 (default; 4 waves of 128x64 per 256x128 tile) or 64
+ * (8 waves of 64x64).  Same results bit for bit; tuning / A-B aid. */
+int aew_set_nt_wave_rows(int rows);
+/* 1 (default): shapes 128 / 256 run the software-pipelined kernel; 0: the plain loop. */
+int aew_set_nt_pipe(int on);
 /* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
 int aew_set_lanes(int on);
 

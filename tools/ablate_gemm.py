@@ -10,6 +10,8 @@ from ae_wavenet_amd import _lib as L
 from ae_wavenet_amd.plan import Mat, Plan, Workspace, make_nt
 
 lib = L.load()
+lib.aew_set_nt_wave_rows(int(os.environ.get('WAVE_ROWS', '64')))
+lib.aew_set_nt_pipe(int(os.environ.get('PIPE', '1')))
 dev = "cuda:0"
 B, T, Rp, Cp, Dp = 8, 7046, int(os.environ.get('RP', '384')), 128, 256
 ws = Workspace(dev)
@@ -43,3 +45,22 @@ for v in [int(x) for x in os.environ.get('ABL', '0,8,1,2,4,12,14,13,11,15').spli
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     print(f"variant {v:2d} {names.get(v, ''):18s}: {us:8.1f} us  ({flops / us / 1e6:7.1f} TFLOP/s-equivalent)")
+
+if os.environ.get('CLOCK'):
+    cnt = torch.zeros(16, dtype=torch.int64, device=dev)
+    g = make_nt(L.BF16, M, Dp, 2 * Dp, B, [x.seg(Rp), x.seg(Rp, row_off=d), cond.seg(Cp, row_off=d)], W.ptr,
+                epi=L.EPI_GATED, out0=z.view(), out1=pf.view(), out2=pg.view(), bias_ptr=bias.data_ptr(),
+                bias_bs=2 * Dp, counter_ptr=cnt.data_ptr())
+    g.reserved = 1024 | int(os.environ.get('CLOCK'))
+    p = Plan("clk")
+    p.add(L.OP_GEMM_NT, g, "g1", 1)
+    p.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c = cnt.cpu().tolist()
+    nb, steps = c[8], (2 * Rp + Cp) // 32
+    names = ["prologue", "vmcnt wait", "barrier", "LDS fragment wait", "DMA issue + MFMA issue", "drain idle DMA", "epilogue issue", "stores retire"]
+    print(f"phase clock (s_memtime ticks = 100 MHz? see total), {nb} blocks, wave 0 of each, {steps} K steps:")
+    tot = sum(c[:8])
+    for n, v in zip(names, c[:8]):
+        per = v / nb
+        print(f"   {n:26s} {per:10.0f} ticks/block  {100.0 * v / tot:5.1f} %   per K step {per / steps:8.1f}")
