@@ -1515,13 +1515,14 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
 }
 
 static int g_tn_fold_rows = 4096;                    // contractions up to this many rows fold the batch
+static int g_tn_target_blocks = 512;                 // split-K until a TN launch has about this many blocks
 
 // split heuristic: aim for >= ~2 blocks per CU
 static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* rps, int* fold) {
     const int tiles = (g.N_pad / tile) * (g.K_total / tile);
     int f = ((int64_t)g.Mc * g.batch <= g_tn_fold_rows) ? 1 : 0;   // short contractions: fold the batch loop
     int slabs_b = f ? 1 : g.batch;
-    int want = (512 + tiles * slabs_b - 1) / (tiles * slabs_b);
+    int want = (g_tn_target_blocks + tiles * slabs_b - 1) / (tiles * slabs_b);
     int max_sp = (g.Mc + 4 * rc - 1) / (4 * rc);        // keep >= 4 stages per block
     if (max_sp < 1) max_sp = 1;
     int sp = want < 1 ? 1 : (want > max_sp ? max_sp : want);

@@ -27,8 +27,18 @@ __global__ void k_copy_table(const aew_copy_table_t t) {
         const int64_t dof = i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
         if (vec) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q = 0; q < r.red_n; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(r.src) + so + q * r.red_stride);
+            const float* sp = reinterpret_cast<const float*>(r.src) + so;
+            int q = 0;
+            // 8 slab loads in flight per thread; the additions stay in slab order (deterministic)
+            for (; q + 8 <= r.red_n; q += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(sp + (int64_t)(q + k) * r.red_stride);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+            }
+            for (; q < r.red_n; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(sp + (int64_t)q * r.red_stride);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             const float a4[4] = {acc.x * r.scale, acc.y * r.scale, acc.z * r.scale, acc.w * r.scale};

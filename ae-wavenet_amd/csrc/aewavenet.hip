@@ -205,6 +205,11 @@ extern "C" int aew_timing_read(float* ms, int32_t* tags, int capacity, int* coun
 }
 
 extern "C" int aew_set_tn_safe(int on) { g_tn_safe = on ? 1 : 0; return 0; }
+extern "C" int aew_set_tn_target_blocks(int n) {
+    if (n < 1) return AEW_E_ARG;
+    g_tn_target_blocks = n;
+    return 0;
+}
 extern "C" int aew_set_nt_pipe(int mode) { g_nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_wave_rows(int rows) {
     if (rows != 0 && rows != 64 && rows != 128 && rows != 256) return AEW_E_ARG;

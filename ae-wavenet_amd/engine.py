@@ -512,9 +512,6 @@ class DecoderPlan:
                 gp, gs, gn = self._wgrad(plan, f"res{l}", BF, P_l, R, Rp, dx_next.seg(Rp, hi=P_l),
                                          [self.z[l].seg(Dp)], TAG_WG_RS)
                 pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
-            gp, gs, gn = self._wgrad(plan, f"skp{l}", BF, w, S, Sp, self.dskp.seg(Sp),
-                                     [self.z[l].seg(Dp, row_off=lg.skip_lead)], TAG_WG_RS)
-            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
             x = self.x[l]
             gp, gs, gn = self._wgrad(plan, f"fg{l}", BF, P_l, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp),
                                      [x.seg(Rp), x.seg(Rp, row_off=d), self.cond.seg(Cp, row_off=lg.cond_lead)],
@@ -544,6 +541,14 @@ class DecoderPlan:
                 aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=impl), f"dx.{l}", TAG_DX)
             dx_next = dx
         dx0 = dx_next
+        # ---- skip weights of all layers: ONE wgrad with NL segments (mirror of the deferred skip GEMM):
+        # dW_skp[s][l*Dp + k] = sum_t dskp[t][s] * z_l[t + skip_lead_l][k].  640 tiles x batch fill the
+        # chip without row splits, so it writes B slabs instead of ~128 per layer.
+        gp, gs, gn = self._wgrad(plan, "skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
+                                 [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
+        for l in range(NL):
+            pk.rec(p + f"conv_layers.{l}.dil_skp.weight", 0, [D, 1], [S, D], None, 0, [NL * Dp, 1],
+                   g_ptr=gp, slabs=gn, slab_stride=gs, g_off=l * Dp)
         # ---- base layer (wavenet.py:351)
         if ps.has(p + "base_layer.bias"):
             self._colsum(plan, dx0, T, R, ps.ptr(p + "base_layer.bias", True), label="db.base")

@@ -373,6 +373,9 @@ int aew_tn_slabs(const aew_gemm_tn_t* g);
 int aew_tn_fold(const aew_gemm_tn_t* g);
 /* Contraction length (rows x batch) up to which TN ops fold the batch; default 4096. */
 int aew_set_tn_fold_rows(int rows);
+/* Split-K target of the TN ops (blocks per launch, default 512).  Changes aew_tn_slabs(): set it
+ * before building a plan. */
+int aew_set_tn_target_blocks(int n);
 /* 1: read TN fragments with a scalar LDS gather instead of ds_read_b64_tr_b16 (debug aid). */
 int aew_set_tn_safe(int on);
 
