@@ -150,6 +150,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(AEW_GLB_PTR(gsrc), AEW_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// Same LDS-DMA as glds16 but opaque to the compiler.  Needed where the LDS tile is read back with
+// ds_read_b64_tr_b16: that builtin carries no alias information, so after a builtin LDS-DMA the
+// compiler inserts s_waitcnt vmcnt(0) in front of it, i.e. it drains the prefetch it was just given
+// (seen in the ISA of k_gemm_tn_bf16; profiles/r02_notes.md).  Callers order it by hand with counted
+// vmcnt waits + barriers.  lds_off = byte offset in LDS (wave-uniform).
+__device__ __forceinline__ void glds16_raw(const void* gsrc, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(gsrc), "s"(lds_off) : "memory", "m0");
+}
+
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- wave reductions -------------------------------------------------------------------------

@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& t
     }
 }
 
-template <int NP, int RC>
+template <int NP, int RC, bool RAW = false>
 __device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, const TnTile& tt, char* stage, int r_end,
                                          int wave, TnPtrs<NP>& P) {
     const char* zp = reinterpret_cast<const char*>(aew_zero_page);
@@ -1170,8 +1170,14 @@ __device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, const TnTile& t
         const bool in = P.m[j] < r_end;
         const bool gok = in && P.grow[j] >= P.glo && P.grow[j] < P.ghi;
         const bool aok = in && P.arow[j] >= P.alo && P.arow[j] < P.ahi;
-        glds16(gok ? P.g[j] : zp, stage + (wave * NP + j) * 1024);
-        glds16(aok ? P.a[j] : zp, stage + RC * 256 + (wave * NP + j) * 1024);
+        if (RAW) {
+            const uint32_t l0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(stage) + (wave * NP + j) * 1024;
+            glds16_raw(gok ? P.g[j] : zp, l0);
+            glds16_raw(aok ? P.a[j] : zp, l0 + RC * 256);
+        } else {
+            glds16(gok ? P.g[j] : zp, stage + (wave * NP + j) * 1024);
+            glds16(aok ? P.a[j] : zp, stage + RC * 256 + (wave * NP + j) * 1024);
+        }
         P.g[j] += P.ginc; P.a[j] += P.ainc;
         P.grow[j] += P.gstep; P.arow[j] += P.astep; P.m[j] += RC;
     }
@@ -1242,7 +1248,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
     const int total = nst * (b_hi - b_lo);
     TnPtrs<2> P;
-    int st_in_b = 0, bcur = b_lo, issued = 0;
+    int st_in_b = 0, bcur = b_lo, issued = 0, slot = 0;
     auto issue_next = [&]() {
         if (issued == 0) {
             tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
@@ -1250,7 +1256,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
             st_in_b = 0; ++bcur;
             tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
         }
-        tn_issue<2, TN_RC>(g, tt, smem + (issued % TN_STAGES) * TN_STAGE_BYTES, r_hi, wave, P);
+        tn_issue<2, TN_RC, true>(g, tt, smem + slot * TN_STAGE_BYTES, r_hi, wave, P);
+        slot = (slot + 1 == TN_STAGES) ? 0 : slot + 1;
         ++issued;
     };
     if (total > 0) issue_next();
