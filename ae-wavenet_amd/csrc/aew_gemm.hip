@@ -304,6 +304,64 @@ struct NtIssue {                                    // walks K tiles across the 
     int seg, left, issued, slot;                    // left = K tiles still to issue from segment `seg`
 };
 
+// ---- split-phase forms for the MFMA kernels: the aux operands (bf16 in these kernels) arrive as raw
+// 16-byte loads issued one row group AHEAD (nt_epilogue), so a row group's loads never sit behind the
+// previous group's stores in the in-order vmcnt queue.
+__device__ __forceinline__ void unpack8_bf16(const uint4& r, float o[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        o[2 * q] = __uint_as_float(w[q] << 16);
+        o[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ void epi_store8_pf(const EpiUni& U, const EpiRow& R, int n, float v[8], unsigned& zero_count,
+                                              unsigned fl, const uint4& a0raw, const uint4& a1raw) {
+    if (fl & AEW_EF_RELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    if (fl & AEW_EF_OUT1_PRE) row_store<8>(R.o1, U.dt_o1, n, v);
+    if (fl & AEW_EF_ADD_AUX0) {
+        float a[8];
+        unpack8_bf16(a0raw, a);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] + a[r];
+    }
+    if (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)) {
+        float a[8], w[8];
+        unpack8_bf16(a1raw, a);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = a[r] > 0.f ? v[r] : 0.f;
+        if (fl & AEW_EF_OUT1_POS1) row_store<8>(R.o1, U.dt_o1, n, w);
+        if (fl & AEW_EF_MUL_POS1) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = w[r];
+        }
+    }
+    if ((fl & AEW_EF_COUNT_ZERO) && R.o0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) zero_count += (n + r < U.N && v[r] == 0.f) ? 1u : 0u;
+    }
+    row_store<8>(R.o0, U.dt_o0, n, v);
+}
+
+__device__ __forceinline__ void epi_dfg8_pf(const EpiUni& U, const EpiRow& R, int n, const float dz[8],
+                                            const uint4& pfraw, const uint4& pgraw) {
+    float pf[8], pg[8], df[8], dg[8];
+    unpack8_bf16(pfraw, pf);
+    unpack8_bf16(pgraw, pg);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        df[r] = dz[r] * pf[r];
+        dg[r] = dz[r] * pg[r];
+    }
+    const int np = (n >> 4) * 32 + (n & 15);           // 8 channels stay inside one 16-group
+    row_store<8>(R.o0, U.dt_o0, np, df);
+    row_store<8>(R.o0, U.dt_o0, np + 16, dg);
+}
+
 // ---- epilogue of the bf16 NT kernels.  With the staging permutation nt_wperm, lane (fi, fg) holds
 // for row m = m0 + wm*16*MT + j*16 + fi the 8 consecutive channels base + fg*8 + {0..7}:
 // registers acc[2u][j][0..3] ++ acc[2u+1][j][0..3].
@@ -369,51 +427,76 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
             bias_b[4 * q] = bg.x; bias_b[4 * q + 1] = bg.y; bias_b[4 * q + 2] = bg.z; bias_b[4 * q + 3] = bg.w;
         }
     } else if (EPI == AEW_EPI_STORE && (fl & AEW_EF_BIAS)) {
+        // folded into the accumulators right away (the same fp32 add the row loop would do), so no
+        // bias registers stay live next to the prefetched aux rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int n = n0 + wn * 64 + u * 32 + 8 * fg;
             if (n < U.N) {
                 const float* bp = g.bias + (int64_t)b * g.bias_bs + n;
-                float* dst = u ? bias_b : bias_a;
+                const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bp + 4 * q);
-                    dst[4 * q] = bb.x; dst[4 * q + 1] = bb.y; dst[4 * q + 2] = bb.z; dst[4 * q + 3] = bb.w;
+                for (int j = 0; j < MT; ++j) {
+                    acc[2 * u][j][0] += b0.x; acc[2 * u][j][1] += b0.y; acc[2 * u][j][2] += b0.z; acc[2 * u][j][3] += b0.w;
+                    acc[2 * u + 1][j][0] += b1.x; acc[2 * u + 1][j][1] += b1.y; acc[2 * u + 1][j][2] += b1.z; acc[2 * u + 1][j][3] += b1.w;
                 }
             }
         }
     }
+    // aux operands (STORE: aux0 = addend, aux1 = relu-mask source; DFG: aux0 = dz/df, aux1 = dz/dg) are
+    // prefetched one (row group, channel octet) step ahead: step s = 2j + u
+    constexpr bool PF = (EPI == AEW_EPI_STORE || EPI == AEW_EPI_DFG);
+    const bool need0 = PF && (EPI == AEW_EPI_DFG || (fl & AEW_EF_ADD_AUX0));
+    const bool need1 = PF && (EPI == AEW_EPI_DFG || (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)));
+    // STORE keeps ONE prefetched operand in flight (register budget of the 128-VGPR shape): aux0 if
+    // it is used, else aux1; with both in use aux1 is loaded in step.  DFG prefetches both.
+    const bool pf1 = need1 && (EPI == AEW_EPI_DFG || !need0);
+    uint4 raw0[2 * MT], raw1[2 * MT];
+    auto aux_load = [&](int sidx) {
+        const int j = sidx >> 1, u = sidx & 1;
+        const char* z = reinterpret_cast<const char*>(aew_zero_region);
+        const int n = n0 + wn * 64 + u * 32 + 8 * fg;
+        raw0[sidx] = make_uint4(0, 0, 0, 0);
+        raw1[sidx] = make_uint4(0, 0, 0, 0);
+        if (need0) { const char* p0 = epi_view_row(ca0, j); raw0[sidx] = *reinterpret_cast<const uint4*>((p0 ? p0 : z) + n * 2); }
+        if (EPI == AEW_EPI_DFG) { const char* p1 = epi_view_row(ca1, j); raw1[sidx] = *reinterpret_cast<const uint4*>((p1 ? p1 : z) + n * 2); }
+        else if (pf1) { const char* p1 = epi_view_row(ca1, j); raw0[sidx] = *reinterpret_cast<const uint4*>((p1 ? p1 : z) + n * 2); }
+    };
+    if (PF) aux_load(0);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        if (mbase + j * 16 >= g.M) continue;
+        const bool row_ok = mbase + j * 16 < g.M;
         EpiRow R;
         R.o0 = epi_view_row(c0, j);
         R.o1 = (EPI != AEW_EPI_DFG) ? epi_view_row(c1, j) : nullptr;
         R.o2 = (EPI == AEW_EPI_GATED || EPI == AEW_EPI_RES_SKIP) ? epi_view_row(c2, j) : nullptr;
-        R.a0 = (EPI != AEW_EPI_GATED) ? epi_view_row(ca0, j) : nullptr;
-        R.a1 = (EPI == AEW_EPI_DFG || EPI == AEW_EPI_STORE) ? epi_view_row(ca1, j) : nullptr;
+        R.a0 = (EPI == AEW_EPI_RES_SKIP) ? epi_view_row(ca0, j) : nullptr;
+        R.a1 = nullptr;
         if (EPI == AEW_EPI_GATED) {
             // wave slab = 64 packed columns = 32 channels; tiles 0,1 filt / 2,3 gate
             const float f[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3],
                                 acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
             const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
                                 acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-            if (ch < U.N) epi_gated<8, ABL>(g, R, ch, f, q, bias_a, bias_b);
+            if (row_ok && ch < U.N) epi_gated<8, ABL>(g, R, ch, f, q, bias_a, bias_b);
         } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if (PF && 2 * j + u + 1 < 2 * MT) aux_load(2 * j + u + 1);
                 const int n = n0 + wn * 64 + u * 32 + 8 * fg;
                 float v[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
                               acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
-                if (n < U.N) {
+                if (row_ok && n < U.N) {
                     if (EPI == AEW_EPI_STORE) {
-                        if (fl & AEW_EF_BIAS) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] += u ? bias_b[r] : bias_a[r];
+                        uint4 a1 = raw0[2 * j + u];                       // aux1 rode in raw0 (pf1) ...
+                        if (need1 && !pf1) {                              // ... or is fetched now (both operands in use)
+                            const char* p1 = epi_view_row(ca1, j);
+                            a1 = p1 ? *reinterpret_cast<const uint4*>(p1 + n * 2) : make_uint4(0, 0, 0, 0);
                         }
-                        epi_store<8>(g, U, R, b, n, v, zc, fl & ~(unsigned)AEW_EF_BIAS);
-                    } else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(U, R, n, v);
-                    else epi_dfg<8>(U, R, n, v);
+                        epi_store8_pf(U, R, n, v, zc, fl, raw0[2 * j + u], a1);
+                    }
+                    else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(U, R, n, v);
+                    else epi_dfg8_pf(U, R, n, v, raw0[2 * j + u], raw1[2 * j + u]);
                 }
             }
         }
@@ -1470,6 +1553,9 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     if (ksum != g.K_total || g.N_pad % ntile || g.N > g.N_pad || (g.N & (g.dtype == AEW_BF16 ? 7 : 3))) return AEW_E_ARG;
     if (g.epi == AEW_EPI_RES_SKIP && (g.n_split % ntile)) return AEW_E_ARG;
     if (g.epi != AEW_EPI_STORE && g.dtype != AEW_BF16) return AEW_E_UNSUP;
+    if (g.dtype == AEW_BF16 && g.impl != 1 && (g.epi == AEW_EPI_STORE || g.epi == AEW_EPI_DFG) &&
+        ((g.aux0.ptr && g.aux0.dtype != AEW_BF16) || (g.aux1.ptr && g.aux1.dtype != AEW_BF16)))
+        return AEW_E_UNSUP;                                  // the MFMA epilogues prefetch aux rows as bf16
     if (g.impl == 1) {
         const int nq = (g.epi == AEW_EPI_GATED) ? g.N_pad / 8 : g.N_pad / 4;
         dim3 grid((nq + 63) / 64, g.M, g.batch);
