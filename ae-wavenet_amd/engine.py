@@ -381,7 +381,8 @@ class DecoderPlan:
         sb = L.SpkBias()
         self._fill_spk(sb)
         sb.bias, sb.gc = self.bias_bl.data_ptr(), self.gc.data_ptr()
-        plan.add(L.OP_SPK_BIAS, sb, "spk_bias", TAG_MISC)
+        with plan.side():                                      # independent of the conditioning path
+            plan.add(L.OP_SPK_BIAS, sb, "spk_bias", TAG_MISC)
         # 5. base layer = column gather (wavenet.py:348-351)
         bg = L.BaseGather()
         bg.wav, bg.wav_pitch, bg.wav_off = self.wav.data_ptr(), self.wav.shape[1], g.trim_dec_in[0]
@@ -392,7 +393,8 @@ class DecoderPlan:
         if need_onehot:
             bg.onehot, bg.oh_bs, bg.oh_pitch, bg.Q_pad = self.onehot.ptr, self.onehot.bs, self.onehot.pitch, Qp
         bg.ones_channel = int(self.R < Rp)
-        plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
+        with plan.side():
+            plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
         # 6. gated dilated stack (wavenet.py:91-111, 355-357)
         NL = self.NL
         for l, lg in enumerate(g.layers):
@@ -404,7 +406,7 @@ class DecoderPlan:
                 BF, P_l, Dp, 2 * Dp, B, segs, self.Wfg[l].ptr, epi=L.EPI_GATED,
                 out0=self.z[l].view(), out1=self.pf[l].view(), out2=self.pg[l].view(),
                 bias_ptr=self.bias_bl.data_ptr() + 4 * l * 2 * Dp, bias_bs=NL * 2 * Dp, impl=impl),
-                f"G1.{l}", TAG_G1)
+                f"G1.{l}", TAG_G1, join=(l == 0))             # x[0] and the gated biases come from the side lane
             if not last:
                 # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
                 plan.add(L.OP_GEMM_NT, make_nt(

@@ -65,10 +65,16 @@ class TrainEngine:
         self.in_jitter = ws.alloc("in.jitter", B * g.embed_len, torch.int64)[:B * g.embed_len].view(B, g.embed_len)
         self.loss_buf = ws.alloc("loss", 8, torch.float32)
         # ---- tables
+        # encoder / bottleneck tables stay on the main lane (their packed weights are needed at once and
+        # their gradients come last); the decoder's are side-lane work: its weight pack overlaps the
+        # (tiny-grid) encoder forward, its gradient unpack overlaps the encoder backward
         self.pack_tbl = CopyTableBuilder(ws, "tbl.pack")
         self.unpack_tbl = CopyTableBuilder(ws, "tbl.unpack")
+        self.pack_dec = CopyTableBuilder(ws, "tbl.pack_dec")
+        self.unpack_dec = CopyTableBuilder(ws, "tbl.unpack_dec")
         self.in_tbl = CopyTableBuilder(ws, "tbl.in")
         self.pk = Packer(ps, self.pack_tbl, self.unpack_tbl)
+        self.pk_dec = Packer(ps, self.pack_dec, self.unpack_dec)
         Mp = ru(self.n_mel, 64)
         self.mel_cl = Mat.new(ws, "mel_cl", B, g.mel_len, Mp, F3)
         self.in_tbl.add(self.in_mel.data_ptr(), self.mel_cl.ptr, [B, g.mel_len, self.n_mel],
@@ -82,7 +88,7 @@ class TrainEngine:
         else:
             lc_src = self.mel_cl
         self.dec = DecoderPlan(ws, ps, hps, g, B, dec_pre, hps.n_lc_in, lc_src, self.in_wav, self.in_voice,
-                               self.in_jitter, take_compat, self.pk, impl)
+                               self.in_jitter, take_compat, self.pk_dec, impl)
         self._build()
         self.adam_state = None
         self.step_count = 0
@@ -215,6 +221,8 @@ class TrainEngine:
         if bn == "vqvae-ema" and self.loss_mode == "head":
             nll_scale = 0.0
         self.dec.build_backward(bw, nll_scale)
+        with bw.side():                                        # after the decoder's last wgrad, same lane
+            self.unpack_dec.emit(bw, "unpack grads (decoder)")
         if self.enc is not None:
             dcode = self.dec.dlc_src                      # d(loss)/d(code) [B][Ne][dp]
             Ep = ru(hps.enc_n_out, 64)
@@ -254,7 +262,7 @@ class TrainEngine:
                                          out1=self.enc.dpre[9].view(), aux1=self.enc.r[9].view(), impl=impl),
                    "d.bn.linear", TAG_VQ)
             self.enc.build_backward(bw, need_input_grad=True)
-        self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads every side-lane wgrad slab
+        self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads the side-lane encoder wgrad slabs
         if bn == "vqvae-ema":
             # deferred codebook refresh (vqema_bn.py:216-222)
             self.cb = Plan("codebook")
@@ -267,6 +275,8 @@ class TrainEngine:
             self.cb.add(L.OP_VQ_EMA, em, "vq.codebook", TAG_VQ)
         # pack goes first in fwd_a (its table is complete only now)
         pk_plan = Plan("pack")
+        with pk_plan.side():                                   # joined by the end of fwd_a
+            self.pack_dec.emit(pk_plan, "pack weights (decoder)")
         self.pack_tbl.emit(pk_plan, "pack weights")
         fa.ops[pack_slot:pack_slot] = pk_plan.ops
         fa.labels[pack_slot:pack_slot] = pk_plan.labels

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Full measurement pass for profiles/: bench line (+per-op), rocprofv3 kernel stats (serial plan order,
+# --lanes 0, so that per-kernel durations are not inflated by side-lane overlap), PMC HBM traffic.
+# usage (on the GPU box): tools/measure_round.sh <tag>
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; TAG=${1:-rXX}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+cd $R
+python bench.py --steps 30 --warmup 5 --per-op $O/per_op_ms.txt > $O/bench.json 2> $O/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 0 > $O/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
+python - <<PY
+import csv, glob, collections, shutil
+O = "$O"
+st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
+if st: shutil.copy(st[0], O + "/kernel_stats.csv")
+def pmc(d, name):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != name: continue
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return acc
+fe, wr = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+with open(O + "/pmc_hbm_traffic.csv", "w") as fh:
+    fh.write("kernel,launches,fetch_MB_raw,fetch_MB_corrected_x2,write_MB\n")
+    for k in sorted(fe, key=lambda k: -fe[k][0]):
+        n = fe[k][1]
+        # FETCH_SIZE / WRITE_SIZE are in KiB-ish units of 1 KB per MI355X_MICROARCH.md; FETCH under-reports 2x on gfx950
+        f = fe[k][0] / n / 1024.0
+        w = wr[k][0] / max(wr[k][1], 1) / 1024.0 if k in wr else 0.0
+        fh.write(f"{k},{n},{f:.2f},{2*f:.2f},{w:.2f}\n")
+print(open(O + "/bench.json").read()[:600])
+PY
