@@ -99,7 +99,7 @@ def pmc_traffic():
         import csv
         n = tot = 0.0
         for r in csv.DictReader(open(path)):
-            if r["kernel"].startswith("k_gemm_nt_bf16"):
+            if "k_gemm_nt_bf16" in r["kernel"]:
                 k = float(r["launches"])
                 n += k
                 tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
