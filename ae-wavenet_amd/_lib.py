@@ -110,7 +110,7 @@ class SpkBwd(C.Structure):
 
 class BaseGather(C.Structure):
     _fields_ = [("wav", vp), ("wav_pitch", i32), ("wav_off", i32), ("W", vp), ("bias", vp),
-                ("B", i32), ("T", i32), ("R", i32), ("R_pad", i32), ("Q", i32), ("x", vp),
+                ("Wt", vp), ("B", i32), ("T", i32), ("R", i32), ("R_pad", i32), ("Q", i32), ("x", vp),
                 ("x_bs", i64), ("x_pitch", i32), ("onehot", vp), ("oh_bs", i64),
                 ("oh_pitch", i32), ("Q_pad", i32), ("ones_channel", i32)]
 
@@ -205,7 +205,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 2:
+    if lib.aew_abi_version() != 3:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

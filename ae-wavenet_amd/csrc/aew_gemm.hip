@@ -535,10 +535,11 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
     // abl & 1024: s_memtime phase clock -> g.counter[0..5] = cycles in {prologue, vmcnt wait, barrier,
     // LDS fragment wait, MFMA + DMA issue, epilogue}, [6] = blocks (wave 0 of every block adds its sums)
     const bool clk = ABL && (abl & 1024);
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clk ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // SGPR-resident (wave-uniform) 32-bit cycle sums
+    unsigned t_prev = clk ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
     auto lap = [&](int k) {
         if (!clk) return;
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
         tk[k] += now - t_prev;
         t_prev = now;
     };
@@ -661,7 +662,7 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
         lap(7);                                        // stores retired
         if (tid == 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(g.counter + k, tk[k]);
+            for (int k = 0; k < 8; ++k) atomicAdd(g.counter + k, (unsigned long long)tk[k]);
             atomicAdd(g.counter + 8, 1ull);
         }
         return;
@@ -1217,11 +1218,12 @@ struct TnPtrs {
     int64_t ginc, ainc;
     int gstep, astep;
     int glo, ghi, alo, ahi;      // row ranges, copied out of the descriptor once (no scalar loads per stage)
+    bool fast;                   // wave-uniform: every row this wave will stage (all stages) is valid
 };
 
 template <int NP, int ESIZE, int RC>
 __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& tt, int b, int r_lo, int n0,
-                                         int wave, int lane, TnPtrs<NP>& P) {
+                                         int wave, int lane, TnPtrs<NP>& P, int nst = 0, int r_end = 0) {
     const aew_seg_t sa = g.seg[tt.seg], sg = g.g;             // one batch of scalar loads
     const int lr = lane >> 4, pc = lane & 15;
     constexpr int EPC = 16 / ESIZE;
@@ -1242,11 +1244,31 @@ __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& t
         P.a[j] = reinterpret_cast<const char*>(sa.ptr) +
                  ((int64_t)b * sa.batch_stride + (int64_t)P.arow[j] * sa.row_pitch + tt.kin + c * EPC) * ESIZE;
     }
+    // interior blocks (the common case) skip the per-row range checks of every stage
+    bool ok = nst > 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int last = nst - 1;
+        const int g0 = P.grow[j], g1 = g0 + last * P.gstep, a0 = P.arow[j], a1 = a0 + last * P.astep;
+        ok = ok && (P.m[j] + last * RC < r_end) && min(g0, g1) >= P.glo && max(g0, g1) < P.ghi &&
+             min(a0, a1) >= P.alo && max(a0, a1) < P.ahi;
+    }
+    P.fast = __all(ok);
 }
 
 template <int NP, int RC, bool RAW = false>
 __device__ __forceinline__ void tn_issue(const aew_gemm_tn_t& g, const TnTile& tt, char* stage, int r_end,
                                          int wave, TnPtrs<NP>& P) {
+    if (RAW && P.fast) {
+        const uint32_t l0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(stage) + wave * NP * 1024;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            glds16_raw(P.g[j], l0 + j * 1024);
+            glds16_raw(P.a[j], l0 + j * 1024 + RC * 256);
+            P.g[j] += P.ginc; P.a[j] += P.ainc;
+        }
+        return;
+    }
     const char* zp = reinterpret_cast<const char*>(aew_zero_page);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -1334,10 +1356,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     int st_in_b = 0, bcur = b_lo, issued = 0, slot = 0;
     auto issue_next = [&]() {
         if (issued == 0) {
-            tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+            tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P, nst, r_hi);
         } else if (++st_in_b == nst) {                 // wave-uniform: next batch element
             st_in_b = 0; ++bcur;
-            tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P);
+            tn_setup<2, 2, TN_RC>(g, tt, bcur, r_lo, n0, wave, lane, P, nst, r_hi);
         }
         tn_issue<2, TN_RC, true>(g, tt, smem + slot * TN_STAGE_BYTES, r_hi, wave, P);
         slot = (slot + 1 == TN_STAGES) ? 0 : slot + 1;

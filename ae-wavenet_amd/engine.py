@@ -270,6 +270,9 @@ class DecoderPlan:
         Kfg = 2 * Rp + Cp
         self.VfgT = self._wmat("VfgT", Cp, NL * 2 * Dp)
         self.Wskp = self._wmat("skp_all", Sp, NL * Dp)
+        # base layer as a row gather: transposed fp32 copy [Q][Rp] (wavenet.py:348-351)
+        self.Wbase_t = self._wmat("base_t", Q, Rp, F3)
+        pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], self.Wbase_t, 0, [1, Rp])
         for l in range(NL):
             last = l == NL - 1
             q = p + f"conv_layers.{l}."
@@ -387,6 +390,7 @@ class DecoderPlan:
         bg = L.BaseGather()
         bg.wav, bg.wav_pitch, bg.wav_off = self.wav.data_ptr(), self.wav.shape[1], g.trim_dec_in[0]
         bg.W = self.ps.ptr(p + "base_layer.weight")
+        bg.Wt = self.Wbase_t.ptr
         bg.bias = self.ps.ptr(p + "base_layer.bias") if self.ps.has(p + "base_layer.bias") else None
         bg.B, bg.T, bg.R, bg.R_pad, bg.Q = B, self.T, self.R, Rp, self.Q
         bg.x, bg.x_bs, bg.x_pitch = self.x[0].ptr, self.x[0].bs, self.x[0].pitch

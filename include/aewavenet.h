@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 2
+#define AEW_ABI_VERSION 3
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -240,6 +240,8 @@ typedef struct {                 /* backward of the above from per-batch column 
 typedef struct {                 /* base layer as a column gather (wavenet.py:348-351)        */
     const float* wav; int32_t wav_pitch; int32_t wav_off;   /* [B][n_wav] float-encoded ints  */
     const float* W; const float* bias;                      /* [R][Q] (k=1), [R] or NULL      */
+    const float* Wt;             /* optional transposed copy [Q][R_pad] (pad columns zero): a row of x
+                                    is then ONE contiguous read instead of R strided ones            */
     int32_t B, T, R, R_pad, Q;
     uint16_t* x; int64_t x_bs; int32_t x_pitch;             /* bf16 [B][T][R_pad]             */
     uint16_t* onehot; int64_t oh_bs; int32_t oh_pitch;      /* optional bf16 [B][T][Q_pad]    */
