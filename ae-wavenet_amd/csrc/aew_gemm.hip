@@ -835,7 +835,6 @@ struct P64Cfg {
     static constexpr int BM = WM * 16 * MT, BN = WN * 64, NW = WM * WN, THREADS = 64 * NW;
     static constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW, PIECES = XP + WP;   // 8-row pieces per wave and tile
     static constexpr int STAGE_BYTES = (BM + BN) * 128, LDS_BYTES = 2 * STAGE_BYTES;
-    static_assert(PIECES % MT == 0 || MT % PIECES == 0, "pieces are threaded evenly between the MFMA groups");
 };
 
 template <int EPI>
@@ -885,7 +884,8 @@ __device__ __forceinline__ void p64_frags_ready(bf16x8_t (&wf)[4], bf16x8_t (&xf
 }
 
 // MT x WM x WN:  8 x 2 x 4 = 256 x 256 tile, 8 fat waves, one block per CU (long-K ops)
-//                4 x 2 x 2 = 128 x 128 tile, 4 waves of 64 x 64, two blocks per CU (default)
+//                4 x 2 x 2 = 128 x 128 tile, 4 waves of 64 x 64, two blocks per CU
+//                4 x 4 x 2 = 256 x 128 tile, 8 waves of 64 x 64, one block per CU (96 KiB)
 template <int EPI, int MT, int WM, int WN>
 __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf16_p64(const aew_gemm_nt_t g) {
     typedef P64Cfg<MT, WM, WN> Cfg;
@@ -976,6 +976,7 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
     } while (0)
 
     if (Cfg::PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tile 0 (mine) landed
+    else if (Cfg::PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     P64_READ(wA, xA, wlane, xlane);
@@ -1003,8 +1004,8 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
 #pragma unroll
             for (int i = 0; i < 4; ++i) AEW_MFMA_BF16(acc[i][j], wB[i], xB[j]);
 #pragma unroll
-            for (int q = 0; q < Cfg::PIECES / MT; ++q)        // tile T+2, threaded between the MFMA groups
-                issue_piece(freed, j * (Cfg::PIECES / MT) + q);
+            for (int q = j * Cfg::PIECES / MT; q < (j + 1) * Cfg::PIECES / MT; ++q)   // tile T+2, threaded
+                issue_piece(freed, q);                                                 // between the MFMA groups
         }
         advance();
     }
@@ -1533,6 +1534,7 @@ static int ensure_big_lds() {
 #define AEW_SET_NT(EPI)                                                   \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), (P64Cfg<8, 2, 4>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), (P64Cfg<4, 2, 2>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 4, 2>), (P64Cfg<4, 4, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 1>), (NtCfg<8, 1>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
@@ -1590,13 +1592,16 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
         const bool wide = g_nt_wave_rows == 256 && g.N_pad % 256 == 0 && !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
         const bool p64 = wide && g_nt_pipe == 2 && zspan;    // 256 x 256 tiles, K tiles of 64
-        const bool p128 = g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64 (default)
+        const bool p128 = g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64
+        const bool p256 = g_nt_wave_rows == 1 && zspan;      // 256 x 128 tiles, K tiles of 64, one block per CU
         const int bm = p128 ? 128 : NT_BM, bn = p128 ? 128 : (wide ? 256 : NT_BN);
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
 #define AEW_NT_GO(EPI, ABL)                                                                                   \
     do {                                                                                                      \
-        if (!ABL && p128)                                                                                      \
+        if (!ABL && p256)                                                                                      \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 4, 2>), grid, dim3(512), (P64Cfg<4, 4, 2>::LDS_BYTES), st, g); \
+        else if (!ABL && p128)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), grid, dim3(256), (P64Cfg<4, 2, 2>::LDS_BYTES), st, g); \
         else if (!ABL && p64)                                                                                  \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), grid, dim3(512), (P64Cfg<8, 2, 4>::LDS_BYTES), st, g); \

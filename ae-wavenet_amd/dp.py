@@ -48,6 +48,29 @@ class DataParallel:
         for s in range(0, n, self.bucket_elems):
             dist.all_reduce(flat[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group)
 
+    def backward_allreduce(self, eng):
+        """Backward with the gradient exchange overlapped.  The flat gradient buffer is
+        [encoder | bottleneck | decoder]; the decoder part (~40 % of the bytes at arch.vqvae-ema) is final
+        once the decoder backward and its unpack are done, so its all-reduce is issued there
+        (async, on the collective's own stream) and runs under the bottleneck / encoder backward.
+        The head of the buffer follows when the backward is complete.  Numerically identical to
+        backward() + allreduce_grads()."""
+        if self.world == 1:
+            eng.backward()
+            return
+        n, lo = eng.ps.numel, eng.dec_grad_offset
+        flat = eng.ps.grads
+        work = []
+
+        def after_decoder():
+            work.append(dist.all_reduce(flat[lo:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        eng.backward(after_decoder=after_decoder)
+        if lo > 0:
+            work.append(dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in work:
+            w.wait()
+
     def allreduce_ema(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
         if self.world == 1:
             return

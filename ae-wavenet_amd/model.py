@@ -263,6 +263,17 @@ class TrainEngine:
                    "d.bn.linear", TAG_VQ)
             self.enc.build_backward(bw, need_input_grad=True)
         self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads the side-lane encoder wgrad slabs
+        # The same ops as two plans, cut after the decoder's gradients are final: lets a data-parallel
+        # caller start reducing the decoder gradients (the contiguous tail of the flat buffer) while the
+        # bottleneck / encoder backward still runs (dp.DataParallel.backward_allreduce)
+        cut = bw.labels.index("unpack grads (decoder)") + 1 if "unpack grads (decoder)" in bw.labels else len(bw.ops)
+        self.bwd_a, self.bwd_b = Plan("bwd_a"), Plan("bwd_b")
+        self.bwd_a.ops, self.bwd_a.labels = bw.ops[:cut], bw.labels[:cut]
+        self.bwd_b.ops, self.bwd_b.labels = bw.ops[cut:], bw.labels[cut:]
+        dec_names = [n for n in ps.names() if n.startswith(self.dec.pre)]
+        self.dec_grad_offset = min(ps.off[n] for n in dec_names)
+        assert all(ps.off[n] >= self.dec_grad_offset for n in dec_names) and \
+            all(ps.off[n] < self.dec_grad_offset for n in ps.names() if n not in dec_names), "decoder params form the tail"
         if bn == "vqvae-ema":
             # deferred codebook refresh (vqema_bn.py:216-222)
             self.cb = Plan("codebook")
@@ -345,6 +356,8 @@ class TrainEngine:
         self.bwd.array()[self._vae_bwd_index].u.vae.kl_coef = float(a)
         self.fwd_b.invalidate_graph()
         self.bwd.invalidate_graph()
+        self.bwd_a.invalidate_graph()
+        self.bwd_b.invalidate_graph()
 
     def _run(self, plan, timing=False):
         if self.use_graphs and not timing:
@@ -360,8 +373,17 @@ class TrainEngine:
         self._run(self.fwd_b, timing)
         return self.loss_buf[0]
 
-    def backward(self, timing=False):
-        self._run(self.bwd, timing)
+    def backward(self, timing=False, after_decoder=None):
+        """after_decoder: optional callback invoked between the decoder part of the backward (all
+        decoder gradients final in ps.grads[dec_grad_offset:]) and the bottleneck / encoder part."""
+        if after_decoder is None or not self.bwd_b.ops:
+            self._run(self.bwd, timing)
+            if after_decoder is not None:
+                after_decoder()
+        else:
+            self._run(self.bwd_a, timing)
+            after_decoder()
+            self._run(self.bwd_b, timing)
         if self.bn_type == "vqvae-ema" and self.update_codebook_every_step:
             self._run(self.cb, timing)
 

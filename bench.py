@@ -156,9 +156,10 @@ def main():
 
     def step():
         eng.forward(ema_ar)
-        eng.backward()
         if dp is not None:
-            dp.allreduce_grads(eng)
+            dp.backward_allreduce(eng)          # decoder gradients reduced under the encoder backward
+        else:
+            eng.backward()
         eng.adam_step(args.lr, gscale)
 
     def fence():

@@ -38,11 +38,32 @@ def _worker(rank, world, port, q):
         p_sum = eng.ps.params[:n].sum().item()
         eng.ps.grads[:n].copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
         d.allreduce_grads(eng)
+        g_bucketed = eng.ps.grads[:n].tolist()
+        # overlapped exchange: the engine's backward is replaced by one that writes the two halves of the
+        # gradient buffer at the two points the real plans would (decoder tail first, then the head)
+        lo = eng.dec_grad_offset
+        assert 0 < lo < n and eng.bwd_a.ops and eng.bwd_b.ops
+        assert len(eng.bwd_a.ops) + len(eng.bwd_b.ops) == len(eng.bwd.ops)
+        order = []
+
+        def fake_backward(timing=False, after_decoder=None):
+            eng.ps.grads[:n].zero_()
+            eng.ps.grads[lo:n].copy_(torch.arange(lo, n, dtype=torch.float32) * (rank + 1))
+            order.append("dec")
+            after_decoder()
+            order.append("hook")
+            eng.ps.grads[:lo].copy_(torch.arange(lo, dtype=torch.float32) * (rank + 1))
+            order.append("enc")
+
+        eng.backward = fake_backward
+        d.backward_allreduce(eng)
+        assert order == ["dec", "hook", "enc"]
+        g_overlap = eng.ps.grads[:n].tolist()
         eng.z_sum.fill_(rank + 1.0)
         eng.n_sum.fill_(2.0 * (rank + 1))
         d.allreduce_ema(eng.z_sum, eng.n_sum)
-        q.put((rank, p_sum, eng.ps.grads[:n].tolist(), eng.z_sum[0, 0].item(), eng.n_sum[0].item(),
-               eng.emb.sum().item(), d.grad_scale(True), d.grad_scale(False)))
+        q.put((rank, p_sum, g_overlap, eng.z_sum[0, 0].item(), eng.n_sum[0].item(),
+               eng.emb.sum().item(), d.grad_scale(True), d.grad_scale(False), g_bucketed))
     finally:
         dist.destroy_process_group()
 
@@ -59,7 +80,8 @@ def test_dp_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, ps0, g0, z0, n0, e0, gm0, gs0), (r1, ps1, g1, z1, n1, e1, gm1, gs1) = res
+    (r0, ps0, g0, z0, n0, e0, gm0, gs0, gb0), (r1, ps1, g1, z1, n1, e1, gm1, gs1, gb1) = res
+    assert gb0 == gb1 == g0                               # bucketed and overlapped exchange agree
     assert ps0 == ps1 and e0 == e1                       # broadcast made the replicas identical
     assert g0 == g1 and g0 == [3.0 * i for i in range(len(g0))]      # SUM over ranks, every bucket
     assert z0 == z1 == 3.0 and n0 == n1 == 6.0            # EMA statistics summed over ranks

@@ -125,7 +125,7 @@ def test_gemm_nt(dtype, epi):
     try:
         # impl 0 under every tile / wave shape of the bf16 kernel (64: 8 waves of 64x64, 128: 4 waves of
         # 128x64, 256: 256x256 tiles where N_pad allows); the shapes must agree bit for bit
-        for impl, shape, pipe in ((0, 64, 1), (1, 64, 1), (0, 0, 1), (0, 128, 1), (0, 128, 0), (0, 256, 0), (0, 256, 1), (0, 256, 2)):
+        for impl, shape, pipe in ((0, 64, 1), (1, 64, 1), (0, 0, 1), (0, 1, 1), (0, 128, 1), (0, 128, 0), (0, 256, 0), (0, 256, 1), (0, 256, 2)):
             lib.aew_set_nt_wave_rows(shape)
             lib.aew_set_nt_pipe(pipe)
             ws_g = _mirror(ws_c, DEV)
@@ -620,6 +620,18 @@ def test_two_lane_schedule_is_bit_identical_to_serial():
         recapture()
         for _ in range(4):
             same(*step(), l_ref, g_ref)
+        # the split form used by the overlapped all-reduce (decoder part | hook | encoder part)
+        calls = []
+
+        def step_split():
+            eng.init_ema_from_emb()
+            loss = float(eng.forward())
+            eng.backward(after_decoder=lambda: calls.append(1))
+            torch.cuda.synchronize()
+            return loss, eng.ps.grads[:eng.ps.numel].clone()
+
+        same(*step_split(), l_ref, g_ref)
+        assert calls == [1]
         eng.use_graphs = False                      # eager: two real streams + events
         for _ in range(2):
             same(*step(), l_ref, g_ref)
