@@ -74,6 +74,13 @@ class DataParallel:
     def allreduce_ema(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
         if self.world == 1:
             return
+        # the engine allocates n_sum right behind z_sum: one collective instead of two
+        if z_sum.is_contiguous() and n_sum.is_contiguous() and \
+                n_sum.data_ptr() == z_sum.data_ptr() + z_sum.numel() * z_sum.element_size() and \
+                z_sum.untyped_storage().data_ptr() == n_sum.untyped_storage().data_ptr():
+            both = torch.as_strided(z_sum, (z_sum.numel() + n_sum.numel(),), (1,))
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
+            return
         dist.all_reduce(z_sum, op=dist.ReduceOp.SUM, group=self.group)
         dist.all_reduce(n_sum, op=dist.ReduceOp.SUM, group=self.group)
 

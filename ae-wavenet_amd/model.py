@@ -119,8 +119,10 @@ class TrainEngine:
                 self.emb = ws.alloc("bn.emb", K * d, torch.float32)[:K * d].view(K, d)
                 self.ema_numer = ws.alloc("bn.ema_numer", K * d, torch.float32)[:K * d].view(K, d)
                 self.ema_denom = ws.alloc("bn.ema_denom", K, torch.float32)[:K]
-                self.z_sum = ws.alloc("bn.z_sum", K * d, torch.float32)[:K * d].view(K, d)
-                self.n_sum = ws.alloc("bn.n_sum", K, torch.float32)[:K]
+                # one buffer so that the data-parallel exchange of the EMA statistics is ONE all-reduce
+                self.zn_sum = ws.alloc("bn.zn_sum", K * d + K, torch.float32)[:K * d + K]
+                self.z_sum = self.zn_sum[:K * d].view(K, d)
+                self.n_sum = self.zn_sum[K * d:]
                 self.ind_hist = ws.alloc("bn.ind_hist", K, torch.float32)[:K]
             else:
                 self.emb = self.ps.view("bottleneck.emb")
