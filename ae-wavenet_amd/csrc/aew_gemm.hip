@@ -1636,13 +1636,18 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
 
 static int g_tn_fold_rows = 4096;                    // contractions up to this many rows fold the batch
 static int g_tn_target_blocks = 512;                 // split-K until a TN launch has about this many blocks
+static int g_tn_small_tiles = 8, g_tn_small_target = 128;   // outputs of <= small_tiles tiles split to small_target blocks
 
 // split heuristic: aim for >= ~2 blocks per CU
 static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* rps, int* fold) {
     const int tiles = (g.N_pad / tile) * (g.K_total / tile);
     int f = ((int64_t)g.Mc * g.batch <= g_tn_fold_rows) ? 1 : 0;   // short contractions: fold the batch loop
     int slabs_b = f ? 1 : g.batch;
-    int want = (g_tn_target_blocks + tiles * slabs_b - 1) / (tiles * slabs_b);
+    // small outputs (a handful of tiles) would need ~100 row splits to fill the chip on their own, and
+    // every split is a slab that is written here and read again by the unpack; they run on the side lane
+    // next to chip-filling kernels, so they are split much less
+    const int target = (tiles <= g_tn_small_tiles) ? g_tn_small_target : g_tn_target_blocks;
+    int want = (target + tiles * slabs_b - 1) / (tiles * slabs_b);
     int max_sp = (g.Mc + 4 * rc - 1) / (4 * rc);        // keep >= 4 stages per block
     if (max_sp < 1) max_sp = 1;
     int sp = want < 1 ? 1 : (want > max_sp ? max_sp : want);

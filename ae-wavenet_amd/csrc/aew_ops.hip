@@ -9,22 +9,49 @@ __global__ void k_copy_table(const aew_copy_table_t t) {
     const aew_copy_rec_t r = t.recs[rec_i];
     // vector form: 4 consecutive elements of the last dim per thread when the fp32 source is
     // contiguous there (the gradient-unpack records: float4 loads over every slab)
-    const bool vec = r.src_dtype == AEW_F32 && r.ss[3] == 1 && (r.dims[3] & 3) == 0 &&
+    // destination-vector form: fp32 -> bf16 pack records whose LAST dim is contiguous in the destination:
+    // 8 (strided) fp32 loads, one 16-byte bf16 store (the element-wise form issued 2-byte scattered stores)
+    const bool vecd = r.src_dtype == AEW_F32 && r.dst_dtype == AEW_BF16 && r.red_n == 1 && r.ds[3] == 1 &&
+                      (r.dims[3] & 7) == 0 &&
+                      (((uintptr_t)r.dst | (uintptr_t)(r.ds[2] * 2) | (uintptr_t)(r.ds[1] * 2) | (uintptr_t)(r.ds[0] * 2)) & 15) == 0;
+    // same idea for fp32 -> fp32 permuting copies (encoder weight pack): 4 strided loads, one float4 store
+    const bool vecf = r.src_dtype == AEW_F32 && r.dst_dtype == AEW_F32 && r.red_n == 1 && !r.accumulate &&
+                      r.ds[3] == 1 && r.ss[3] != 1 && (r.dims[3] & 3) == 0 &&
+                      (((uintptr_t)r.dst | (uintptr_t)(r.ds[2] * 4) | (uintptr_t)(r.ds[1] * 4) | (uintptr_t)(r.ds[0] * 4)) & 15) == 0;
+    const bool vec = !vecd && !vecf && r.src_dtype == AEW_F32 && r.ss[3] == 1 && (r.dims[3] & 3) == 0 &&
                      (((uintptr_t)r.src | (uintptr_t)(r.ss[2] * 4) | (uintptr_t)(r.ss[1] * 4) |
                        (uintptr_t)(r.ss[0] * 4) | (uintptr_t)(r.red_stride * 4)) & 15) == 0;
-    const int d3 = vec ? r.dims[3] >> 2 : r.dims[3];
+    const int d3 = (vec || vecf) ? r.dims[3] >> 2 : (vecd ? r.dims[3] >> 3 : r.dims[3]);
     const int64_t total = (int64_t)r.dims[0] * r.dims[1] * r.dims[2] * d3;
-    const int64_t base = (int64_t)(blockIdx.x - r.first_block) * 1024;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    // the host sizes the grid as ceil(elements / 1024) blocks per record; the vector forms cover >= 4
+    // elements per thread, so they take ONE item per thread (4x the threads in flight for the slab loads of
+    // the unpack records) and the scalar form four
+    const int per_thread = (vec || vecf || vecd) ? 1 : 4;
+    const int64_t base = (int64_t)(blockIdx.x - r.first_block) * (256 * per_thread);
+    for (int u = 0; u < per_thread; ++u) {
         int64_t e = base + u * 256 + threadIdx.x;
         if (e >= total) return;
-        const int i3 = (int)(e % d3) * (vec ? 4 : 1); e /= d3;
+        const int i3 = (int)(e % d3) * ((vec || vecf) ? 4 : (vecd ? 8 : 1)); e /= d3;
         const int i2 = (int)(e % r.dims[2]); e /= r.dims[2];
         const int i1 = (int)(e % r.dims[1]); e /= r.dims[1];
         const int i0 = (int)e;
         const int64_t so = i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3];
         const int64_t dof = i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
+        if (vecf) {
+            const float* sp = reinterpret_cast<const float*>(r.src) + so;
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(r.dst) + dof) =
+                make_float4(sp[0] * r.scale, sp[r.ss[3]] * r.scale, sp[2 * r.ss[3]] * r.scale, sp[3 * r.ss[3]] * r.scale);
+            continue;
+        }
+        if (vecd) {
+            const float* sp = reinterpret_cast<const float*>(r.src) + so;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sp[k * r.ss[3]] * r.scale;
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(r.dst) + dof) =
+                make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+            continue;
+        }
         if (vec) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             const float* sp = reinterpret_cast<const float*>(r.src) + so;

@@ -245,6 +245,18 @@ class CopyTableBuilder:
         # thread index runs fastest over the LAST dim: order dims so that it is the one with the
         # smallest source stride (coalesced reads; the read side carries the slab reduction)
         order = sorted(range(4), key=lambda i: (0, 0) if dims[i] == 1 else (1, -abs(ss[i])))
+        if src_dtype == L.F32 and dst_dtype == L.F32 and red_n == 1 and not accumulate:
+            # permuting fp32 copies (encoder weight pack): destination-contiguous dim last unless the
+            # source-contiguous one already is (then the float4-load form applies)
+            cand = [i for i in range(4) if ds[i] == 1 and dims[i] % 4 == 0 and dims[i] > 1]
+            if cand and ds[order[-1]] != 1:
+                order = [i for i in order if i != cand[0]] + [cand[0]]
+        if src_dtype == L.F32 and dst_dtype == L.BF16 and red_n == 1:
+            # fp32 -> bf16 packs: the kernel's destination-vector form wants the dim that is contiguous in
+            # the DESTINATION last (8 strided loads, one 16-byte store)
+            cand = [i for i in range(4) if ds[i] == 1 and dims[i] % 8 == 0 and dims[i] > 1]
+            if cand and ds[order[-1]] != 1:
+                order = [i for i in order if i != cand[0]] + [cand[0]]
         dims, ss, ds = [dims[i] for i in order], [ss[i] for i in order], [ds[i] for i in order]
         r = L.CopyRec()
         r.src, r.dst = src_ptr, dst_ptr

@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--nt-wave-rows", dest="nt_wave_rows", type=int, default=64, help="bf16 NT shape (64|128|256)")
     ap.add_argument("--nt-pipe", dest="nt_pipe", type=int, default=1, help="0 plain loop, 1 pipelined, 2 pipelined K=64 tiles")
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")
+    ap.add_argument("--tn-small", dest="tn_small", default="", help="max_tiles,target_blocks for small-output TN ops")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
@@ -145,6 +146,9 @@ def main():
     lib.aew_set_nt_pipe(args.nt_pipe)
     if args.tn_blocks:
         lib.aew_set_tn_target_blocks(args.tn_blocks)
+    if args.tn_small:
+        a, b = (int(v) for v in args.tn_small.split(","))
+        lib.aew_set_tn_small(a, b)
     hps, eng = build_engine(args, device)
     if dp is not None:
         dp.broadcast_params(eng)

@@ -378,6 +378,9 @@ int aew_set_tn_fold_rows(int rows);
 /* Split-K target of the TN ops (blocks per launch, default 512).  Changes aew_tn_slabs(): set it
  * before building a plan. */
 int aew_set_tn_target_blocks(int n);
+/* TN ops whose output has <= max_tiles 128x128 tiles are split to ~target_blocks blocks only (fewer
+ * slabs).  Like the call above it changes aew_tn_slabs(): set before building a plan. */
+int aew_set_tn_small(int max_tiles, int target_blocks);
 /* 1: read TN fragments with a scalar LDS gather instead of ds_read_b64_tr_b16 (debug aid). */
 int aew_set_tn_safe(int on);
 
