@@ -201,14 +201,15 @@ class DecoderPlan:
     def _alloc(self):
         ws, B, g = self.ws, self.B, self.g
         p = self.pre
-        M = lambda n, rows, pitch, dt, cols=None: Mat.new(ws, p + n, B, rows, pitch, dt, cols)
+        M = lambda n, rows, pitch, dt, cols=None, guard=0: Mat.new(ws, p + n, B, rows, pitch, dt, cols, guard)
         self.lcj = M("lcj", self.Ne, self.Lp, BF)
         self.lc_lens = g.lc_lens                      # [Ne, Ne-2, after each upsampler]
         self.ups_in: List[Mat] = [M("lc1", self.lc_lens[1], self.Cp, BF)]
         n_ups = len(self.hps.lc_upsample_strides)
+        # upsampler outputs carry guard rows: the merged-phase GEMM writes `stride` matrix rows per GEMM row
         for i in range(n_ups - 1):
-            self.ups_in.append(M(f"ups{i}", self.lc_lens[2 + i], self.Cp, BF))
-        self.cond = M("cond", self.T, self.Cp, BF)
+            self.ups_in.append(M(f"ups{i}", self.lc_lens[2 + i], self.Cp, BF, guard=8))
+        self.cond = M("cond", self.T, self.Cp, BF, guard=8)
         self.bias_bl = ws.alloc(p + "bias_bl", B * self.NL * 2 * self.Dp, torch.float32)
         self.gc = ws.alloc(p + "gc", B * self.Gc, torch.float32)
         self.x: List[Mat] = [M(f"x{l}", lg.in_len, self.Rp, BF) for l, lg in enumerate(g.layers)]
@@ -329,19 +330,24 @@ class DecoderPlan:
         for i, (f, s) in enumerate(zip(self.hps.lc_upsample_filt_sizes, self.hps.lc_upsample_strides)):
             nm = p + f"lc_upsample.{i}.tconv.weight"
             phases = []
+            Kph = (f // s) * Cp
+            Wall = self._wmat(f"up{i}", s * Cp, Kph)             # phase ph = rows ph*Cp .. (ph+1)*Cp
             for ph in range(s):
-                Wm = self._wmat(f"up{i}.{ph}", Cp, (f // s) * Cp)
+                Wm = Mat(self.ws, Wall.name, 1, Cp, Kph, BF, base_off=ph * Cp * Kph)
                 # [co][j*Cp + ci] <- W[ci][co][ph + s*j]
                 pk.rec(nm, ph, [f, Clc * f, s], [Clc, Clc, f // s], Wm, 0, [(f // s) * Cp, 1, Cp])
                 phases.append(Wm)
             self.Wup.append(phases)
+            self.Wup_all = getattr(self, "Wup_all", []) + [Wall]
             WT = self._wmat(f"upT{i}", Cp, f * Cp)
             # [ci][k*Cp + co] <- W[ci][co][k]
             pk.rec(nm, 0, [Clc * f, f, 1], [Clc, Clc, f], WT, 0, [f * Cp, 1, Cp])
             self.WupT.append(WT)
-            t = self.ws.alloc(p + f"wp.bias.up{i}", Cp, torch.float32)
+            t = self.ws.alloc(p + f"wp.bias.up{i}", s * Cp, torch.float32)     # the bias once per phase
             self.bias_vec[f"up{i}"] = t.data_ptr()
-            pk.pack_tbl.add(ps.ptr(p + f"lc_upsample.{i}.tconv.bias"), t.data_ptr(), [Clc], [1], [1], F3, F3)
+            for ph in range(s):
+                pk.pack_tbl.add(ps.ptr(p + f"lc_upsample.{i}.tconv.bias"), t.data_ptr() + 4 * ph * Cp, [Clc], [1], [1],
+                                F3, F3)
 
     # -- forward ---------------------------------------------------------------------------
     def build_forward(self, plan: Plan, need_onehot: bool = True):
@@ -369,6 +375,23 @@ class DecoderPlan:
             last = i == n_ups - 1
             trim0 = g.trim_ups_out[0] if last else 0
             Y = self.cond if last else self.ups_in[i + 1]
+            if pad % s == 0 and f % s == 0 and s <= 8:
+                # all phases in ONE GEMM: N = s*Cp, GEMM row q holds matrix rows s*q + ph - trim0 (ph = 0..s-1),
+                # i.e. the output is addressed as [rows/s][s*Cp]; partial rows at the ends land in the guard rows
+                q0 = pad // s
+                q_lo = trim0 // s
+                q_hi = min(-(-(Y.rows + trim0) // s), (Lout - 1) // s + 1)
+                Mq = q_hi - q_lo
+                assert s * q_lo - trim0 >= -8 and s * (q_hi - 1) + s - 1 - trim0 < Y.rows + 8
+                segs = [X.seg(Cp, row_off=q0 + q_lo - j) for j in range(f // s)]
+                ov = L.View()
+                ov.ptr = Y.ptr + 2 * (s * q_lo - trim0) * Cp
+                ov.batch_stride, ov.row_pitch, ov.row_step, ov.row_off = Y.bs, s * Cp, 1, 0
+                ov.row_lo, ov.row_hi, ov.dtype = 0, Mq, BF
+                plan.add(L.OP_GEMM_NT, make_nt(
+                    BF, Mq, s * Cp, s * Cp, B, segs, self.Wup_all[i].ptr, flags=L.EF_BIAS, out0=ov,
+                    bias_ptr=self.bias_vec[f"up{i}"], impl=impl), f"ups{i}", TAG_UPS)
+                continue
             for ph in range(s):
                 q0 = -((ph - pad) // s)                 # ceil((pad - ph)/s): first q with o >= 0
                 o0 = s * q0 + ph - pad

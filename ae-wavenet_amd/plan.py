@@ -63,25 +63,27 @@ class Mat:
     """A channels-last matrix [batch][rows][pitch] inside a workspace buffer."""
 
     def __init__(self, ws: Workspace, name: str, batch: int, rows: int, pitch: int, dtype: int,
-                 cols: Optional[int] = None, base_off: int = 0):
+                 cols: Optional[int] = None, base_off: int = 0, bs: Optional[int] = None):
         self.ws, self.name, self.batch, self.rows, self.pitch, self.dtype = ws, name, batch, rows, pitch, dtype
         self.cols = pitch if cols is None else cols
         self.base_off = base_off
-        self.bs = rows * pitch
+        self.bs = rows * pitch if bs is None else bs
 
     @staticmethod
     def new(ws: Workspace, name: str, batch: int, rows: int, pitch: int, dtype: int,
-            cols: Optional[int] = None) -> "Mat":
-        ws.alloc(name, batch * rows * pitch, TORCH_DT[dtype])
-        return Mat(ws, name, batch, rows, pitch, dtype, cols)
+            cols: Optional[int] = None, guard: int = 0) -> "Mat":
+        """guard: that many scratch rows before and after every batch element's rows (a writer whose
+        GEMM row covers several matrix rows may spill into them; readers never see them)."""
+        ws.alloc(name, batch * (rows + 2 * guard) * pitch, TORCH_DT[dtype])
+        return Mat(ws, name, batch, rows, pitch, dtype, cols, base_off=guard * pitch, bs=(rows + 2 * guard) * pitch)
 
     @property
     def ptr(self) -> int:
         return self.ws.ptr(self.name, self.base_off)
 
     def tensor(self) -> torch.Tensor:
-        t = self.ws.get(self.name)[self.base_off:self.base_off + self.batch * self.bs]
-        return t.view(self.batch, self.rows, self.pitch)
+        t = self.ws.get(self.name)
+        return torch.as_strided(t, (self.batch, self.rows, self.pitch), (self.bs, self.pitch, 1), self.base_off)
 
     def seg(self, k_len: int, row_off: int = 0, row_step: int = 1, lo: int = 0,
             hi: Optional[int] = None, col_off: int = 0) -> L.Seg:
