@@ -177,6 +177,10 @@ class Packer:
 class DecoderPlan:
     """Conditioning path + gated stack + post network + NLL, forward and backward."""
 
+    split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
+                              # measured slower (8.86 vs 8.62 ms/step): half-batch launches lose more than the
+                              # overlap of their tails returns
+
     def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, pre: str,
                  n_lc_in: int, lc_src: Mat, wav: torch.Tensor, voice: torch.Tensor,
                  jitter: torch.Tensor, take_compat: bool, packer: Packer, impl: int = 0):
@@ -424,26 +428,38 @@ class DecoderPlan:
             plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
         # 6. gated dilated stack (wavenet.py:91-111, 355-357)
         NL = self.NL
+        # Optionally (split_chains) the gated stack runs as two independent half-batch chains, chain 0 on the
+        # main lane and chain 1 on the side lane, so that each fills the other's tile-wave tails (a full-batch
+        # layer GEMM is 1.1-1.5 waves of tiles and nothing else is runnable in the forward).
+        n_chains = 2 if (self.split_chains and B % 2 == 0 and B >= 2) else 1
+        nb = B // n_chains
         for l, lg in enumerate(g.layers):
             last = l == NL - 1
             x = self.x[l]
             P_l = lg.out_len
-            segs = [x.seg(Rp), x.seg(Rp, row_off=lg.dil), self.cond.seg(Cp, row_off=lg.cond_lead)]
-            plan.add(L.OP_GEMM_NT, make_nt(
-                BF, P_l, Dp, 2 * Dp, B, segs, self.Wfg[l].ptr, epi=L.EPI_GATED,
-                out0=self.z[l].view(), out1=self.pf[l].view(), out2=self.pg[l].view(),
-                bias_ptr=self.bias_bl.data_ptr() + 4 * l * 2 * Dp, bias_bs=NL * 2 * Dp, impl=impl),
-                f"G1.{l}", TAG_G1, join=(l == 0))             # x[0] and the gated biases come from the side lane
-            if not last:
-                # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
+            for c in range(n_chains):
+                b0 = c * nb
+                plan.lane = 1 if c == 1 else 0
+                segs = [x.seg(Rp, b0=b0), x.seg(Rp, row_off=lg.dil, b0=b0),
+                        self.cond.seg(Cp, row_off=lg.cond_lead, b0=b0)]
                 plan.add(L.OP_GEMM_NT, make_nt(
-                    BF, P_l, Rp, Rp, B, [self.z[l].seg(Dp)], self.Wrs[l].ptr, flags=L.EF_ADD_AUX0,
-                    out0=self.x[l + 1].view(), aux0=x.view(row_off=lg.dil), impl=impl), f"G2.{l}", TAG_G2)
+                    BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, epi=L.EPI_GATED,
+                    out0=self.z[l].view(b0=b0), out1=self.pf[l].view(b0=b0), out2=self.pg[l].view(b0=b0),
+                    bias_ptr=self.bias_bl.data_ptr() + 4 * (l * 2 * Dp + b0 * NL * 2 * Dp), bias_bs=NL * 2 * Dp,
+                    impl=impl), f"G1.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_G1,
+                    join=(l == 0 and c == 0))                 # x[0] and the gated biases come from the side lane
+                if not last:
+                    # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
+                    plan.add(L.OP_GEMM_NT, make_nt(
+                        BF, P_l, Rp, Rp, nb, [self.z[l].seg(Dp, b0=b0)], self.Wrs[l].ptr, flags=L.EF_ADD_AUX0,
+                        out0=self.x[l + 1].view(b0=b0), aux0=x.view(row_off=lg.dil, b0=b0), impl=impl),
+                        f"G2.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_G2)
+        plan.lane = 0
         # skip path of all layers as ONE GEMM: relu(sum_l Wk_l . z_l[u + skip_lead_l]) -> h0
         # (wavenet.py:103,355-359).  K = NL*256; the fp32 skip sum never touches HBM.
         segs = [self.z[l].seg(Dp, row_off=lg.skip_lead) for l, lg in enumerate(g.layers)]
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp.ptr, flags=L.EF_RELU,
-                                       out0=self.h0.view(), impl=impl), "skip_all", TAG_G2)
+                                       out0=self.h0.view(), impl=impl), "skip_all", TAG_G2, join=True)
         # 7. post network (wavenet.py:359-360)
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Pp, Pp, B, [self.h0.seg(Sp)], self.Wp1.ptr,
                                        flags=L.EF_BIAS | L.EF_RELU, out0=self.h1.view(),

@@ -86,9 +86,10 @@ class Mat:
         return torch.as_strided(t, (self.batch, self.rows, self.pitch), (self.bs, self.pitch, 1), self.base_off)
 
     def seg(self, k_len: int, row_off: int = 0, row_step: int = 1, lo: int = 0,
-            hi: Optional[int] = None, col_off: int = 0) -> L.Seg:
+            hi: Optional[int] = None, col_off: int = 0, b0: int = 0) -> L.Seg:
+        """b0: first batch element (ops that cover a sub-range of the batch)."""
         s = L.Seg()
-        s.ptr = self.ptr + col_off * ESIZE[self.dtype]
+        s.ptr = self.ptr + (col_off + b0 * self.bs) * ESIZE[self.dtype]
         s.batch_stride, s.row_pitch = self.bs, self.pitch
         s.row_step, s.row_off = row_step, row_off
         s.row_lo, s.row_hi = lo, self.rows if hi is None else hi
@@ -96,9 +97,9 @@ class Mat:
         return s
 
     def view(self, row_off: int = 0, row_step: int = 1, lo: int = 0, hi: Optional[int] = None,
-             col_off: int = 0) -> L.View:
+             col_off: int = 0, b0: int = 0) -> L.View:
         v = L.View()
-        v.ptr = self.ptr + col_off * ESIZE[self.dtype]
+        v.ptr = self.ptr + (col_off + b0 * self.bs) * ESIZE[self.dtype]
         v.batch_stride, v.row_pitch = self.bs, self.pitch
         v.row_step, v.row_off = row_step, row_off
         v.row_lo, v.row_hi = lo, self.rows if hi is None else hi

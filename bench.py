@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--nt-pipe", dest="nt_pipe", type=int, default=1, help="0 plain loop, 1 pipelined, 2 pipelined K=64 tiles")
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")
     ap.add_argument("--tn-small", dest="tn_small", default="", help="max_tiles,target_blocks for small-output TN ops")
+    ap.add_argument("--chains", type=int, default=1, help="1: gated stack as one full-batch chain; 2: two half-batch chains")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
@@ -149,6 +150,8 @@ def main():
     if args.tn_small:
         a, b = (int(v) for v in args.tn_small.split(","))
         lib.aew_set_tn_small(a, b)
+    from ae_wavenet_amd import engine as _E
+    _E.DecoderPlan.split_chains = args.chains == 2
     hps, eng = build_engine(args, device)
     if dp is not None:
         dp.broadcast_params(eng)
