@@ -104,6 +104,16 @@ def make_hps(*named: str, **overrides) -> Hyperparams:
     return h
 
 
+def from_checkpoint_hps(saved: Dict[str, Any], **overrides) -> Hyperparams:
+    """hps as stored in a reference checkpoint (checkpoint.py:27-29: `Hyperparams(**ckpt['hps'])`, then
+    the command-line overrides).  Keys this build does not use (output_dir, hw, ...) are carried along."""
+    h = Hyperparams(_DEFAULTS)
+    h.update(saved)
+    h.update(overrides)
+    _finalize(h)
+    return h
+
+
 def from_par(arch: Dict[str, Any], train: Dict[str, Any] | None = None, **overrides) -> Hyperparams:
     """Build hps from the contents of a ``par/arch.*.json`` (+ optional
     ``par/train.*.json``) dictionary."""

@@ -563,8 +563,44 @@ def gen_full_modules():
     save("recloss.npz", pred=t2n(pred), target=t2n(tgt), loss=t2n(loss), grad=t2n(gp))
 
 
+# ------------------------------------------------------------------------------------
+# E. a checkpoint file in the reference's format (checkpoint.py:82-102), written with the
+#    reference's own classes: MfccInverter state_dict, torch Adam state after two steps,
+#    hps as hparams.Hyperparams.  Pins ae_wavenet_amd.checkpoint.
+# ------------------------------------------------------------------------------------
+def gen_ckpt():
+    hps = make_hps(**TINY, n_lc_in=7)
+    torch.manual_seed(0)
+    m = mfcc_inverter.MfccInverter(hps)
+    load_np_weights(m, 23)
+    optim = torch.optim.Adam(params=m.parameters(), lr=hps.learning_rate_rates[0])
+    g = torch.Generator().manual_seed(99)
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = torch.randn(p.shape, generator=g) * 0.1
+        optim.step()
+    state = {                                   # exactly the dict of checkpoint.py:87-98
+        "hps": hps, "epoch": 3, "step": 1234, "optim_step": 2,
+        "model_state_dict": m.state_dict(), "optim": optim.state_dict(),
+        "rand_state": torch.get_rng_state(), "cuda_rand_states": None,
+    }
+    path = os.path.join(HERE, "reference_format.ckpt")
+    torch.save(state, path)
+    # one more reference Adam step from known gradients: what a restored optimizer must reproduce
+    grads = {}
+    for k, p in m.named_parameters():
+        p.grad = torch.randn(p.shape, generator=g) * 0.1
+        grads["grad." + k] = t2n(p.grad)
+    optim.step()
+    after = {"after." + k: t2n(p) for k, p in m.named_parameters()}
+    save("reference_ckpt_next_step.npz", **grads, **after)
+    print(f"wrote reference_format.ckpt: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main():
-    which = sys.argv[1:] or ["geometry", "mi", "ae", "full"]
+    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt"]
+    if "ckpt" in which:
+        gen_ckpt()
     if "geometry" in which:
         gen_geometry()
     if "mi" in which:
