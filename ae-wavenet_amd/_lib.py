@@ -20,7 +20,7 @@ EF_MUL_POS1, EF_OUT1_POS1, EF_ACCUM, EF_OUT2_RELU, EF_COUNT_ZERO = 1 << 4, 1 << 
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
- OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM) = range(1, 20)
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER) = range(1, 21)
 
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -154,12 +154,17 @@ class AeNorm(C.Structure):
                 ("dze_in", vp), ("coef", f32), ("dze", vp), ("backward", i32)]
 
 
+class Jitter(C.Structure):
+    _fields_ = [("out", vp), ("out_pitch", i32), ("B", i32), ("n", i32), ("p", f32), ("mode", i32),
+                ("seed", C.c_uint64), ("step", C.c_uint64)]
+
+
 class _OpU(C.Union):
     _fields_ = [("nt", GemmNT), ("tn", GemmTN), ("copy", CopyTable), ("vqn", VqNearest),
                 ("vqs", VqStats), ("vqe", VqEma), ("vqb", VqBwd), ("lcg", LcGather),
                 ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
                 ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
-                ("zero", Zero), ("vae", Vae), ("aen", AeNorm)]
+                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter)]
 
 
 class Op(C.Structure):
@@ -170,7 +175,7 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_VQ_STATS: "vqs", OP_VQ_EMA: "vqe", OP_VQ_BWD: "vqb", OP_LC_GATHER: "lcg",
             OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
-            OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen"}
+            OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaewavenet_hip.so")
 _lib = None
@@ -205,7 +210,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 3:
+    if lib.aew_abi_version() != 4:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

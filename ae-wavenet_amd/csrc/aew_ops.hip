@@ -467,15 +467,20 @@ __global__ void k_zero(uint4* p, int64_t n16) {
 // =============================================================================================
 // scalar reduction (loss):  out[0] = sum_i scale_i * sum(x_i)     single block, deterministic
 // =============================================================================================
-__global__ void k_reduce(const aew_reduce_t p) {
-    __shared__ float sh[256];
+__global__ __launch_bounds__(1024) void k_reduce(const aew_reduce_t p) {
+    // one block of 1024 threads, 4 loads in flight per thread; fixed summation order (deterministic)
+    __shared__ float sh[1024];
     float tot = 0.f;
     for (int i = 0; i < p.n_terms; ++i) {
-        float s = 0.f;
-        for (int e = threadIdx.x; e < p.n[i]; e += 256) s += p.x[i][e];
-        sh[threadIdx.x] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float* x = p.x[i];
+        const int n = p.n[i];
+        int e = threadIdx.x;
+        for (; e + 3072 < n; e += 4096) { s0 += x[e]; s1 += x[e + 1024]; s2 += x[e + 2048]; s3 += x[e + 3072]; }
+        for (; e < n; e += 1024) s0 += x[e];
+        sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = 512; o > 0; o >>= 1) {
             if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
             __syncthreads();
         }
@@ -578,6 +583,40 @@ __global__ void k_ae_norm(const aew_ae_norm_t p) {
 }
 
 // =============================================================================================
+// time-jitter indices (jitter.py:13-33): one thread per batch row (the documented rule is a
+// second-order chain; n is a few hundred at most)
+// =============================================================================================
+__device__ __forceinline__ unsigned long long aew_mix64(unsigned long long z) {      // splitmix64 finaliser
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27; z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ double aew_jitter_u(unsigned long long seed, unsigned long long step, int b, int t) {
+    unsigned long long h = aew_mix64(seed + 0x9e3779b97f4a7c15ull);
+    h = aew_mix64(h ^ (step + 0x9e3779b97f4a7c15ull));
+    h = aew_mix64(h ^ (((unsigned long long)(unsigned)b << 32) | (unsigned long long)(unsigned)t));
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);                               // 53 bits -> [0, 1)
+}
+__global__ void k_jitter(const aew_jitter_t j) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= j.B) return;
+    const double p = (double)j.p, s = 1.0 - 2.0 * (double)j.p;
+    int x2 = 1, x1 = 1;
+    for (int t = 0; t < j.n; ++t) {
+        int x = 1;
+        if (t >= 2) {
+            const double u = aew_jitter_u(j.seed, j.step, b, t);
+            double c0 = p, c1 = p + s;                                   // cumulative [p, s, p]
+            if (j.mode == 1 && x2 == 2 && x1 == 1) { c0 = 0.0; c1 = s / (p + s); }
+            x = (u >= c0 ? 1 : 0) + (u >= c1 ? 1 : 0);
+        }
+        j.out[(int64_t)b * j.out_pitch + t] = (int64_t)(t - 1 + x);
+        x2 = x1; x1 = x;
+    }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -656,7 +695,7 @@ static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
 }
 static int launch_reduce(const aew_reduce_t& p, hipStream_t st) {
     if (p.n_terms < 1 || p.n_terms > 4) return AEW_E_ARG;
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, p);
     return (int)hipGetLastError();
 }
 static int launch_adam(const aew_adam_t& p, hipStream_t st) {
@@ -675,6 +714,11 @@ static int launch_zero(const aew_zero_t& z, hipStream_t st) {
 }
 static int launch_vae(const aew_vae_t& p, hipStream_t st) {
     hipLaunchKernelGGL(k_vae, dim3(p.Q), dim3(64), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_jitter(const aew_jitter_t& j, hipStream_t st) {
+    if (!j.out || j.B <= 0 || j.n < 0 || j.out_pitch < j.n || !(j.p >= 0.f && j.p <= 0.5f)) return AEW_E_ARG;
+    hipLaunchKernelGGL(k_jitter, dim3(cdiv64(j.B, 64)), dim3(64), 0, st, j);
     return (int)hipGetLastError();
 }
 static int launch_ae_norm(const aew_ae_norm_t& p, hipStream_t st) {

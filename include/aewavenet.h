@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 3
+#define AEW_ABI_VERSION 4
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -307,6 +307,21 @@ typedef struct {                 /* AE norm term (ae_bn.py:36-38): | ||ze|| - 1 
     int32_t backward;
 } aew_ae_norm_t;
 
+typedef struct {                 /* time-jitter indices on the device (jitter.py:13-33).  out[b][t] = t - 1 + X[b][t],
+                                    X in {0,1,2}; X = 1 for t < 2.  mode 0 = what the reference does at HEAD:
+                                    X iid with P = [p, 1-2p, p] (its conditional table is indexed [p1][p1], so the
+                                    "no three in a row" rule never fires); mode 1 = the documented rule:
+                                    P(X_t | X_t-2, X_t-1) = [p, s, p] except (2,1) -> [0, s/(p+s), p/(p+s)].
+                                    Randomness: counter-based, u(b,t) = mix64(seed, step, b, t) / 2^53 in [0,1);
+                                    X = (u >= c0) + (u >= c1) on the cumulative table (oracle/jitter_rng.py is the
+                                    same arithmetic in numpy: bit-identical output).                                  */
+    int64_t* out; int32_t out_pitch;
+    int32_t B, n;
+    float p;
+    int32_t mode;
+    uint64_t seed, step;
+} aew_jitter_t;
+
 /* ---------------------------------------------------------------------------------------
  * plan
  * ------------------------------------------------------------------------------------- */
@@ -314,7 +329,7 @@ enum {
     AEW_OP_GEMM_NT = 1, AEW_OP_GEMM_TN, AEW_OP_COPY_TABLE, AEW_OP_VQ_NEAREST, AEW_OP_VQ_STATS,
     AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
     AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
-    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM
+    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
@@ -336,7 +351,7 @@ typedef struct {
         aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;
         aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
         aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
-        aew_vae_t vae; aew_ae_norm_t aen;
+        aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit;
     } u;
 } aew_op_t;
 

@@ -597,8 +597,36 @@ def gen_ckpt():
     print(f"wrote reference_format.ckpt: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+# ------------------------------------------------------------------------------------
+# F. statistics of the reference's Jitter class (jitter.py:13-33), numpy seed 0: what a generator with
+#    another random stream can be held to (offset frequencies, pair frequencies, structure)
+# ------------------------------------------------------------------------------------
+def gen_jitter():
+    import jitter as ref_jitter
+    out = {}
+    for p in (0.12, 0.3):
+        np.random.seed(0)
+        J = ref_jitter.Jitter(p)
+        n, reps = 72, 400
+        rows = np.stack([J(n) for _ in range(reps)])
+        off = rows - np.arange(n)[None, :]                       # -1 / 0 / +1
+        body = off[:, 2:]
+        pairs = Counter(zip(body[:, :-1].reshape(-1).tolist(), body[:, 1:].reshape(-1).tolist()))
+        triples = int(((body[:, :-2] == body[:, 1:-1]) & (body[:, 1:-1] == body[:, 2:]) & (body[:, 2:] != 0)).sum())
+        out[str(p)] = dict(n=n, reps=reps, first_two_identity=bool((off[:, :2] == 0).all()),
+                           counts=[int((body == v).sum()) for v in (-1, 0, 1)],
+                           pair_counts={f"{a},{b}": c for (a, b), c in sorted(pairs.items())},
+                           same_nonzero_triples=triples, min_off=int(off.min()), max_off=int(off.max()),
+                           first_row=rows[0].tolist())
+    with open(os.path.join(HERE, "jitter_stats.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+    print("wrote jitter_stats.json", os.path.getsize(os.path.join(HERE, "jitter_stats.json")), "bytes")
+
+
 def main():
-    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt"]
+    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt", "jitter"]
+    if "jitter" in which:
+        gen_jitter()
     if "ckpt" in which:
         gen_ckpt()
     if "geometry" in which:

@@ -425,3 +425,9 @@ class Emu:
             out = torch.zeros(p.Q, p.d_pitch)
             out[:, :p.d] = g
             self.wr(p.dze, torch.arange(p.Q * p.d_pitch), out.reshape(-1))
+
+    def op_20(self, p):  # JITTER (counter RNG restated in oracle/jitter_rng.py)
+        from oracle import jitter_rng
+        idx = jitter_rng.device_indices(p.seed, p.step, p.B, p.n, p.p, p.mode)
+        for b in range(p.B):
+            self.wr(p.out, torch.arange(p.n) + b * p.out_pitch, torch.from_numpy(idx[b]))
