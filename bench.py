@@ -238,7 +238,10 @@ def main():
                 "ms_per_step_by_class": {str(k): round(v, 4) for k, v in sorted(cls_ms.items())}}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if world > 1:
+        cpu = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+               "sample": "measured at --gpus 1 only (rank 0 would hold the other ranks for ~20 s)"}
+    elif rank == 0 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(hps, eng)
         except Exception as e:                                   # never lose the GPU line
