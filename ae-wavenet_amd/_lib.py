@@ -129,7 +129,8 @@ class Colsum(C.Structure):
 
 class Reduce(C.Structure):
     _fields_ = [("x", vp * 4), ("n", i32 * 4), ("scale", f32 * 4), ("clamp", i32 * 4),
-                ("clamp_min", f32 * 4), ("post_scale", f32 * 4), ("n_terms", i32), ("out", vp)]
+                ("clamp_min", f32 * 4), ("post_scale", f32 * 4), ("n_terms", i32), ("out", vp),
+                ("post_scale_dev", vp * 4)]
 
 
 class Adam(C.Structure):
@@ -146,7 +147,7 @@ class Vae(C.Structure):
     _fields_ = [("lin", vp), ("lin_pitch", i32), ("eps", vp), ("Q", i32), ("d", i32),
                 ("d_pitch", i32), ("sample", vp), ("kl_terms", vp), ("dsample", vp),
                 ("kl_coef", f32), ("kl_value", vp), ("free_nats", f32), ("dlin", vp),
-                ("backward", i32)]
+                ("backward", i32), ("kl_coef_dev", vp)]
 
 
 class AeNorm(C.Structure):
@@ -210,7 +211,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 4:
+    if lib.aew_abi_version() != 5:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

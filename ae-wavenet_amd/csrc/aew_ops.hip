@@ -486,7 +486,8 @@ __global__ __launch_bounds__(1024) void k_reduce(const aew_reduce_t p) {
         }
         const float v = sh[0] * p.scale[i];
         if (threadIdx.x == 0) p.out[1 + i] = v;
-        tot += p.clamp[i] ? p.post_scale[i] * fmaxf(v, p.clamp_min[i]) : v;
+        const float ps = p.post_scale_dev[i] ? p.post_scale_dev[i][0] : p.post_scale[i];
+        tot += p.clamp[i] ? ps * fmaxf(v, p.clamp_min[i]) : v;
         __syncthreads();
     }
     if (threadIdx.x == 0) p.out[0] = tot;
@@ -535,8 +536,9 @@ __global__ void k_vae(const aew_vae_t p) {
     const int lane = threadIdx.x;                     // 64 threads
     const float* lin = p.lin + (int64_t)q * p.lin_pitch;
     float kl = 0.f;
-    float klc = p.kl_coef;
-    if (p.backward && p.kl_value) klc = (p.kl_value[0] >= p.free_nats) ? p.kl_coef : 0.f;
+    const float kl_coef = p.kl_coef_dev ? p.kl_coef_dev[0] : p.kl_coef;
+    float klc = kl_coef;
+    if (p.backward && p.kl_value) klc = (p.kl_value[0] >= p.free_nats) ? kl_coef : 0.f;
     for (int j = lane; j < p.d_pitch; j += 64) {
         if (j < p.d) {
             const float mu = lin[j], ls = lin[p.d + j];

@@ -131,6 +131,7 @@ class TrainEngine:
             self.eps = ws.alloc("bn.eps", self.Q * d, torch.float32)[:self.Q * d].view(B, Ne, d)
             self.kl_terms = ws.alloc("bn.kl_terms", self.Q, torch.float32)
             self.anneal_weight = 0.0
+            self.anneal_buf = ws.alloc("bn.anneal", 4, torch.float32)[:1]   # read by the loss / KL-gradient ops
         elif bn == "ae":
             self.code = self.lin
             self.norm_terms = ws.alloc("bn.norm_terms", self.Q, torch.float32)
@@ -212,6 +213,7 @@ class TrainEngine:
             red.post_scale[i] = 1.0
         if bn == "vae":
             red.clamp[1], red.clamp_min[1], red.post_scale[1] = 1, float(hps.bn_free_nats), 0.0
+            red.post_scale_dev[1] = self.anneal_buf.data_ptr()
             self._red_index = len(fb.ops)
         red.out = self.loss_buf.data_ptr()
         fb.add(L.OP_REDUCE, red, "loss", TAG_LOSS)
@@ -315,6 +317,7 @@ class TrainEngine:
         if backward:
             va.dsample = dcode.ptr
             va.kl_coef = float(self.anneal_weight)
+            va.kl_coef_dev = self.anneal_buf.data_ptr()
             va.kl_value = self.loss_buf.data_ptr() + 4 * 2       # out[1 + term 1]
             va.free_nats = float(self.hps.bn_free_nats)
             va.dlin = self.dlin.ptr
@@ -351,15 +354,11 @@ class TrainEngine:
                 self.eps.copy_(eps.permute(0, 2, 1) if eps.shape[1] == self.d and eps.dim() == 3 else eps)
 
     def set_anneal_weight(self, a: float):
-        """SGVBLoss.update_anneal_weight (vae_bn.py:72-73)."""
+        """SGVBLoss.update_anneal_weight (vae_bn.py:72-73).  The weight changes every step
+        (chassis.py:148-149), so the ops read it from device memory (`anneal_buf`): no descriptor is
+        patched and no captured graph is invalidated."""
         self.anneal_weight = float(a)
-        arr = self.fwd_b.array()
-        arr[self._red_index].u.red.post_scale[1] = float(a)
-        self.bwd.array()[self._vae_bwd_index].u.vae.kl_coef = float(a)
-        self.fwd_b.invalidate_graph()
-        self.bwd.invalidate_graph()
-        self.bwd_a.invalidate_graph()
-        self.bwd_b.invalidate_graph()
+        self.anneal_buf.fill_(float(a))
 
     def _run(self, plan, timing=False):
         if self.use_graphs and not timing:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 4
+#define AEW_ABI_VERSION 5
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -274,6 +274,9 @@ typedef struct {                 /* v_i = scale_i * sum(x_i[0:n_i]);  out[1+i] =
     const float* x[4]; int32_t n[4]; float scale[4]; int32_t clamp[4]; float clamp_min[4];
     float post_scale[4]; int32_t n_terms;
     float* out;                  /* [5] */
+    const float* post_scale_dev[4];   /* if non-NULL, post_scale_i is read from device memory at run time
+                                         (values that change every step, e.g. the KL anneal weight, must not
+                                         be frozen into a captured graph)                                    */
 } aew_reduce_t;
 
 typedef struct {                 /* fused Adam over a flat fp32 buffer (torch.optim.Adam defaults,
@@ -298,6 +301,7 @@ typedef struct {                 /* VAE reparameterisation (vae_bn.py:44-53) and
                                                [kl_value[0] >= free_nats] (torch.clamp backward)   */
     float* dlin;                            /* bwd: [Q][2d pitch]                            */
     int32_t backward;
+    const float* kl_coef_dev;               /* if non-NULL, kl_coef is read from device memory at run time  */
 } aew_vae_t;
 
 typedef struct {                 /* AE norm term (ae_bn.py:36-38): | ||ze|| - 1 | per row      */

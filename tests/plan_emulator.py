@@ -375,7 +375,8 @@ class Emu:
         for i in range(p.n_terms):
             v = self.rd(p.x[i], torch.arange(p.n[i])).sum() * p.scale[i]
             t[off + 1 + i] = v
-            tot = tot + (p.post_scale[i] * torch.clamp(v, min=p.clamp_min[i]) if p.clamp[i] else v)
+            ps = float(self.rd(p.post_scale_dev[i], torch.arange(1))[0]) if p.post_scale_dev[i] else p.post_scale[i]
+            tot = tot + (ps * torch.clamp(v, min=p.clamp_min[i]) if p.clamp[i] else v)
         t[off] = tot
 
     def op_16(self, a):  # ADAM
@@ -406,7 +407,7 @@ class Emu:
             s2 = sigma * sigma
             self.wr(p.kl_terms, torch.arange(p.Q), (1 + torch.log(s2) - mu * mu - s2).sum(1))
         else:
-            klc = p.kl_coef
+            klc = float(self.rd(p.kl_coef_dev, torch.arange(1))[0]) if p.kl_coef_dev else p.kl_coef
             if p.kl_value:
                 klc = klc if float(self.rd(p.kl_value, torch.arange(1))[0]) >= p.free_nats else 0.0
             ds = self.rd(p.dsample, q * p.d_pitch + j)

@@ -498,6 +498,16 @@ def test_vae_and_deep_configs_full_size():
             eng.init_ema_from_emb()
         l1 = float(eng.forward())
         assert l1 == l0
+        if arch == "vae":
+            # the anneal weight lives in device memory: changing it takes effect in the already captured
+            # graphs (chassis.py:148-149 changes it every step), loss = nll + a * max(KL, free_nats)
+            kl = max(float(eng.loss_buf[2]), float(hps.bn_free_nats))
+            eng.set_anneal_weight(0.6)
+            l2 = float(eng.forward())
+            assert abs((l2 - l0) - 0.3 * kl) <= 1e-4 * abs(l0) + 1e-3, (l0, l2, kl)
+            eng.backward()
+            g1 = eng.ps.grads[:eng.ps.numel].clone()
+            assert torch.isfinite(g1).all() and not torch.equal(g1, g0)
         del eng
         torch.cuda.empty_cache()
 
