@@ -61,7 +61,7 @@ class CopyTable(C.Structure):
 
 class VqNearest(C.Structure):
     _fields_ = [("ze", vp), ("emb", vp), ("Q", i32), ("K", i32), ("d", i32), ("d_pitch", i32),
-                ("metric", i32), ("ind", vp), ("dist", vp), ("zq", vp)]
+                ("metric", i32), ("ind", vp), ("dist", vp), ("zq", vp), ("scratch", vp), ("n_split", i32)]
 
 
 class VqStats(C.Structure):
@@ -211,7 +211,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 5:
+    if lib.aew_abi_version() != 6:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

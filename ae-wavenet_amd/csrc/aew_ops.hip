@@ -96,28 +96,36 @@ __global__ void k_copy_table(const aew_copy_table_t t) {
 // the exact order of oracle/exact_chain.c (fma chains, IEEE sqrt and divide, strict '<',
 // lowest index wins).   vqema_bn.py:135-142, vq_bn.py:39-41
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
-    // one block (4 waves) per query; wave w scans codes w*64+lane, +256, ...  The argmin with
-    // lowest-index tie-break is independent of the scan order, so the result equals the
-    // sequential oracle loop.
+// Scan of codes [k0, k1) by one block: per-code arithmetic in the exact order of oracle/exact_chain.c;
+// returns the block's (min, lowest index) in every thread.
+__device__ __forceinline__ void vq_scan(const aew_vq_nearest_t& p, const float* z, float zn, int k0, int k1,
+                                        float& best, int& bi) {
     __shared__ float sh_d[4];
     __shared__ int sh_i[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = blockIdx.x;
-    const float* z = p.ze + (int64_t)q * p.d_pitch;
-    float zz = 0.f;
-    for (int j = 0; j < p.d; ++j) zz = __fmaf_rn(z[j], z[j], zz);
-    const float zn = sqrtf(zz);          // sqrtf is IEEE-rounded; __fsqrt_rn lowers to a bare v_sqrt_f32
-    float best = INFINITY;
-    int bi = 0x7fffffff;
-    for (int k = threadIdx.x; k < p.K; k += 256) {
+    best = INFINITY;
+    bi = 0x7fffffff;
+    for (int k = k0 + threadIdx.x; k < k1; k += 256) {
         const float* c = p.emb + (int64_t)k * p.d;
         float dd = 0.f, qq = 0.f;
-        for (int j = 0; j < p.d; ++j) {
-            const float cj = c[j];
-            const float t = __fsub_rn(z[j], cj);
-            dd = __fmaf_rn(t, t, dd);
-            qq = __fmaf_rn(cj, cj, qq);
+        if ((p.d & 3) == 0) {                        // 16-byte loads of the code row; arithmetic order unchanged
+            for (int j = 0; j < p.d; j += 4) {
+                const float4 c4 = *reinterpret_cast<const float4*>(c + j);
+                const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = __fsub_rn(z[j + r], cv[r]);
+                    dd = __fmaf_rn(t, t, dd);
+                    qq = __fmaf_rn(cv[r], cv[r], qq);
+                }
+            }
+        } else {
+            for (int j = 0; j < p.d; ++j) {
+                const float cj = c[j];
+                const float t = __fsub_rn(z[j], cj);
+                dd = __fmaf_rn(t, t, dd);
+                qq = __fmaf_rn(cj, cj, qq);
+            }
         }
         float v;
         if (p.metric == 0) v = __fdiv_rn(sqrtf(dd), __fadd_rn(zn, sqrtf(qq)));
@@ -136,21 +144,81 @@ __global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (sh_d[w] < best || (sh_d[w] == best && sh_i[w] < bi)) { best = sh_d[w]; bi = sh_i[w]; }
+}
+
+__device__ __forceinline__ float vq_znorm(const aew_vq_nearest_t& p, const float* z) {
+    float zz = 0.f;
+    for (int j = 0; j < p.d; ++j) zz = __fmaf_rn(z[j], z[j], zz);
+    return sqrtf(zz);                    // sqrtf is IEEE-rounded; __fsqrt_rn lowers to a bare v_sqrt_f32
+}
+
+__device__ __forceinline__ void vq_emit(const aew_vq_nearest_t& p, int q, float best, int bi) {
     if (bi == 0x7fffffff) bi = 0;                    // all-NaN row: torch.min would return NaN; pick 0
     if (threadIdx.x == 0) { p.ind[q] = bi; p.dist[q] = best; }
     float* zq = p.zq + (int64_t)q * p.d_pitch;
-    for (int j = threadIdx.x; j < p.d_pitch; j += 256) zq[j] = j < p.d ? p.emb[(int64_t)bi * p.d + j] : 0.f;
+    for (int j = threadIdx.x; j < p.d_pitch; j += blockDim.x) zq[j] = j < p.d ? p.emb[(int64_t)bi * p.d + j] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_vq_nearest(const aew_vq_nearest_t p) {
+    // one block (4 waves) per query; wave w scans codes w*64+lane, +256, ...  The argmin with
+    // lowest-index tie-break is independent of the scan order, so the result equals the
+    // sequential oracle loop.
+    const int q = blockIdx.x;
+    const float* z = p.ze + (int64_t)q * p.d_pitch;
+    float best; int bi;
+    vq_scan(p, z, vq_znorm(p, z), 0, p.K, best, bi);
+    vq_emit(p, q, best, bi);
+}
+
+// split form: grid (n_split, Q); block (s, q) scans its slice of the codebook and leaves (min, index) in
+// scratch; k_vq_nearest_combine takes the minimum over the slices (ties: lowest index, i.e. lowest slice)
+__global__ __launch_bounds__(256) void k_vq_nearest_part(const aew_vq_nearest_t p) {
+    const int s = blockIdx.x, q = blockIdx.y;
+    const int per = (p.K + p.n_split - 1) / p.n_split;
+    const float* z = p.ze + (int64_t)q * p.d_pitch;
+    float best; int bi;
+    vq_scan(p, z, vq_znorm(p, z), s * per, min(p.K, (s + 1) * per), best, bi);
+    if (threadIdx.x == 0) {
+        float* pd = reinterpret_cast<float*>(p.scratch) + ((int64_t)q * p.n_split + s) * 2;
+        pd[0] = best;
+        reinterpret_cast<int*>(pd)[1] = bi;
+    }
+}
+__global__ __launch_bounds__(64) void k_vq_nearest_combine(const aew_vq_nearest_t p) {
+    const int q = blockIdx.x;
+    const float* pd = reinterpret_cast<const float*>(p.scratch) + (int64_t)q * p.n_split * 2;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int s = 0; s < p.n_split; ++s) {
+        const float v = pd[2 * s];
+        const int i = reinterpret_cast<const int*>(pd)[2 * s + 1];
+        if (v < best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    vq_emit(p, q, best, bi);
 }
 
 // z_sum / n_sum: one thread per (code, channel), queries in ascending order (deterministic and
 // bit-identical to the oracle).  vqema_bn.py:172-188
-__global__ void k_vq_stats(const aew_vq_stats_t p) {
+__global__ __launch_bounds__(256) void k_vq_stats(const aew_vq_stats_t p) {
+    // the code index of every query is staged through LDS in chunks (a global load per query and thread
+    // made this loop a chain of L2 round trips: 47 us for Q = 232)
+    __shared__ int sh_ind[1024];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)p.K * p.d) return;
-    const int k = (int)(e / p.d), j = (int)(e % p.d);
+    const bool live = e < (int64_t)p.K * p.d;
+    const int k = live ? (int)(e / p.d) : -1, j = live ? (int)(e % p.d) : 0;
     float s = 0.f, n = 0.f;
-    for (int q = 0; q < p.Q; ++q)
-        if (p.ind[q] == k) { s = __fadd_rn(s, p.ze[(int64_t)q * p.d_pitch + j]); n = __fadd_rn(n, 1.0f); }
+    for (int q0 = 0; q0 < p.Q; q0 += 1024) {
+        const int nq = min(1024, p.Q - q0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) sh_ind[i] = (int)p.ind[q0 + i];
+        __syncthreads();
+        for (int i = 0; i < nq; ++i)                      // queries in ascending order: deterministic,
+            if (sh_ind[i] == k) {                         // bit-identical to the oracle
+                s = __fadd_rn(s, p.ze[(int64_t)(q0 + i) * p.d_pitch + j]);
+                n = __fadd_rn(n, 1.0f);
+            }
+    }
+    if (!live) return;
     p.z_sum[e] = s;
     if (j == 0) {
         p.n_sum[k] = n;
@@ -629,6 +697,12 @@ static int launch_copy(const aew_copy_table_t& t, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_vq_nearest(const aew_vq_nearest_t& p, hipStream_t st) {
+    if (p.scratch && p.n_split > 1) {
+        if (p.n_split > 64 || ((uintptr_t)p.scratch & 7)) return AEW_E_ARG;
+        hipLaunchKernelGGL(k_vq_nearest_part, dim3(p.n_split, p.Q), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_vq_nearest_combine, dim3(p.Q), dim3(64), 0, st, p);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_vq_nearest, dim3(p.Q), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }

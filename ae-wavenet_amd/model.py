@@ -167,6 +167,9 @@ class TrainEngine:
                 vq.Q, vq.K, vq.d, vq.d_pitch = self.Q, self.K, self.d, self.nlin_p
                 vq.metric = 0 if bn == "vqvae-ema" else 1
                 vq.ind, vq.dist, vq.zq = self.ind.data_ptr(), self.min_dist.data_ptr(), self.code.ptr
+                vq.n_split = max(1, min(16, self.K // 256))       # each block scans >= 256 codes (one per thread)
+                if vq.n_split > 1:
+                    vq.scratch = ws.alloc("bn.vq_part", 2 * self.Q * vq.n_split, torch.float32).data_ptr()
                 assert self.dp == self.nlin_p
                 fa.add(L.OP_VQ_NEAREST, vq, "vq.nearest", TAG_VQ)
                 if bn == "vqvae-ema":

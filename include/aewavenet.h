@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 5
+#define AEW_ABI_VERSION 6
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -172,6 +172,10 @@ typedef struct {                 /* nearest code  (vqema_bn.py:135-142, vq_bn.py
     int64_t* ind;                /* [Q]                                                       */
     float* dist;                 /* [Q]                                                       */
     float* zq;                   /* [Q][d_pitch] (pad channels zeroed)                        */
+    void* scratch; int32_t n_split;   /* optional: 8*Q*n_split bytes.  The K codes are then scanned by n_split
+                                         blocks per query (partial minima into scratch) and a second tiny kernel
+                                         combines them in ascending split order: same result bit for bit, 4x
+                                         shorter critical path at Q = 232, K = 4096                           */
 } aew_vq_nearest_t;
 
 typedef struct {                 /* z_sum/n_sum, deterministic order (vqema_bn.py:172-188)     */
