@@ -886,6 +886,8 @@ __device__ __forceinline__ void p64_frags_ready(bf16x8_t (&wf)[4], bf16x8_t (&xf
 // MT x WM x WN:  8 x 2 x 4 = 256 x 256 tile, 8 fat waves, one block per CU (long-K ops)
 //                4 x 2 x 2 = 128 x 128 tile, 4 waves of 64 x 64, two blocks per CU
 //                4 x 4 x 2 = 256 x 128 tile, 8 waves of 64 x 64, one block per CU (96 KiB)
+//                4 x 1 x 2 =  64 x 128 tile, 2 waves, three blocks per CU: launches with few rows (the
+//                            upsampler dgrads have 56 tiles of 256 rows for 256 CUs)
 template <int EPI, int MT, int WM, int WN>
 __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf16_p64(const aew_gemm_nt_t g) {
     typedef P64Cfg<MT, WM, WN> Cfg;
@@ -977,6 +979,7 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
 
     if (Cfg::PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tile 0 (mine) landed
     else if (Cfg::PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (Cfg::PIECES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     P64_READ(wA, xA, wlane, xlane);
@@ -1519,6 +1522,7 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 // =============================================================================================
 static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
 static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kernel
+static int g_nt_small_tiles = 128; // default shape: launches of <= this many 256x128 tiles use 64-row tiles
 static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 128 = 4 fat waves (128x64), both on
                                    // 256x128 tiles; 256 = 8 fat waves on 256x256 tiles where N_pad allows
 
@@ -1535,6 +1539,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), (P64Cfg<8, 2, 4>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), (P64Cfg<4, 2, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 4, 2>), (P64Cfg<4, 4, 2>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), (P64Cfg<4, 1, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 1>), (NtCfg<8, 1>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
@@ -1592,14 +1597,19 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
         const bool wide = g_nt_wave_rows == 256 && g.N_pad % 256 == 0 && !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
         const bool p64 = wide && g_nt_pipe == 2 && zspan;    // 256 x 256 tiles, K tiles of 64
-        const bool p128 = g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64
+        // launches that would be a small fraction of one tile wave use 64-row tiles (default shape only)
+        const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
+        const bool p64r = g_nt_wave_rows == 64 && g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan;
+        const bool p128 = !p64r && g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64
         const bool p256 = g_nt_wave_rows == 1 && zspan;      // 256 x 128 tiles, K tiles of 64, one block per CU
-        const int bm = p128 ? 128 : NT_BM, bn = p128 ? 128 : (wide ? 256 : NT_BN);
+        const int bm = p64r ? 64 : (p128 ? 128 : NT_BM), bn = (p128 || p64r) ? 128 : (wide ? 256 : NT_BN);
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
 #define AEW_NT_GO(EPI, ABL)                                                                                   \
     do {                                                                                                      \
-        if (!ABL && p256)                                                                                      \
+        if (!ABL && p64r)                                                                                      \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), grid, dim3(128), (P64Cfg<4, 1, 2>::LDS_BYTES), st, g); \
+        else if (!ABL && p256)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 4, 2>), grid, dim3(512), (P64Cfg<4, 4, 2>::LDS_BYTES), st, g); \
         else if (!ABL && p128)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), grid, dim3(256), (P64Cfg<4, 2, 2>::LDS_BYTES), st, g); \

@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")
     ap.add_argument("--tn-small", dest="tn_small", default="", help="max_tiles,target_blocks for small-output TN ops")
     ap.add_argument("--chains", type=int, default=1, help="1: gated stack as one full-batch chain; 2: two half-batch chains")
+    ap.add_argument("--nt-small", dest="nt_small", type=int, default=-1, help="tile-count threshold for 64-row NT tiles")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
@@ -145,6 +146,8 @@ def main():
     lib.aew_set_lanes(args.lanes)
     lib.aew_set_nt_wave_rows(args.nt_wave_rows)
     lib.aew_set_nt_pipe(args.nt_pipe)
+    if args.nt_small >= 0:
+        lib.aew_set_nt_small_tiles(args.nt_small)
     if args.tn_blocks:
         lib.aew_set_tn_target_blocks(args.tn_blocks)
     if args.tn_small:

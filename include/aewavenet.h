@@ -389,6 +389,8 @@ int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
 int aew_set_nt_wave_rows(int rows);
 /* 1 (default): shapes 128 / 256 run the software-pipelined kernel; 0: the plain loop. */
 int aew_set_nt_pipe(int on);
+/* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
+int aew_set_nt_small_tiles(int n);
 /* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
 int aew_set_lanes(int on);
 

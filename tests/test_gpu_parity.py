@@ -125,23 +125,27 @@ def test_gemm_nt(dtype, epi):
     try:
         # impl 0 under every tile / wave shape of the bf16 kernel (64: 8 waves of 64x64, 128: 4 waves of
         # 128x64, 256: 256x256 tiles where N_pad allows); the shapes must agree bit for bit
-        for impl, shape, pipe in ((0, 64, 1), (1, 64, 1), (0, 0, 1), (0, 1, 1), (0, 128, 1), (0, 128, 0), (0, 256, 0), (0, 256, 1), (0, 256, 2)):
+        # (impl, shape, pipe, small): small = tile-count threshold of the 64-row tiles (0: plain 256x128)
+        for impl, shape, pipe, small in ((0, 64, 1, 0), (1, 64, 1, 0), (0, 64, 1, 128), (0, 0, 1, 0), (0, 1, 1, 0),
+                                         (0, 128, 1, 0), (0, 128, 0, 0), (0, 256, 0, 0), (0, 256, 1, 0), (0, 256, 2, 0)):
             lib.aew_set_nt_wave_rows(shape)
             lib.aew_set_nt_pipe(pipe)
+            lib.aew_set_nt_small_tiles(small)
             ws_g = _mirror(ws_c, DEV)
             p = Plan("nt")
             p.add(L.OP_GEMM_NT, _nt_case(ws_g, dtype, epi, impl), "nt")
             p.run(stream())
             torch.cuda.synchronize()
             res = {n: ws_g.get(n).float().cpu() for n in ("O0", "O1", "O2")}
-            if shape == 64:
+            if shape == 64 and small == 0:
                 results[impl] = res
             else:
                 for n in res:
-                    assert torch.equal(res[n], results[0][n]), (n, "shape", shape, "pipe", pipe)
+                    assert torch.equal(res[n], results[0][n]), (n, "shape", shape, "pipe", pipe, "small", small)
     finally:
         lib.aew_set_nt_wave_rows(64)
         lib.aew_set_nt_pipe(1)
+        lib.aew_set_nt_small_tiles(128)
     ws_e = Workspace("cpu")
     for n, t in ws_c.bufs.items():
         ws_e.bufs[n] = t.clone()
