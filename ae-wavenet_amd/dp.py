@@ -71,14 +71,58 @@ class DataParallel:
         for w in work:
             w.wait()
 
+    def train_step(self, eng, lr: float, grad_scale: float = 1.0, **adam_kw):
+        """forward + backward + Adam with every collective off the critical path that can be:
+          * EMA statistics: async all-reduce issued after the encoder / VQ part of the forward, consumed by the
+            (deferred) EMA accumulation after the backward;
+          * decoder gradients: async all-reduce between the two backward plans (under the encoder backward);
+          * encoder gradients: all-reduce after the backward, under the Adam update of the decoder range."""
+        if self.world == 1:
+            eng.forward()
+            eng.backward()
+            eng.adam_step(lr, grad_scale, **adam_kw)
+            return
+        n, lo = eng.ps.numel, eng.dec_grad_offset
+        flat = eng.ps.grads
+        work = {}
+
+        def after_decoder():
+            work["dec"] = dist.all_reduce(flat[lo:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        eng.forward(self.allreduce_ema_async)
+        eng.backward(after_decoder=after_decoder)
+        if lo > 0:
+            work["enc"] = dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work["dec"].wait()
+        eng.adam_step(lr, grad_scale, lo=lo, hi=n, **adam_kw)
+        if lo > 0:
+            work["enc"].wait()
+            eng.adam_step(lr, grad_scale, lo=0, hi=lo, count=False, **adam_kw)
+
+    def allreduce_ema_async(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
+        """Like allreduce_ema but returns the work handle (the engine then defers the EMA accumulation)."""
+        if self.world == 1:
+            return None
+        both = self._ema_flat(z_sum, n_sum)
+        if both is None:
+            self.allreduce_ema(z_sum, n_sum)
+            return None
+        return dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def _ema_flat(z_sum, n_sum):
+        if z_sum.is_contiguous() and n_sum.is_contiguous() and \
+                n_sum.data_ptr() == z_sum.data_ptr() + z_sum.numel() * z_sum.element_size() and \
+                z_sum.untyped_storage().data_ptr() == n_sum.untyped_storage().data_ptr():
+            return torch.as_strided(z_sum, (z_sum.numel() + n_sum.numel(),), (1,))
+        return None
+
     def allreduce_ema(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
         if self.world == 1:
             return
         # the engine allocates n_sum right behind z_sum: one collective instead of two
-        if z_sum.is_contiguous() and n_sum.is_contiguous() and \
-                n_sum.data_ptr() == z_sum.data_ptr() + z_sum.numel() * z_sum.element_size() and \
-                z_sum.untyped_storage().data_ptr() == n_sum.untyped_storage().data_ptr():
-            both = torch.as_strided(z_sum, (z_sum.numel() + n_sum.numel(),), (1,))
+        both = self._ema_flat(z_sum, n_sum)
+        if both is not None:
             dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
             return
         dist.all_reduce(z_sum, op=dist.ReduceOp.SUM, group=self.group)

@@ -270,6 +270,15 @@ class TrainEngine:
                    "d.bn.linear", TAG_VQ)
             self.enc.build_backward(bw, need_input_grad=True)
         self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads the side-lane encoder wgrad slabs
+        # Deferred EMA (data parallel): the EMA accumulators are not read again before the codebook
+        # refresh, so the cross-rank sum of z_sum | n_sum can run asynchronously under the whole
+        # decoder forward + backward; fwd_b_noema / ema_plan are fwd_b without / only its leading vq.ema op
+        self.fwd_b_noema, self.ema_plan = None, None
+        if fb.labels and fb.labels[0] == "vq.ema":
+            self.fwd_b_noema, self.ema_plan = Plan("fwd_b_noema"), Plan("ema")
+            self.fwd_b_noema.ops, self.fwd_b_noema.labels = fb.ops[1:], fb.labels[1:]
+            self.ema_plan.ops, self.ema_plan.labels = fb.ops[:1], fb.labels[:1]
+        self._ema_work = None
         # The same ops as two plans, cut after the decoder's gradients are final: lets a data-parallel
         # caller start reducing the decoder gradients (the contiguous tail of the flat buffer) while the
         # bottleneck / encoder backward still runs (dp.DataParallel.backward_allreduce)
@@ -370,12 +379,25 @@ class TrainEngine:
             plan.run(self._stream())
 
     def forward(self, ema_allreduce=None, timing=False):
-        """timing=True forces eager launches (the per-op event timing needs them)."""
+        """timing=True forces eager launches (the per-op event timing needs them).
+        ema_allreduce(z_sum, n_sum): cross-rank sum of the EMA statistics.  If it returns a work handle
+        (async collective) the EMA accumulation is deferred to finish_ema(), called by backward()."""
         self._run(self.fwd_a, timing)
         if ema_allreduce is not None and self.bn_type == "vqvae-ema":
-            ema_allreduce(self.z_sum, self.n_sum)
+            work = ema_allreduce(self.z_sum, self.n_sum)
+            if work is not None and self.ema_plan is not None:
+                self._ema_work = work
+                self._run(self.fwd_b_noema, timing)
+                return self.loss_buf[0]
         self._run(self.fwd_b, timing)
         return self.loss_buf[0]
+
+    def finish_ema(self, timing=False):
+        """Deferred vq.ema (see forward): wait for the statistics' all-reduce, then accumulate."""
+        if self._ema_work is not None:
+            self._ema_work.wait()
+            self._ema_work = None
+            self._run(self.ema_plan, timing)
 
     def backward(self, timing=False, after_decoder=None):
         """after_decoder: optional callback invoked between the decoder part of the backward (all
@@ -388,15 +410,27 @@ class TrainEngine:
             self._run(self.bwd_a, timing)
             after_decoder()
             self._run(self.bwd_b, timing)
+        self.finish_ema(timing)
         if self.bn_type == "vqvae-ema" and self.update_codebook_every_step:
             self._run(self.cb, timing)
 
     def update_codebook(self):
+        self.finish_ema()
         self.cb.run(self._stream())
 
-    def adam_step(self, lr: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8):
-        self.step_count += 1
+    def adam_step(self, lr: float, grad_scale: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                  lo: int = 0, hi: Optional[int] = None, count: bool = True):
+        """One Adam step over the flat buffer, or over its element range [lo, hi) (multiples of 4): a
+        data-parallel caller updates the decoder tail while the encoder gradients are still being
+        reduced (`count=False` on all but the first range of a step)."""
+        if count:
+            self.step_count += 1
+        hi = self.ps.numel if hi is None else hi
+        assert lo % 4 == 0 and (hi % 4 == 0 or hi == self.ps.numel) and 0 <= lo < hi <= self.ps.numel
         a = self.opt.array()[0].u.adam
+        a.p, a.g = self.ps.params.data_ptr() + 4 * lo, self.ps.grads.data_ptr() + 4 * lo
+        a.m, a.v = self.adam_m.data_ptr() + 4 * lo, self.adam_v.data_ptr() + 4 * lo
+        a.n = hi - lo
         a.lr, a.beta1, a.beta2, a.eps = lr, betas[0], betas[1], eps
         a.bc1 = 1.0 - betas[0] ** self.step_count
         a.bc2 = 1.0 - betas[1] ** self.step_count

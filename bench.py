@@ -165,12 +165,12 @@ def main():
     gscale = 1.0
 
     def step():
-        eng.forward(ema_ar)
         if dp is not None:
-            dp.backward_allreduce(eng)          # decoder gradients reduced under the encoder backward
+            dp.train_step(eng, args.lr, gscale)     # collectives overlapped (EMA stats, decoder / encoder grads)
         else:
+            eng.forward()
             eng.backward()
-        eng.adam_step(args.lr, gscale)
+            eng.adam_step(args.lr, gscale)
 
     def fence():
         torch.cuda.synchronize()

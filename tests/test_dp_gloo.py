@@ -59,6 +59,33 @@ def _worker(rank, world, port, q):
         d.backward_allreduce(eng)
         assert order == ["dec", "hook", "enc"]
         g_overlap = eng.ps.grads[:n].tolist()
+        # full overlapped step (EMA statistics async + deferred, decoder / encoder gradient halves, ranged Adam)
+        calls = []
+
+        def fake_forward(ema_allreduce=None, timing=False):
+            eng.z_sum.fill_(10.0 * (rank + 1))
+            eng.n_sum.fill_(100.0 * (rank + 1))
+            w = ema_allreduce(eng.z_sum, eng.n_sum)
+            assert w is not None                      # async handle -> the engine defers the EMA accumulation
+            eng._ema_work = w
+            calls.append("fwd")
+
+        def fake_backward2(timing=False, after_decoder=None):
+            fake_backward(timing, after_decoder)
+            eng._ema_work.wait()
+            eng._ema_work = None
+            calls.append(("ema", eng.z_sum[0, 0].item(), eng.n_sum[-1].item()))
+
+        def fake_adam(lr, gs=1.0, lo=0, hi=None, count=True, **kw):
+            hi = n if hi is None else hi
+            calls.append(("adam", lo, hi, count, eng.ps.grads[lo].item(), eng.ps.grads[hi - 1].item()))
+
+        eng.forward, eng.backward, eng.adam_step = fake_forward, fake_backward2, fake_adam
+        order.clear()
+        d.train_step(eng, 1e-3)
+        assert calls[0] == "fwd" and calls[1] == ("ema", 30.0, 300.0)            # summed over both ranks
+        assert calls[2] == ("adam", lo, n, True, 3.0 * lo, 3.0 * (n - 1))          # decoder range first, reduced
+        assert calls[3] == ("adam", 0, lo, False, 0.0, 3.0 * (lo - 1))            # then the head, same step count
         eng.z_sum.fill_(rank + 1.0)
         eng.n_sum.fill_(2.0 * (rank + 1))
         d.allreduce_ema(eng.z_sum, eng.n_sum)

@@ -23,9 +23,28 @@ for it in range(3):
     g = eng.ps.grads[:eng.ps.numel]
     rel = (g - ref).abs().max().item() / ref.abs().max().item()
     assert rel < 1e-5, rel      # bias sums are accumulated with fp32 atomics: round-off level only
+# full overlapped step against the plain one: same parameters after two optimizer steps
+import copy
+state = {k: eng.ws.get(k).clone() for k in ("params", "adam.m", "adam.v", "bn.emb", "bn.ema_numer", "bn.ema_denom")}
+def restore():
+    for k, v in state.items():
+        eng.ws.get(k).copy_(v)
+    eng.step_count = 0
+restore()
+for it in range(2):
+    eng.forward(); eng.backward(); eng.adam_step(1e-3)
+torch.cuda.synchronize()
+p_ref = eng.ps.params[:eng.ps.numel].clone(); e_ref = eng.emb.clone()
+restore()
+for it in range(2):
+    d.train_step(eng, 1e-3)
+torch.cuda.synchronize()
+dp_ = (eng.ps.params[:eng.ps.numel] - p_ref).abs().max().item()
+de_ = (eng.emb - e_ref).abs().max().item()
+assert dp_ < 1e-5 and de_ == 0.0, (dp_, de_)
 torch.cuda.synchronize(); t = time.perf_counter()
 for it in range(10):
-    eng.forward(d.allreduce_ema); d.backward_allreduce(eng); eng.adam_step(1e-4)
+    d.train_step(eng, 1e-4)
 torch.cuda.synchronize()
-print(f"overlapped-exchange path ok; {(time.perf_counter() - t) / 10 * 1e3:.3f} ms/step with 1-rank collectives")
+print(f"overlapped-exchange path ok (params {dp_:.1e}, codebook exact); {(time.perf_counter() - t) / 10 * 1e3:.3f} ms/step with 1-rank collectives")
 dist.destroy_process_group()
