@@ -35,13 +35,6 @@ __device__ __forceinline__ uint2 pack4_bf16(const float v[4]) {
     r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
     return r;
 }
-__device__ __forceinline__ void unpack4_bf16(uint2 r, float v[4]) {
-    v[0] = __uint_as_float(r.x << 16);
-    v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16);
-    v[3] = __uint_as_float(r.y & 0xffff0000u);
-}
-
 // ---- view access: W (4 or 8) consecutive channels of one row ---------------------------------
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -49,11 +42,6 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
     // v_cvt_pk_bf16_f32 (round-to-nearest-even, same as torch .to(bfloat16))
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
-}
-
-__device__ __forceinline__ bool view_row(const aew_view_t& v, int m, int64_t& row) {
-    row = (int64_t)m * v.row_step + v.row_off;
-    return row >= v.row_lo && row < v.row_hi;
 }
 
 // byte pointer to channel 0 of the view row that GEMM row m maps to; nullptr if the row does not

@@ -159,18 +159,6 @@ __device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n,
 }
 
 // =============================================================================================
-// segment iterator: walks K tiles across the segment table in order
-// =============================================================================================
-struct KIter {
-    int seg, kin, kglob;
-    __device__ __forceinline__ void init() { seg = 0; kin = 0; kglob = 0; }
-    __device__ __forceinline__ void advance(const aew_seg_t* segs, int bk) {
-        kin += bk; kglob += bk;
-        if (kin >= segs[seg].k_len) { ++seg; kin = 0; }
-    }
-};
-
-// =============================================================================================
 // NT kernel, bf16: block tile 256 (rows m) x 128 (channels n), BK = 32.  Operand tiles go
 // global -> LDS by 16-byte LDS-DMA into a 3-stage ring (3 x 24 KiB = 72 KiB, so TWO blocks are
 // resident per CU and cover each other's barrier / epilogue stalls); tile t+2 is issued while
@@ -209,12 +197,6 @@ struct NtCfg {
     static constexpr int STAGE_BYTES = (NT_BM + BN) * NT_ROWB;
     static constexpr int LDS_BYTES = NT_STAGES * STAGE_BYTES;
 };
-
-__device__ __forceinline__ const char* seg_row_ptr(const aew_seg_t& s, int b, int m, int esize) {
-    const int64_t row = (int64_t)m * s.row_step + s.row_off;
-    if (row < s.row_lo || row >= s.row_hi) return nullptr;
-    return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
-}
 
 // Per-lane source pointers of the X and W pieces a wave stages per K tile.  Computed once per
 // segment (X) / once per kernel (W) and advanced by one K tile per issue, so the K loop carries no
@@ -691,11 +673,6 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
 // K_total is a multiple of 64 (ABI), so the step count is even and the loop is unrolled by two
 // (register sets A and B swap roles).
 // =============================================================================================
-__device__ __forceinline__ bf16x8_t lds_read16(uint32_t addr, int off_is_imm_dummy = 0) {
-    bf16x8_t r;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-    return r;
-}
 #define AEW_DS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
 #define AEW_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
