@@ -180,6 +180,14 @@ __device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n,
 #define NT_BK 32
 #define NT_ROWB 64                                  // bytes per staged row (32 bf16)
 #define NT_STAGES 3
+// inline-asm forms used where instruction order / waits are placed by hand
+#define AEW_DS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+#define AEW_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#ifndef AEW_NT_COUNTED
+#define AEW_NT_COUNTED 0     /* 1: thin shape with asm fragment reads, counted lgkmcnt waits and hand-placed
+                                MFMA / LDS-DMA order.  Bit-identical, measured null (NT 4.84 vs 4.84 ms per
+                                step), so the compiler-scheduled loop stays the default */
+#endif
 #ifndef AEW_NT_SETPRIO
 #define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
 #endif
@@ -586,7 +594,18 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
         stage = (stage + 1 == NT_STAGES) ? 0 : stage + 1;
         {
             bf16x8_t wf[4], xf[MT];
-            if (!(abl & 2)) {
+            constexpr bool COUNTED = AEW_NT_COUNTED && !ABL && MT == 4;
+            if constexpr (COUNTED) {
+                // fragment reads as inline asm in consumption order, so the waits below can be COUNTED: the
+                // first MFMA group needs W0-3 + X0 (5 of 8 reads), each later group one more X fragment.  (The
+                // compiler waits lgkmcnt(0) before the first MFMA whenever it sees the reads itself.)
+                const uint32_t sb = (uint32_t)(uintptr_t)AEW_LDS_PTR(st);
+                const uint32_t wa = sb + woff[0], xa = sb + xoff[0];       // tile i / j adds i*1024 bytes
+                AEW_DS_READ16(wf[0], wa, 0); AEW_DS_READ16(wf[1], wa, 1024);
+                AEW_DS_READ16(wf[2], wa, 2048); AEW_DS_READ16(wf[3], wa, 3072);
+                AEW_DS_READ16(xf[0], xa, 0); AEW_DS_READ16(xf[1], xa, 1024);
+                AEW_DS_READ16(xf[2], xa, 2048); AEW_DS_READ16(xf[3], xa, 3072);
+            } else if (!(abl & 2)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff[i]);
 #pragma unroll
@@ -605,8 +624,40 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
                 lap(3);
             }
             // tile t+2 goes into the stage that was computed at step t-1 (every wave is past it: barrier)
-            if (!(abl & 4)) nt_issue_bf16<MT, NB>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
-            if (!(abl & 1)) {
+            if (!COUNTED && !(abl & 4)) nt_issue_bf16<MT, NB>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
+            if constexpr (COUNTED) {
+                // hand-placed: wait for what the group needs, 4 MFMAs, one LDS-DMA piece of tile t+2
+                // (asm MFMAs with a memory clobber so that neither they nor the DMA builtins move)
+                char* dstage = smem + is.slot * Cfg::STAGE_BYTES;
+                auto piece = [&](int q) {
+                    if (q < Cfg::XP) {
+                        glds16(P.x[q], dstage + (wave * Cfg::XP + q) * 1024);
+                        P.x[q] += P.xinc[q];
+                    } else if (q < Cfg::XP + Cfg::WP) {
+                        const int w = q - Cfg::XP;
+                        glds16(P.w[w], dstage + NT_BM * NT_ROWB + (wave * Cfg::WP + w) * 1024);
+                        P.w[w] += P.winc;
+                    }
+                };
+#define AEW_MFMA4(J)                                                                                          \
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t" \
+                             "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %8, %3"        \
+                             : "+v"(acc[0][J]), "+v"(acc[1][J]), "+v"(acc[2][J]), "+v"(acc[3][J])                     \
+                             : "v"(wf[0]), "v"(wf[1]), "v"(wf[2]), "v"(wf[3]), "v"(xf[J]) : "memory")
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]));
+                AEW_MFMA4(0);
+                piece(0);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xf[1]));
+                AEW_MFMA4(1);
+                piece(1);
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xf[2]));
+                AEW_MFMA4(2);
+                piece(2);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[3]));
+                AEW_MFMA4(3);
+#undef AEW_MFMA4
+                static_assert(!COUNTED || Cfg::XP + Cfg::WP == 3, "three pieces per wave and K tile in the thin shape");
+            } else if (!(abl & 1)) {
                 if (AEW_NT_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)           // j outer: X fragments are consumed in arrival order
@@ -620,7 +671,7 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
 #pragma unroll
                 for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(xf[j]));
             }
-            if (!ABL) {
+            if (!ABL && !COUNTED) {
                 // shape of the step: every fragment read in flight first, then the MFMAs with the
                 // LDS-DMA pieces of tile t+2 threaded between them (one piece per 4 MFMAs)
                 __builtin_amdgcn_sched_group_barrier(0x100, 4 + MT, 0);            // DS reads
@@ -636,6 +687,13 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
         lap(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the idle-tail LDS-DMA must land before the LDS is released
+    if (AEW_NT_COUNTED && !ABL && MT == 4) {           // asm MFMAs are invisible to the compiler's hazard logic
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
     if (clk) {
         lap(5);                                        // drain of the idle-tail DMA
         nt_epilogue<EPI, ABL, MT>(g, acc, b, m0, n0, wm, wn, lane);
@@ -673,8 +731,6 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
 // K_total is a multiple of 64 (ABI), so the step count is even and the loop is unrolled by two
 // (register sets A and B swap roles).
 // =============================================================================================
-#define AEW_DS_READ16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
-#define AEW_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
 template <int MT>
 __device__ __forceinline__ void nt_read_frags(uint32_t wa, uint32_t xa, bf16x8_t (&wf)[4], bf16x8_t (&xf)[MT]) {
