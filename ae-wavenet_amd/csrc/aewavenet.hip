@@ -69,7 +69,6 @@ extern "C" int aew_sizeof(int which) {
 // waiting on an event recorded in the capturing stream).
 // ---------------------------------------------------------------------------------------------
 static int g_lanes = 1;
-static hipStream_t g_side_stream = nullptr;
 static std::vector<hipEvent_t> g_lane_ev;
 static size_t g_lane_ev_next = 0;
 
@@ -94,25 +93,36 @@ static int edge(hipStream_t from, hipStream_t to) {          // `to` continues a
     return (int)hipStreamWaitEvent(to, e, 0);
 }
 
+#define AEW_MAX_SIDE 4
+static hipStream_t g_side[AEW_MAX_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [1..AEW_MAX_SIDE]
+
 static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, bool timing) {
     const bool lanes = g_lanes && !timing;
-    bool main_ahead = true;          // main has work the side stream has not been ordered after
-    bool side_open = false;          // side has work main has not joined
+    bool main_ahead[AEW_MAX_SIDE + 1];   // main has work side stream k has not been ordered after
+    bool open[AEW_MAX_SIDE + 1];         // side stream k has work that main (or a joining side op) has not waited for
+    for (int k = 0; k <= AEW_MAX_SIDE; ++k) { main_ahead[k] = true; open[k] = false; }
     int rc = 0;
     for (int i = 0; i < n && rc == 0; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         hipStream_t target = st;
-        if (lanes && ops[i].lane == 1) {
-            if (!g_side_stream) {
-                hipError_t e = hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking);
+        const int lane = ops[i].lane;
+        if (lane < 0 || lane > AEW_MAX_SIDE) { rc = AEW_E_ARG; if (fail_index) *fail_index = i; break; }
+        if (lanes && lane >= 1) {
+            if (!g_side[lane]) {
+                hipError_t e = hipStreamCreateWithFlags(&g_side[lane], hipStreamNonBlocking);
                 if (e != hipSuccess) { rc = (int)e; break; }
             }
-            if (main_ahead) { rc = edge(st, g_side_stream); main_ahead = false; }
-            target = g_side_stream;
-            side_open = true;
+            if (main_ahead[lane]) { rc = edge(st, g_side[lane]); main_ahead[lane] = false; }
+            if (ops[i].join)                                  // side join: after the other side lanes too
+                for (int k = 1; k <= AEW_MAX_SIDE && rc == 0; ++k)
+                    if (k != lane && open[k]) rc = edge(g_side[k], g_side[lane]);
+            target = g_side[lane];
+            open[lane] = true;
         } else {
-            if (ops[i].join && side_open) { rc = edge(g_side_stream, st); side_open = false; }
-            main_ahead = true;
+            if (ops[i].join)
+                for (int k = 1; k <= AEW_MAX_SIDE && rc == 0; ++k)
+                    if (open[k]) { rc = edge(g_side[k], st); open[k] = false; }
+            for (int k = 1; k <= AEW_MAX_SIDE; ++k) main_ahead[k] = true;
         }
         if (rc != 0) { if (fail_index) *fail_index = i; break; }
         if (timing) {
@@ -130,10 +140,11 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
         }
         if (rc != 0 && fail_index) *fail_index = i;
     }
-    if (side_open) {                                         // implicit join (also on the error path,
-        const int jr = edge(g_side_stream, st);              // so a capture is never left forked)
-        if (rc == 0) rc = jr;
-    }
+    for (int k = 1; k <= AEW_MAX_SIDE; ++k)                  // implicit join (also on the error path,
+        if (open[k]) {                                       // so a capture is never left forked)
+            const int jr = edge(g_side[k], st);
+            if (rc == 0) rc = jr;
+        }
     return rc;
 }
 

@@ -228,8 +228,8 @@ class TrainEngine:
         if bn == "vqvae-ema" and self.loss_mode == "head":
             nll_scale = 0.0
         self.dec.build_backward(bw, nll_scale)
-        with bw.side():                                        # after the decoder's last wgrad, same lane
-            self.unpack_dec.emit(bw, "unpack grads (decoder)")
+        with bw.side(1):                                       # after every decoder wgrad on any side lane
+            self.unpack_dec.emit(bw, "unpack grads (decoder)", join=True)
         if self.enc is not None:
             dcode = self.dec.dlc_src                      # d(loss)/d(code) [B][Ne][dp]
             Ep = ru(hps.enc_n_out, 64)

@@ -121,13 +121,16 @@ class Plan:
         self.keep: list = []          # device tables etc. that must outlive the plan
         self.lane = 0                 # lane given to ops added next (see aew_op_t in aewavenet.h)
 
-    def side(self):
-        """`with plan.side():` — ops added inside are off the critical chain (lane 1)."""
+    N_SIDE = 4
+
+    def side(self, lane: int = 1):
+        """`with plan.side(k):` — ops added inside are off the critical chain, on side lane k (1..4)."""
         plan = self
+        assert 1 <= lane <= Plan.N_SIDE
 
         class _Side:
             def __enter__(self):
-                self.prev, plan.lane = plan.lane, 1
+                self.prev, plan.lane = plan.lane, lane
 
             def __exit__(self, *a):
                 plan.lane = self.prev

@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--tn-small", dest="tn_small", default="", help="max_tiles,target_blocks for small-output TN ops")
     ap.add_argument("--chains", type=int, default=1, help="1: gated stack as one full-batch chain; 2: two half-batch chains")
     ap.add_argument("--nt-small", dest="nt_small", type=int, default=-1, help="tile-count threshold for 64-row NT tiles")
+    ap.add_argument("--side-lanes", dest="side_lanes", type=int, default=0, help="side lanes the wgrads rotate over (1..4)")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     args = ap.parse_args()
 
@@ -155,6 +156,8 @@ def main():
         lib.aew_set_tn_small(a, b)
     from ae_wavenet_amd import engine as _E
     _E.DecoderPlan.split_chains = args.chains == 2
+    if args.side_lanes:
+        _E.DecoderPlan.n_side_lanes = args.side_lanes
     hps, eng = build_engine(args, device)
     if dp is not None:
         dp.broadcast_params(eng)

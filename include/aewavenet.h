@@ -341,19 +341,20 @@ enum {
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
- * critical chain (weight gradients, bias column sums, weight packing) so that they execute on a
- * second HIP stream / a parallel hipGraph branch and fill the tail of the chain's kernels:
- *   lane 0 (main)  runs after the preceding lane-0 ops; it waits for preceding lane-1 ops only
- *                  if `join` != 0.  The end of the plan is an implicit join.
- *   lane 1 (side)  runs after ALL ops that precede it in the plan (both lanes).
+ * critical chain (weight gradients, bias column sums, weight packing) so that they execute on side
+ * HIP streams / parallel hipGraph branches and fill the tails of the chain's kernels:
+ *   lane 0 (main)      runs after the preceding lane-0 ops; it waits for preceding side ops only if
+ *                      `join` != 0.  The end of the plan is an implicit join.
+ *   lane k = 1..4      runs after ALL lane-0 ops that precede it in the plan and after the preceding ops
+ *                      of the SAME lane; with `join` != 0 also after the preceding ops of every other side
+ *                      lane.  Ops on different side lanes are otherwise unordered (they may run concurrently).
  * Any serial execution in plan order is a valid schedule (that is what the timing mode and
- * aew_set_lanes(0) do), so a lane assignment is correct iff no lane-0 op without `join` reads or
- * overwrites what an earlier, un-joined lane-1 op writes or reads. */
+ * aew_set_lanes(0) do), so a lane assignment is correct iff it respects every true dependency. */
 typedef struct {
     int32_t kind;
     int32_t tag;                 /* caller-defined label, reported by the timing interface    */
-    int32_t lane;                /* 0 main, 1 side                                             */
-    int32_t join;                /* lane-0 op: wait for every preceding lane-1 op first        */
+    int32_t lane;                /* 0 main, 1..4 side lanes                                    */
+    int32_t join;                /* wait for the preceding ops of all (other) side lanes first */
     union {
         aew_gemm_nt_t nt; aew_gemm_tn_t tn; aew_copy_table_t copy; aew_vq_nearest_t vqn;
         aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;
