@@ -528,6 +528,13 @@ class DecoderPlan:
         pk = self.pk
         plan.add(L.OP_SOFTMAX_NLL, self._softmax(True, nll_scale), "softmax_grad", TAG_LOSS)
         plan.zero(self.ws, p + "colsum_fg")
+        # gradients of the post network and of the upper half of the stack are unpacked mid-chain (side
+        # lane), so that less unpack work is left when the chain ends (shorter drain before the encoder
+        # backward / before a data-parallel caller may start reducing the decoder gradients)
+        early_tbl = getattr(self, "unpack_early_tbl", None)
+        late_tbl = pk.unpack_tbl
+        if early_tbl is not None:
+            pk.unpack_tbl = early_tbl
         # ---- post network
         if ps.has(p + "post2.bias"):
             self._colsum(plan, self.dlogits, w, Q, ps.ptr(p + "post2.bias", True), label="db.post2")
@@ -592,6 +599,12 @@ class DecoderPlan:
                 out0=dx.view(hi=lg.in_len),
                 aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=impl), f"dx.{l}", TAG_DX)
             dx_next = dx
+            if early_tbl is not None and l == NL // 2:
+                with plan.side(1):                                 # after the wgrads issued so far, on any lane
+                    early_tbl.emit(plan, "unpack grads (decoder, upper layers)", join=True)
+                pk.unpack_tbl = late_tbl
+                early_tbl = None
+        pk.unpack_tbl = late_tbl
         dx0 = dx_next
         # ---- skip weights of all layers: ONE wgrad with NL segments (mirror of the deferred skip GEMM):
         # dW_skp[s][l*Dp + k] = sum_t dskp[t][s] * z_l[t + skip_lead_l][k].  640 tiles x batch fill the

@@ -89,6 +89,7 @@ class TrainEngine:
             lc_src = self.mel_cl
         self.dec = DecoderPlan(ws, ps, hps, g, B, dec_pre, hps.n_lc_in, lc_src, self.in_wav, self.in_voice,
                                self.in_jitter, take_compat, self.pk_dec, impl)
+        self.dec.unpack_early_tbl = CopyTableBuilder(ws, "tbl.unpack_dec_early")
         self._build()
         self.adam_state = None
         self.step_count = 0
