@@ -64,6 +64,10 @@ __device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiUni& 
 #pragma unroll
         for (int r = 0; r < W; ++r) v[r] = v[r] + a[r];
     }
+    if (fl & AEW_EF_RELU_POST) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
     if (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)) {
         float a[W], w[W];
         row_load<W>(R.a1, U.dt_a1, n, a);
@@ -318,6 +322,10 @@ __device__ __forceinline__ void epi_store8_pf(const EpiUni& U, const EpiRow& R, 
         unpack8_bf16(a0raw, a);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = v[r] + a[r];
+    }
+    if (fl & AEW_EF_RELU_POST) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
     }
     if (fl & (AEW_EF_MUL_POS1 | AEW_EF_OUT1_POS1)) {
         float a[8], w[8];

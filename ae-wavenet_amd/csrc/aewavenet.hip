@@ -93,8 +93,8 @@ static int edge(hipStream_t from, hipStream_t to) {          // `to` continues a
     return (int)hipStreamWaitEvent(to, e, 0);
 }
 
-#define AEW_MAX_SIDE 4
-static hipStream_t g_side[AEW_MAX_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [1..AEW_MAX_SIDE]
+#define AEW_MAX_SIDE 5
+static hipStream_t g_side[AEW_MAX_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [1..AEW_MAX_SIDE]
 
 static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, bool timing) {
     const bool lanes = g_lanes && !timing;
@@ -119,7 +119,10 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
             target = g_side[lane];
             open[lane] = true;
         } else {
-            if (ops[i].join)
+            if (ops[i].join >= 10 && ops[i].join <= 10 + AEW_MAX_SIDE) {      // one side lane only
+                const int k = ops[i].join - 10;
+                if (k >= 1 && open[k]) { rc = edge(g_side[k], st); open[k] = false; }
+            } else if (ops[i].join)
                 for (int k = 1; k <= AEW_MAX_SIDE && rc == 0; ++k)
                     if (open[k]) { rc = edge(g_side[k], st); open[k] = false; }
             for (int k = 1; k <= AEW_MAX_SIDE; ++k) main_ahead[k] = true;

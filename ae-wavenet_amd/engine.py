@@ -177,6 +177,10 @@ class Packer:
 class DecoderPlan:
     """Conditioning path + gated stack + post network + NLL, forward and backward."""
 
+    EARLY_LANE = 5            # side lane of the early halves below (the wgrads rotate over lanes 1..n_side_lanes)
+    split_multiseg = False    # True: skip-sum / cond-gradient GEMMs as two halves, the early half on a side lane.
+                              # Measured 8.31-8.34 vs 8.34-8.39 ms/step, but the bf16 partial sum costs accuracy (one
+                              # gradient at 15.1 % of its max against the oracle, limit 15 %): off
     n_side_lanes = 4          # weight gradients / column sums rotate over this many side lanes (1..4): they are
                               # mutually independent, so they need no ordering among themselves.  Measured
                               # ms/step: 1 lane 8.44, 2: 8.54, 3: 8.59, 4: 8.19 (one lane per op kind: 8.93)
@@ -225,6 +229,7 @@ class DecoderPlan:
         self.pf = [M(f"pf{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
         self.pg = [M(f"pg{l}", lg.out_len, self.Dp, BF) for l, lg in enumerate(g.layers)]
         self.h0 = M("h0", self.w, self.Sp, BF)
+        self.skp_part = M("skp_part", self.w, self.Sp, BF)      # skip sum of the lower half of the stack (pre-relu)
         self.h1 = M("h1", self.w, self.Pp, BF)
         self.logits = M("logits", self.w, self.Qp, F3)
         self.nll = ws.alloc(p + "nll", B * self.w, torch.float32)
@@ -240,6 +245,7 @@ class DecoderPlan:
         self.dfg = [M(f"dfg{l}", lg.out_len, 2 * self.Dp, BF) for l, lg in enumerate(g.layers)]
         self.colsum_fg = ws.alloc(p + "colsum_fg", B * self.NL * 2 * self.Dp, torch.float32)
         self.dcond = M("dcond", self.T, self.Cp, BF)
+        self.dcond_part = M("dcond_part", self.T, self.Cp, BF)  # cond gradient of the upper half of the stack
         self.dups = [M(f"d{m.name[len(p):]}", m.rows, self.Cp, BF) for m in self.ups_in]
         self.dlcj = M("dlcj", self.Ne, self.Lp, F3)
         # gradient w.r.t. the LC source (fp32, same shape as lc_src)
@@ -276,8 +282,14 @@ class DecoderPlan:
         self.tn: Dict[str, L.GemmTN] = {}         # wgrad ops by name (built in build_backward)
         self.gbuf: Dict[str, Tuple[int, int, int]] = {}  # name -> (ptr, slab stride, slabs)
         Kfg = 2 * Rp + Cp
-        self.VfgT = self._wmat("VfgT", Cp, NL * 2 * Dp)
-        self.Wskp = self._wmat("skp_all", Sp, NL * Dp)
+        # the 20-segment GEMMs (skip sum, cond gradient) run as two halves: the half whose inputs exist
+        # mid-chain goes to a side lane (fills tile-wave tails), the other half adds it as aux
+        self.n_lo = NL // 2 if (self.split_multiseg and NL >= 4) else NL      # layers [0, n_lo) | [n_lo, NL)
+        n_lo, n_hi = self.n_lo, NL - self.n_lo
+        self.VfgT_lo = self._wmat("VfgT_lo", Cp, n_lo * 2 * Dp)
+        self.VfgT_hi = self._wmat("VfgT_hi", Cp, max(n_hi, 1) * 2 * Dp)
+        self.Wskp_lo = self._wmat("skp_lo", Sp, n_lo * Dp)
+        self.Wskp_hi = self._wmat("skp_hi", Sp, max(n_hi, 1) * Dp)
         # base layer as a row gather: transposed fp32 copy [Q][Rp] (wavenet.py:348-351)
         self.Wbase_t = self._wmat("base_t", Q, Rp, F3)
         pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], self.Wbase_t, 0, [1, Rp])
@@ -298,8 +310,9 @@ class DecoderPlan:
                     # conditioning projection [D][Cc][1], first Clc columns only
                     pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
                            Wfg, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1])
+                    Vt, lv, nv = (self.VfgT_lo, l, self.n_lo) if l < self.n_lo else (self.VfgT_hi, l - self.n_lo, NL - self.n_lo)
                     pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
-                           self.VfgT, l * 2 * Dp + row0, [32, 1, NL * 2 * Dp])
+                           Vt, lv * 2 * Dp + row0, [32, 1, nv * 2 * Dp])
             # residual 1x1 (forward) and [res | skip]^T (backward dz); the skip 1x1s of ALL layers
             # form one matrix Wskp [Sp][NL*Dp] for the deferred skip GEMM (wavenet.py:103,357)
             Nrs = Sp if last else Rp + Sp
@@ -310,7 +323,8 @@ class DecoderPlan:
             if not last:
                 pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], Wrs, 0, [Dp, 1])
                 pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], WrsT, 0, [1, Nrs])
-            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], self.Wskp, l * Dp, [NL * Dp, 1])
+            Ws, ls, ns = (self.Wskp_lo, l, self.n_lo) if l < self.n_lo else (self.Wskp_hi, l - self.n_lo, NL - self.n_lo)
+            pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], Ws, ls * Dp, [ns * Dp, 1])
             pk.rec(q + "dil_skp.weight", 0, [D, 1], [S, D], WrsT, so, [1, Nrs])
         # post network
         self.Wp1, self.Wp1T = self._wmat("p1", Pp, Sp), self._wmat("p1T", Sp, Pp)
@@ -457,12 +471,29 @@ class DecoderPlan:
                         BF, P_l, Rp, Rp, nb, [self.z[l].seg(Dp, b0=b0)], self.Wrs[l].ptr, flags=L.EF_ADD_AUX0,
                         out0=self.x[l + 1].view(b0=b0), aux0=x.view(row_off=lg.dil, b0=b0), impl=impl),
                         f"G2.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_G2)
+            if self.n_lo < NL and l == self.n_lo - 1:
+                # early half of the skip sum (layers 0 .. n_lo-1): all its inputs exist now
+                plan.lane = 0
+                segs = [self.z[k].seg(Dp, row_off=g.layers[k].skip_lead) for k in range(self.n_lo)]
+                with plan.side(self.EARLY_LANE):
+                    plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp_lo.ptr,
+                                                   out0=self.skp_part.view(), impl=impl), "skip_lo", TAG_G2,
+                             join=n_chains > 1)
         plan.lane = 0
         # skip path of all layers as ONE GEMM: relu(sum_l Wk_l . z_l[u + skip_lead_l]) -> h0
         # (wavenet.py:103,355-359).  K = NL*256; the fp32 skip sum never touches HBM.
-        segs = [self.z[l].seg(Dp, row_off=lg.skip_lead) for l, lg in enumerate(g.layers)]
-        plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp.ptr, flags=L.EF_RELU,
-                                       out0=self.h0.view(), impl=impl), "skip_all", TAG_G2, join=True)
+        # With split_multiseg the layers [0, n_lo) were already summed on a side lane right after
+        # G1 of layer n_lo-1 (skp_part, below in the layer loop); this GEMM adds them and applies the relu.
+        lo = self.n_lo
+        if lo < NL:
+            segs = [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(lo, NL)]
+            plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp_hi.ptr,
+                                           flags=L.EF_ADD_AUX0 | L.EF_RELU_POST, out0=self.h0.view(),
+                                           aux0=self.skp_part.view(), impl=impl), "skip_all", TAG_G2, join=True)
+        else:
+            segs = [self.z[l].seg(Dp, row_off=lg.skip_lead) for l, lg in enumerate(g.layers)]
+            plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp_lo.ptr, flags=L.EF_RELU,
+                                           out0=self.h0.view(), impl=impl), "skip_all", TAG_G2, join=True)
         # 7. post network (wavenet.py:359-360)
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Pp, Pp, B, [self.h0.seg(Sp)], self.Wp1.ptr,
                                        flags=L.EF_BIAS | L.EF_RELU, out0=self.h1.view(),
@@ -567,6 +598,11 @@ class DecoderPlan:
             plan.add(L.OP_GEMM_NT, make_nt(BF, P_l, Dp, Dp, B, segs, self.WrsT[l].ptr, epi=L.EPI_DFG,
                                            aux0=self.pf[l].view(), aux1=self.pg[l].view(),
                                            out0=self.dfg[l].view(), impl=impl), f"dz.{l}", TAG_DZ)
+            if self.n_lo < NL and l == self.n_lo:
+                hsegs = [self.dfg[k].seg(2 * Dp, row_off=-g.layers[k].cond_lead) for k in range(self.n_lo, NL)]
+                with plan.side(self.EARLY_LANE):               # upper half of the cond gradient: inputs complete
+                    plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, hsegs, self.VfgT_hi.ptr,
+                                                   out0=self.dcond_part.view(), impl=impl), "dcond_hi", TAG_DCOND)
             if not last:
                 gp, gs, gn = self._wgrad(plan, f"res{l}", BF, P_l, R, Rp, dx_next.seg(Rp, hi=P_l),
                                          [self.z[l].seg(Dp)], TAG_WG_RS)
@@ -619,10 +655,18 @@ class DecoderPlan:
             self._colsum(plan, dx0, T, R, ps.ptr(p + "base_layer.bias", True), label="db.base")
         gp, gs, gn = self._wgrad(plan, "base", BF, T, R, Rp, dx0.seg(Rp), [self.onehot.seg(Qp)], TAG_MISC)
         pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], None, 0, [Qp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
-        # ---- conditioning gradient: one GEMM over all layers' dfg (wavenet.py:100-101 cond terms)
-        segs = [self.dfg[l].seg(2 * Dp, row_off=-lg.cond_lead) for l, lg in enumerate(g.layers)]
-        plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT.ptr, out0=self.dcond.view(),
-                                       impl=impl), "dcond", TAG_DCOND)
+        # ---- conditioning gradient over all layers' dfg (wavenet.py:100-101 cond terms).  With split_multiseg the
+        # layers [n_lo, NL) were summed on a side lane mid-chain (dcond_part); this GEMM adds them.
+        lo = self.n_lo
+        if lo < NL:
+            segs = [self.dfg[l].seg(2 * Dp, row_off=-g.layers[l].cond_lead) for l in range(lo)]
+            plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT_lo.ptr, flags=L.EF_ADD_AUX0,
+                                           out0=self.dcond.view(), aux0=self.dcond_part.view(), impl=impl),
+                     "dcond", TAG_DCOND, join=("lane", self.EARLY_LANE))
+        else:
+            segs = [self.dfg[l].seg(2 * Dp, row_off=-lg.cond_lead) for l, lg in enumerate(g.layers)]
+            plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT_lo.ptr, out0=self.dcond.view(),
+                                           impl=impl), "dcond", TAG_DCOND)
         # ---- speaker / gated-bias gradients
         sbw = L.SpkBwd()
         self._fill_spk(sbw)

@@ -121,7 +121,7 @@ class Plan:
         self.keep: list = []          # device tables etc. that must outlive the plan
         self.lane = 0                 # lane given to ops added next (see aew_op_t in aewavenet.h)
 
-    N_SIDE = 4
+    N_SIDE = 5
 
     def side(self, lane: int = 1):
         """`with plan.side(k):` — ops added inside are off the critical chain, on side lane k (1..4)."""
@@ -136,7 +136,8 @@ class Plan:
                 plan.lane = self.prev
         return _Side()
 
-    def add(self, kind: int, payload, label: str, tag: int = 0, join: bool = False) -> L.Op:
+    def add(self, kind: int, payload, label: str, tag: int = 0, join=False) -> L.Op:
+        """join: False / True (all side lanes) / ("lane", k) = side lane k only (main-lane ops)."""
         op = L.Op()
         # tag = semantic tag + 100 * kernel class (1 NT bf16, 2 TN bf16, 3 NT f32, 4 TN f32)
         cls = 0
@@ -145,7 +146,7 @@ class Plan:
         elif kind == L.OP_GEMM_TN:
             cls = 2 if payload.dtype == L.BF16 else 4
         op.kind, op.tag = kind, tag + 100 * cls
-        op.lane, op.join = self.lane, int(join)
+        op.lane, op.join = self.lane, (10 + join[1] if isinstance(join, tuple) else int(join))
         setattr(op.u, L.OP_FIELD[kind], payload)
         self.ops.append(op)
         self.labels.append(label)

@@ -158,6 +158,8 @@ def main():
     _E.DecoderPlan.split_chains = args.chains == 2
     if args.side_lanes:
         _E.DecoderPlan.n_side_lanes = args.side_lanes
+    if os.environ.get("AEW_SPLIT_MULTISEG"):
+        _E.DecoderPlan.split_multiseg = os.environ["AEW_SPLIT_MULTISEG"] == "1"
     hps, eng = build_engine(args, device)
     if dp is not None:
         dp.broadcast_params(eng)

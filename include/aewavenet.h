@@ -97,6 +97,7 @@ typedef struct {
 #define AEW_EF_OUT1_POS1   (1u << 5)  /* out1 = val * (aux1[m][n] > 0)  (out0 keeps val)       */
 #define AEW_EF_ACCUM       (1u << 6)  /* RES_SKIP: out1 += acc instead of =                    */
 #define AEW_EF_OUT2_RELU   (1u << 7)  /* RES_SKIP: out2 = relu(new out1) as bf16              */
+#define AEW_EF_RELU_POST   (1u << 9)  /* val = max(val,0) AFTER the aux0 add (sum of partial GEMMs, then relu) */
 #define AEW_EF_COUNT_ZERO  (1u << 8)  /* atomically add #(out0==0) into counter (enc_az metric,
                                          wave_encoder.py:46)                                   */
 
@@ -345,7 +346,7 @@ enum {
  * HIP streams / parallel hipGraph branches and fill the tails of the chain's kernels:
  *   lane 0 (main)      runs after the preceding lane-0 ops; it waits for preceding side ops only if
  *                      `join` != 0.  The end of the plan is an implicit join.
- *   lane k = 1..4      runs after ALL lane-0 ops that precede it in the plan and after the preceding ops
+ *   lane k = 1..5      runs after ALL lane-0 ops that precede it in the plan and after the preceding ops
  *                      of the SAME lane; with `join` != 0 also after the preceding ops of every other side
  *                      lane.  Ops on different side lanes are otherwise unordered (they may run concurrently).
  * Any serial execution in plan order is a valid schedule (that is what the timing mode and
@@ -353,8 +354,9 @@ enum {
 typedef struct {
     int32_t kind;
     int32_t tag;                 /* caller-defined label, reported by the timing interface    */
-    int32_t lane;                /* 0 main, 1..4 side lanes                                    */
-    int32_t join;                /* wait for the preceding ops of all (other) side lanes first */
+    int32_t lane;                /* 0 main, 1..5 side lanes                                    */
+    int32_t join;                /* 1: wait for the preceding ops of all (other) side lanes first;
+                                    10+k (lane-0 ops): wait for the preceding ops of side lane k only */
     union {
         aew_gemm_nt_t nt; aew_gemm_tn_t tn; aew_copy_table_t copy; aew_vq_nearest_t vqn;
         aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;

@@ -124,6 +124,8 @@ class Emu:
             self.vstore(g.out1, b, m, 0, v)
         if fl & L.EF_ADD_AUX0:
             v = v + self.vload(g.aux0, b, m, 0, N)
+        if fl & L.EF_RELU_POST:
+            v = torch.relu(v)
         if fl & (L.EF_MUL_POS1 | L.EF_OUT1_POS1):
             a = self.vload(g.aux1, b, m, 0, N)
             wv = torch.where(a > 0, v, torch.zeros_like(v))
