@@ -10,6 +10,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 0 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --lanes 0 > $O/pmc_sq.log 2>&1
 python - <<PY
 import csv, glob, collections, shutil
 O = "$O"
@@ -33,5 +34,18 @@ with open(O + "/pmc_hbm_traffic.csv", "w", newline="") as fh:
         f = fe[k][0] / n / 1024.0
         w = wr[k][0] / max(wr[k][1], 1) / 1024.0 if k in wr else 0.0
         cw.writerow([k, n, f"{f:.2f}", f"{2*f:.2f}", f"{w:.2f}"])
+# MFMA utilisation per kernel: MFMA-busy cycles (summed over the 1024 SIMDs) / (1024 x kernel cycles)
+sq = {c: pmc("pmc_sq", c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")}
+with open(O + "/pmc_mfma_util.csv", "w", newline="") as fh:
+    cw = csv.writer(fh)
+    cw.writerow(["kernel", "launches", "mfma_busy_cycles_per_launch", "gui_active_per_launch", "mfma_util_of_1024_simds",
+                 "lds_conflict_share"])
+    for k in sorted(sq["SQ_VALU_MFMA_BUSY_CYCLES"], key=lambda k: -sq["SQ_VALU_MFMA_BUSY_CYCLES"][k][0]):
+        n = sq["SQ_VALU_MFMA_BUSY_CYCLES"][k][1]
+        mf = sq["SQ_VALU_MFMA_BUSY_CYCLES"][k][0] / n
+        # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs
+        ga = sq["GRBM_GUI_ACTIVE"][k][0] / max(sq["GRBM_GUI_ACTIVE"][k][1], 1) / 8.0
+        lc = sq["SQ_LDS_BANK_CONFLICT"][k][0] / max(sq["SQ_LDS_IDX_ACTIVE"][k][0], 1.0)
+        cw.writerow([k, n, f"{mf:.0f}", f"{ga:.0f}", f"{mf / (1024.0 * ga):.4f}" if ga > 0 else "", f"{lc:.4f}"])
 print(open(O + "/bench.json").read()[:600])
 PY
