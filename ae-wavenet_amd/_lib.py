@@ -193,6 +193,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's, which this
+    # library is linked against).  Whichever is loaded first serves both, and torch does not find its devices
+    # through the system copy ("no ROCm-capable device"), so torch has to be imported before the dlopen below.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AewError(f"HIP extension not built: {LIB_PATH} is missing "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
