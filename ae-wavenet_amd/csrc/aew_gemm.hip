@@ -196,40 +196,42 @@ __device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n,
 #define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
 #endif
 
-template <int MT, int NB = 1>                           // NB = block columns / 128
+template <int MT, int NB = 1, int BMV = NT_BM>          // NB = block columns / 128, BMV = block rows (256 | 192)
 struct NtCfg {
+    static constexpr int BM = BMV;
     static constexpr int BN = 128 * NB;
-    static constexpr int WAVES_M = NT_BM / (16 * MT);   // 4 (thin) or 2 (fat)
+    static constexpr int WAVES_M = BM / (16 * MT);      // 4 (thin; 192-row tiles: 48 x 64 per wave) or 2 (fat)
     static constexpr int WAVES_N = 2 * NB;
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
-    static constexpr int XP = 16 / NWAVES;              // X pieces (16 rows x 64 B) a wave stages per K tile
-    static constexpr int WP = 8 * NB / NWAVES;          // W pieces
-    static constexpr int MINW = MT == 8 ? 2 : 4;        // waves per SIMD the register budget must allow
-    static constexpr int STAGE_BYTES = (NT_BM + BN) * NT_ROWB;
+    static constexpr int NXP = BM / 16, NWP = 8 * NB;   // 16-row pieces per K tile: X rows, W rows
+    static constexpr int XP = (NXP + NWAVES - 1) / NWAVES;   // pieces a wave stages per K tile; piece indices
+    static constexpr int WP = (NWP + NWAVES - 1) / NWAVES;   // beyond NXP / NWP are dummies (zero page -> pad)
+    static constexpr int MINW = MT == 8 ? 2 : 4;   // waves per SIMD the register budget must allow
+    static constexpr int PAD_OFF = (BM + BN) * NT_ROWB;      // 1 KiB landing pad of the dummy pieces
+    static constexpr int STAGE_BYTES = PAD_OFF + ((NXP % NWAVES || NWP % NWAVES) ? 1024 : 0);
     static constexpr int LDS_BYTES = NT_STAGES * STAGE_BYTES;
 };
 
 // Per-lane source pointers of the X and W pieces a wave stages per K tile.  Computed once per
 // segment (X) / once per kernel (W) and advanced by one K tile per issue, so the K loop carries no
 // address arithmetic beyond 64-bit adds.
-template <int MT, int NB = 1>
+template <int MT, int NB = 1, int BMV = NT_BM>
 struct NtPtrs {
-    const char* x[NtCfg<MT, NB>::XP];
-    const char* w[NtCfg<MT, NB>::WP];
-    int xinc[NtCfg<MT, NB>::XP];
-    int winc;
+    const char* x[NtCfg<MT, NB, BMV>::XP];
+    const char* w[NtCfg<MT, NB, BMV>::WP];
+    int xinc[NtCfg<MT, NB, BMV>::XP];
+    int winc[NtCfg<MT, NB, BMV>::WP];
 };
 
 // after the last real K tile: the (uniform) loop keeps issuing, from the zero page, into stages
 // nobody reads any more
-template <int MT, int NB>
-__device__ __forceinline__ void nt_setup_idle(NtPtrs<MT, NB>& P) {
+template <int MT, int NB, int BMV>
+__device__ __forceinline__ void nt_setup_idle(NtPtrs<MT, NB, BMV>& P) {
 #pragma unroll
-    for (int j = 0; j < NtCfg<MT, NB>::XP; ++j) { P.x[j] = reinterpret_cast<const char*>(aew_zero_page); P.xinc[j] = 0; }
+    for (int j = 0; j < NtCfg<MT, NB, BMV>::XP; ++j) { P.x[j] = reinterpret_cast<const char*>(aew_zero_page); P.xinc[j] = 0; }
 #pragma unroll
-    for (int j = 0; j < NtCfg<MT, NB>::WP; ++j) P.w[j] = reinterpret_cast<const char*>(aew_zero_page);
-    P.winc = 0;
+    for (int j = 0; j < NtCfg<MT, NB, BMV>::WP; ++j) { P.w[j] = reinterpret_cast<const char*>(aew_zero_page); P.winc[j] = 0; }
 }
 
 // branch-free: the segment record is read with one batch of scalar loads, masked rows are selects
@@ -239,16 +241,18 @@ __device__ __forceinline__ const char* seg_row_ptr_sel(const aew_seg_t& s, int b
     return reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + row * s.row_pitch) * esize;
 }
 
-template <int MT, int NB>
+template <int MT, int NB, int BMV>
 __device__ __forceinline__ void nt_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
-                                           NtPtrs<MT, NB>& P) {
+                                           NtPtrs<MT, NB, BMV>& P) {
     const aew_seg_t s = g.seg[seg];
     const int lr = lane >> 2, pc = lane & 3;
 #pragma unroll
-    for (int j = 0; j < NtCfg<MT, NB>::XP; ++j) {
-        const int r = (wave * NtCfg<MT, NB>::XP + j) * 16 + lr;          // 16 pieces of 16 rows
+    for (int j = 0; j < NtCfg<MT, NB, BMV>::XP; ++j) {
+        const int piece = wave * NtCfg<MT, NB, BMV>::XP + j;                  // BM / 16 pieces of 16 rows
+        const int r = piece * 16 + lr;
         bool ok;
         const char* src = seg_row_ptr_sel(s, b, m0 + r, 2, ok) + (nt_swz64(r, pc) << 4);
+        ok = ok && piece < NtCfg<MT, NB, BMV>::NXP;                           // dummy pieces read the zero page
         P.x[j] = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
         P.xinc[j] = ok ? NT_BK * 2 : 0;
     }
@@ -268,29 +272,35 @@ __device__ __forceinline__ int nt_wperm(int rho) {
     return (i >> 1) * 32 + c;
 }
 
-template <int EPI, int MT, int NB>
-__device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int wave, int lane, NtPtrs<MT, NB>& P) {
+template <int EPI, int MT, int NB, int BMV>
+__device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int wave, int lane, NtPtrs<MT, NB, BMV>& P) {
     const int lr = lane >> 2, pc = lane & 3;
 #pragma unroll
-    for (int j = 0; j < NtCfg<MT, NB>::WP; ++j) {
-        const int r = (wave * NtCfg<MT, NB>::WP + j) * 16 + lr;          // 8 pieces of 16 rows
+    for (int j = 0; j < NtCfg<MT, NB, BMV>::WP; ++j) {
+        const int piece = wave * NtCfg<MT, NB, BMV>::WP + j;                  // 8 * NB pieces of 16 rows
+        const bool real = piece < NtCfg<MT, NB, BMV>::NWP;                    // (wave-uniform)
+        const int r = piece * 16 + lr;
         const int src_row = (r & ~63) + nt_wperm<EPI>(r & 63);
-        P.w[j] = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + src_row) * g.K_total * 2 + (nt_swz64(r, pc) << 4);
+        const char* src = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + src_row) * g.K_total * 2 + (nt_swz64(r, pc) << 4);
+        P.w[j] = real ? src : reinterpret_cast<const char*>(aew_zero_page);
+        P.winc[j] = real ? NT_BK * 2 : 0;
     }
-    P.winc = NT_BK * 2;
 }
 
-template <int MT, int NB>
-__device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs<MT, NB>& P) {
+template <int MT, int NB, int BMV>
+__device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs<MT, NB, BMV>& P) {
 #pragma unroll
-    for (int j = 0; j < NtCfg<MT, NB>::XP; ++j) {
-        glds16(P.x[j], stage + (wave * NtCfg<MT, NB>::XP + j) * 1024);
+    for (int j = 0; j < NtCfg<MT, NB, BMV>::XP; ++j) {
+        const int piece = wave * NtCfg<MT, NB, BMV>::XP + j;
+        glds16(P.x[j], stage + (piece < NtCfg<MT, NB, BMV>::NXP ? piece * 1024 : NtCfg<MT, NB, BMV>::PAD_OFF));
         P.x[j] += P.xinc[j];
     }
 #pragma unroll
-    for (int j = 0; j < NtCfg<MT, NB>::WP; ++j) {
-        glds16(P.w[j], stage + NT_BM * NT_ROWB + (wave * NtCfg<MT, NB>::WP + j) * 1024);
-        P.w[j] += P.winc;
+    for (int j = 0; j < NtCfg<MT, NB, BMV>::WP; ++j) {
+        typedef NtCfg<MT, NB, BMV> Cfg;
+        const int piece = wave * Cfg::WP + j;
+        glds16(P.w[j], stage + (piece < Cfg::NWP ? Cfg::BM * NT_ROWB + piece * 1024 : Cfg::PAD_OFF));
+        P.w[j] += P.winc[j];
     }
 }
 
@@ -507,24 +517,24 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
 
 // ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved);
 // the production instantiations (ABL = false) contain none of that code.
-template <int EPI, bool ABL = false, int MT = 8, int NB = 1>
-__global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
-    typedef NtCfg<MT, NB> Cfg;
+template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM>
+__global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+    typedef NtCfg<MT, NB, BMV> Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % Cfg::WAVES_N, wm = wave / Cfg::WAVES_N;
     // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (observed dispatch rule; used for
     // speed only).  All N tiles of one (batch, row-tile) are consecutive on ONE XCD, so the
     // activation tile is fetched from HBM into that XCD's L2 once and re-hit by the others.
-    const int n_mt = (g.M + NT_BM - 1) / NT_BM, n_nt = g.N_pad / Cfg::BN;
+    const int n_mt = (g.M + Cfg::BM - 1) / Cfg::BM, n_nt = g.N_pad / Cfg::BN;
     const int L = blockIdx.x, seq = L >> 3;
     const int rt = (seq / n_nt) * 8 + (L & 7);
     if (rt >= n_mt * g.batch) return;
     const int b = rt / n_mt;
-    const int m0 = (rt - b * n_mt) * NT_BM, n0 = (seq % n_nt) * Cfg::BN;
+    const int m0 = (rt - b * n_mt) * Cfg::BM, n0 = (seq % n_nt) * Cfg::BN;
     // RES_SKIP: skip-part tiles that lie entirely before the skip window do nothing
     if (EPI == AEW_EPI_RES_SKIP && n0 >= g.n_split) {
-        const int64_t last = (int64_t)(min(m0 + NT_BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
+        const int64_t last = (int64_t)(min(m0 + Cfg::BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
         if (last < g.out1.row_lo) return;
     }
     const int nkt = g.K_total / NT_BK;
@@ -547,10 +557,10 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    NtPtrs<MT, NB> P;
+    NtPtrs<MT, NB, BMV> P;
     NtIssue is = {0, g.seg[0].k_len / NT_BK, 0, 0};
-    nt_setup_w<EPI, MT, NB>(g, n0, wave, lane, P);
-    nt_setup_x<MT, NB>(g, 0, b, m0, wave, lane, P);
+    nt_setup_w<EPI, MT, NB, BMV>(g, n0, wave, lane, P);
+    nt_setup_x<MT, NB, BMV>(g, 0, b, m0, wave, lane, P);
     // One K tile is issued per loop step, unconditionally, so the loop body is a single basic block
     // that the scheduler directives below can shape; `advance` runs after a tile has been issued
     // and points P at the next one (next segment, or the zero page once K is exhausted).
@@ -560,19 +570,19 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
         is.slot = (is.slot + 1 == NT_STAGES) ? 0 : is.slot + 1;
         if (is.left == 0 && !(abl & 128)) {            // wave-uniform and rare: scalar loads only here
             if (is.issued >= nkt) {
-                nt_setup_idle<MT, NB>(P);
+                nt_setup_idle<MT, NB, BMV>(P);
                 is.left = 1 << 30;
             } else {
                 ++is.seg;
                 is.left = g.seg[is.seg].k_len / NT_BK;
-                nt_setup_x<MT, NB>(g, is.seg, b, m0, wave, lane, P);
+                nt_setup_x<MT, NB, BMV>(g, is.seg, b, m0, wave, lane, P);
             }
         }
     };
     if (abl & 16) return;                              // launch + pointer setup
-    if (!(abl & 4)) nt_issue_bf16<MT, NB>(smem, wave, P);
+    if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem, wave, P);
     advance();
-    if (!(abl & 4)) nt_issue_bf16<MT, NB>(smem + Cfg::STAGE_BYTES, wave, P);
+    if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + Cfg::STAGE_BYTES, wave, P);
     advance();
     const int fi = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (constant over the K loop)
@@ -580,7 +590,7 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rw = wn * 64 + i * 16 + fi;
-        woff[i] = NT_BM * NT_ROWB + rw * NT_ROWB + (nt_swz64(rw, fg) << 4);
+        woff[i] = Cfg::BM * NT_ROWB + rw * NT_ROWB + (nt_swz64(rw, fg) << 4);
     }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -632,7 +642,7 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
                 lap(3);
             }
             // tile t+2 goes into the stage that was computed at step t-1 (every wave is past it: barrier)
-            if (!COUNTED && !(abl & 4)) nt_issue_bf16<MT, NB>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
+            if (!COUNTED && !(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
             if constexpr (COUNTED) {
                 // hand-placed: wait for what the group needs, 4 MFMAs, one LDS-DMA piece of tile t+2
                 // (asm MFMAs with a memory clobber so that neither they nor the DMA builtins move)
@@ -643,8 +653,8 @@ __global__ __launch_bounds__((NtCfg<MT, NB>::THREADS), (NtCfg<MT, NB>::MINW)) vo
                         P.x[q] += P.xinc[q];
                     } else if (q < Cfg::XP + Cfg::WP) {
                         const int w = q - Cfg::XP;
-                        glds16(P.w[w], dstage + NT_BM * NT_ROWB + (wave * Cfg::WP + w) * 1024);
-                        P.w[w] += P.winc;
+                        glds16(P.w[w], dstage + Cfg::BM * NT_ROWB + (wave * Cfg::WP + w) * 1024);
+                        P.w[w] += P.winc[w];
                     }
                 };
 #define AEW_MFMA4(J)                                                                                          \
@@ -784,27 +794,27 @@ __global__ __launch_bounds__((NtCfg<8, NB>::THREADS), 2) void k_gemm_nt_bf16_pip
 
     NtPtrs<MT, NB> P;
     NtIssue is = {0, g.seg[0].k_len / NT_BK, 0, 0};
-    nt_setup_w<EPI, MT, NB>(g, n0, wave, lane, P);
-    nt_setup_x<MT, NB>(g, 0, b, m0, wave, lane, P);
+    nt_setup_w<EPI, MT, NB, NT_BM>(g, n0, wave, lane, P);
+    nt_setup_x<MT, NB, NT_BM>(g, 0, b, m0, wave, lane, P);
     auto advance = [&]() {
         --is.left;
         ++is.issued;
         is.slot = (is.slot + 1 == NT_STAGES) ? 0 : is.slot + 1;
         if (is.left == 0) {                                  // wave-uniform and rare
             if (is.issued >= nkt) {
-                nt_setup_idle<MT, NB>(P);
+                nt_setup_idle<MT, NB, NT_BM>(P);
                 is.left = 1 << 30;
             } else {
                 ++is.seg;
                 is.left = g.seg[is.seg].k_len / NT_BK;
-                nt_setup_x<MT, NB>(g, is.seg, b, m0, wave, lane, P);
+                nt_setup_x<MT, NB, NT_BM>(g, is.seg, b, m0, wave, lane, P);
             }
         }
     };
     // prologue: tiles 0, 1, 2 in flight; tile 0 into register set A
 #pragma unroll
     for (int q = 0; q < NT_STAGES; ++q) {
-        nt_issue_bf16<MT, NB>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
+        nt_issue_bf16<MT, NB, NT_BM>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
         advance();
     }
     const int fi = lane & 15, fg = lane >> 4;
@@ -836,7 +846,7 @@ __global__ __launch_bounds__((NtCfg<8, NB>::THREADS), 2) void k_gemm_nt_bf16_pip
                 P.x[j] += P.xinc[j];                                                                       \
             } else if (j < PIECES) {                                                                       \
                 glds16(P.w[j - Cfg::XP], dst + NT_BM * NT_ROWB + (wave * Cfg::WP + (j - Cfg::XP)) * 1024); \
-                P.w[j - Cfg::XP] += P.winc;                                                                \
+                P.w[j - Cfg::XP] += P.winc[j - Cfg::XP];                                                                \
             }                                                                                              \
         }                                                                                                  \
         advance();                                                                                         \
@@ -1563,6 +1573,7 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 // =============================================================================================
 static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
 static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kernel
+static int g_nt_rows192 = 1;      // default shape: 0 never, 1 cost model, 2 always use 192-row tiles
 static int g_nt_small_tiles = 128; // default shape: launches of <= this many 256x128 tiles use 64-row tiles
 static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 128 = 4 fat waves (128x64), both on
                                    // 256x128 tiles; 256 = 8 fat waves on 256x256 tiles where N_pad allows
@@ -1585,7 +1596,8 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8, 2>), (NtCfg<8, 2>::LDS_BYTES)) \
-    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4>), NT_LDS_BYTES)
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4>), NT_LDS_BYTES)          \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), (NtCfg<3, 1, 192>::LDS_BYTES))
     AEW_SET_NT(AEW_EPI_STORE)
     AEW_SET_NT(AEW_EPI_GATED)
     AEW_SET_NT(AEW_EPI_RES_SKIP)
@@ -1643,12 +1655,24 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         const bool p64r = g_nt_wave_rows == 64 && g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan;
         const bool p128 = !p64r && g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64
         const bool p256 = g_nt_wave_rows == 1 && zspan;      // 256 x 128 tiles, K tiles of 64, one block per CU
-        const int bm = p64r ? 64 : (p128 ? 128 : NT_BM), bn = (p128 || p64r) ? 128 : (wide ? 256 : NT_BN);
+        // 192-row tiles (8 waves of 48 x 64) where they shorten the launch.  Blocks spread over the 256 CUs before
+        // they double up, and a CU is MFMA-bound with one block already, so a launch costs about
+        // ceil(tiles / 256) * rows-per-tile; the 192-row shape is ~5 % less efficient per row (12 MFMAs per wave
+        // and K step instead of 16), hence the margin.
+        bool t192 = false;
+        if (g_nt_wave_rows == 64 && !p64r && g_nt_rows192) {
+            const int tiles192 = ((g.M + 191) / 192) * g.batch * (g.N_pad / NT_BN);
+            const int c256 = ((tiles256 + 255) / 256) * 256, c192 = ((tiles192 + 255) / 256) * 192;
+            t192 = g_nt_rows192 == 2 || c192 * 10 < c256 * 9;
+        }
+        const int bm = p64r ? 64 : (p128 ? 128 : (t192 ? 192 : NT_BM)), bn = (p128 || p64r) ? 128 : (wide ? 256 : NT_BN);
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
 #define AEW_NT_GO(EPI, ABL)                                                                                   \
     do {                                                                                                      \
-        if (!ABL && p64r)                                                                                      \
+        if (!ABL && t192)                                                                                      \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), grid, dim3((NtCfg<3, 1, 192>::THREADS)), (NtCfg<3, 1, 192>::LDS_BYTES), st, g); \
+        else if (!ABL && p64r)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), grid, dim3(128), (P64Cfg<4, 1, 2>::LDS_BYTES), st, g); \
         else if (!ABL && p256)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 4, 2>), grid, dim3(512), (P64Cfg<4, 4, 2>::LDS_BYTES), st, g); \

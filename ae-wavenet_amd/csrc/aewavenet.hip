@@ -231,6 +231,7 @@ extern "C" int aew_set_tn_target_blocks(int n) {
     g_tn_target_blocks = n;
     return 0;
 }
+extern "C" int aew_set_nt_rows192(int mode) { g_nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n; return 0; }
 extern "C" int aew_set_nt_pipe(int mode) { g_nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_wave_rows(int rows) {

@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")
     ap.add_argument("--tn-small", dest="tn_small", default="", help="max_tiles,target_blocks for small-output TN ops")
     ap.add_argument("--chains", type=int, default=1, help="1: gated stack as one full-batch chain; 2: two half-batch chains")
+    ap.add_argument("--nt-rows192", dest="nt_rows192", type=int, default=-1, help="192-row NT tiles: 0 never, 1 cost model, 2 always")
     ap.add_argument("--nt-small", dest="nt_small", type=int, default=-1, help="tile-count threshold for 64-row NT tiles")
     ap.add_argument("--side-lanes", dest="side_lanes", type=int, default=0, help="side lanes the wgrads rotate over (1..4)")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
@@ -147,6 +148,8 @@ def main():
     lib.aew_set_lanes(args.lanes)
     lib.aew_set_nt_wave_rows(args.nt_wave_rows)
     lib.aew_set_nt_pipe(args.nt_pipe)
+    if args.nt_rows192 >= 0:
+        lib.aew_set_nt_rows192(args.nt_rows192)
     if args.nt_small >= 0:
         lib.aew_set_nt_small_tiles(args.nt_small)
     if args.tn_blocks:

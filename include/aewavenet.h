@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 6
+#define AEW_ABI_VERSION 7
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -394,6 +394,9 @@ int aew_set_nt_wave_rows(int rows);
 int aew_set_nt_pipe(int on);
 /* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
 int aew_set_nt_small_tiles(int n);
+/* default NT shape only: 192 x 128 tiles (6 waves) instead of 256 x 128 — 0 never, 1 (default) where the
+ * tile-wave cost model prefers them, 2 always.  Results are bit-identical either way. */
+int aew_set_nt_rows192(int mode);
 /* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
 int aew_set_lanes(int on);
 

@@ -126,8 +126,11 @@ def test_gemm_nt(dtype, epi):
         # impl 0 under every tile / wave shape of the bf16 kernel (64: 8 waves of 64x64, 128: 4 waves of
         # 128x64, 256: 256x256 tiles where N_pad allows); the shapes must agree bit for bit
         # (impl, shape, pipe, small): small = tile-count threshold of the 64-row tiles (0: plain 256x128)
-        for impl, shape, pipe, small in ((0, 64, 1, 0), (1, 64, 1, 0), (0, 64, 1, 128), (0, 0, 1, 0), (0, 1, 1, 0),
+        # small < 0: 192-row tiles forced (small tiles off)
+        for impl, shape, pipe, small in ((0, 64, 1, 0), (1, 64, 1, 0), (0, 64, 1, 128), (0, 64, 1, -1), (0, 0, 1, 0), (0, 1, 1, 0),
                                          (0, 128, 1, 0), (0, 128, 0, 0), (0, 256, 0, 0), (0, 256, 1, 0), (0, 256, 2, 0)):
+            lib.aew_set_nt_rows192(2 if small < 0 else 0)
+            small = max(small, 0)
             lib.aew_set_nt_wave_rows(shape)
             lib.aew_set_nt_pipe(pipe)
             lib.aew_set_nt_small_tiles(small)
@@ -137,7 +140,7 @@ def test_gemm_nt(dtype, epi):
             p.run(stream())
             torch.cuda.synchronize()
             res = {n: ws_g.get(n).float().cpu() for n in ("O0", "O1", "O2")}
-            if shape == 64 and small == 0:
+            if shape == 64 and small == 0 and impl not in results:
                 results[impl] = res
             else:
                 for n in res:
@@ -146,6 +149,7 @@ def test_gemm_nt(dtype, epi):
         lib.aew_set_nt_wave_rows(64)
         lib.aew_set_nt_pipe(1)
         lib.aew_set_nt_small_tiles(128)
+        lib.aew_set_nt_rows192(1)
     ws_e = Workspace("cpu")
     for n, t in ws_c.bufs.items():
         ws_e.bufs[n] = t.clone()
