@@ -179,6 +179,31 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
             OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit"}
 
+# ---- autoregressive sampler (aew_actor_t / aew_sampler_t) ----
+ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMPLE = -1, 0, 1, 2, 3, 4, 5, 6
+
+
+class Sbuf(C.Structure):
+    _fields_ = [("ptr", vp), ("bstride", i64), ("entry", i64), ("pitch", i64), ("ring", i32), ("pad", i32)]
+
+
+class Wait(C.Structure):
+    _fields_ = [("flags", vp), ("n", i32), ("lag", i32)]
+
+
+class Actor(C.Structure):
+    _fields_ = [("role", i32), ("layer", i32), ("index", i32), ("nt", i32), ("nk", i32), ("nk2", i32),
+                ("dil", i32), ("pad", i32), ("wait", Wait * 2), ("flag", vp), ("w", vp), ("w2", vp),
+                ("bias", vp), ("bias_pitch", i64), ("in0", Sbuf), ("in1", Sbuf), ("out", Sbuf), ("out2", Sbuf),
+                ("n_quant", i32), ("row_bytes", i32)]
+
+
+class Sampler(C.Structure):
+    _fields_ = [("actors", vp), ("n_slots", i32), ("n_batches", i32), ("n_steps", i32), ("flag_stride", i32),
+                ("kr_max", i32), ("spin_max", i32), ("flags", vp), ("status", vp), ("forced", vp),
+                ("wav_out", vp), ("seed", C.c_uint64)]
+
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaewavenet_hip.so")
 _lib = None
 
@@ -211,12 +236,13 @@ def load():
     lib.aew_graph_capture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.aew_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.aew_graph_destroy.argtypes = [C.c_void_p]
-    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec)):
+    lib.aew_sampler_run.argtypes = [C.c_void_p, C.c_void_p]
+    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler)):
         want = lib.aew_sizeof(which)
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 7:
+    if lib.aew_abi_version() != 8:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -239,4 +265,5 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe",
            "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
            "aew_set_lanes", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
-           "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_rows192")
+           "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_rows192",
+           "aew_sampler_run")

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC aewavenet.hip -o libaewavenet_hip.so
 #include "aew_gemm.hip"
 #include "aew_ops.hip"
+#include "aew_sampler.hip"
 
 #include <vector>
 
@@ -59,6 +60,8 @@ extern "C" int aew_sizeof(int which) {
         case 3: return (int)sizeof(aew_seg_t);
         case 4: return (int)sizeof(aew_view_t);
         case 5: return (int)sizeof(aew_copy_rec_t);
+        case 6: return (int)sizeof(aew_actor_t);
+        case 7: return (int)sizeof(aew_sampler_t);
         default: return -1;
     }
 }
@@ -230,6 +233,10 @@ extern "C" int aew_set_tn_target_blocks(int n) {
     if (n < 1) return AEW_E_ARG;
     g_tn_target_blocks = n;
     return 0;
+}
+extern "C" int aew_sampler_run(const aew_sampler_t* s, void* stream) {
+    if (!s) return AEW_E_ARG;
+    return launch_sampler(*s, reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int aew_set_nt_rows192(int mode) { g_nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n; return 0; }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 7
+#define AEW_ABI_VERSION 8
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -369,7 +369,7 @@ typedef struct {
 /* Library / build identification. */
 int aew_abi_version(void);
 /* sizeof(aew_op_t) etc. so the binding can verify its struct mirrors. */
-int aew_sizeof(int which);      /* 0 op, 1 gemm_nt, 2 gemm_tn, 3 seg, 4 view, 5 copy_rec */
+int aew_sizeof(int which);      /* 0 op, 1 gemm_nt, 2 gemm_tn, 3 seg, 4 view, 5 copy_rec, 6 actor, 7 sampler */
 
 /* Execute ops[0..n) in order on `stream` (a hipStream_t).  Returns at the first error and
  * writes the failing index to *fail_index if non-NULL. */
@@ -414,6 +414,104 @@ int aew_set_tn_target_blocks(int n);
 int aew_set_tn_small(int max_tiles, int target_blocks);
 /* 1: read TN fragments with a scalar LDS gather instead of ds_read_b64_tr_b16 (debug aid). */
 int aew_set_tn_safe(int on);
+
+/* =======================================================================================
+ * Autoregressive sampler — replaces WaveNet.forward_test (wavenet.py:367-531: the per-sample Python
+ * loop over base_layer / conv_layers / post1 / post2 / softmax / torch.multinomial with rolling
+ * per-layer buffers, driven by InferenceChassis, chassis.py:283-349).
+ *
+ * One PERSISTENT kernel; every wavefront is an ACTOR that owns a fixed slice of one layer's weights
+ * (MFMA A-fragments resident in its VGPRs for the whole generation) and processes the work items
+ * (t, b) — time step t of stream-batch b, 16 streams per batch — in the same global order
+ * t = 0..n_steps-1, b = 0..n_batches-1.  Actors exchange 16-stream activation rows through global
+ * memory and signal with monotone sequence flags: flag = seq(t, b) = t*n_batches + b + 1 once item
+ * (t, b) is published.  Per layer l (dilation d):
+ *   EARLY(l,p)  pre-activations of channel pair-tile p from h_l(t-d) and cond(t)  (off the critical path)
+ *   LATE(l,p)   adds the h_l(t) taps, gates: z_l = tanh(filt)*sigmoid(gate)          (wavenet.py:100-103)
+ *   RES(l,q)    h_{l+1}(t) = h_l(t) + W_res z_l                                      (wavenet.py:108-110)
+ *   SKIP(l,q)   skip sum += W_skp z_l                                                (wavenet.py:104,458)
+ * then POST1 / POST2 (wavenet.py:461-462) and SAMPLE (softmax + inverse-CDF draw from a counter RNG in
+ * place of torch.multinomial, wavenet.py:463-466; writes the base-layer row h_0(t+1), wavenet.py:452).
+ * With n_batches > 1 the layers work on different stream-batches at the same time (a pipeline).
+ * Every spin is bounded: if a producer never arrives the kernel sets status[0] and all actors exit.
+ * ===================================================================================== */
+#define AEW_ACT_NONE   (-1)
+#define AEW_ACT_EARLY  0
+#define AEW_ACT_LATE   1
+#define AEW_ACT_RES    2
+#define AEW_ACT_SKIP   3
+#define AEW_ACT_POST1  4
+#define AEW_ACT_POST2  5
+#define AEW_ACT_SAMPLE 6
+
+/* 16-stream activation buffer.  Row of stream i of stream-batch b at time t (BYTES):
+ *     ptr + b*bstride + (t % ring)*entry + i*pitch */
+typedef struct {
+    void*   ptr;
+    int64_t bstride;
+    int64_t entry;
+    int64_t pitch;
+    int32_t ring;                /* >= 1 */
+    int32_t pad;
+} aew_sbuf_t;
+
+/* wait until flags[j*flag_stride] >= seq(t - lag, b) for j < n (skipped while t < lag) */
+typedef struct {
+    const uint32_t* flags;
+    int32_t n;                   /* <= 32 */
+    int32_t lag;
+} aew_wait_t;
+
+typedef struct {
+    int32_t role;                /* AEW_ACT_* */
+    int32_t layer, index;        /* informational */
+    int32_t nt;                  /* 16-channel output tiles this actor owns: 1 or 2                       */
+    int32_t nk;                  /* K tiles (32 channels) of the register-resident weights `w`             */
+    int32_t nk2;                 /* EARLY: K tiles of the streamed cond weights `w2`                       */
+    int32_t dil;                 /* EARLY: dilation d                                                      */
+    int32_t pad;
+    aew_wait_t wait[2];
+    uint32_t* flag;              /* this actor's sequence flag                                             */
+    /* weight fragments, bf16: blob[k][n(2)][lane(64)][8] = W[n*16 + (lane&15)][k*32 + (lane>>4)*8 + j]
+     * (the MFMA 16x16x32 A operand); SAMPLE: `w` = base-layer table [Q][in0-row] bf16 (bias folded in)  */
+    const void* w;
+    const void* w2;
+    /* fp32 bias: EARLY per stream [n_streams][bias_pitch] (speaker term folded in), lane reads
+     * bias[stream*bias_pitch + n*16 + (lane>>4)*4 .. +3]; POST1/POST2 shared (bias_pitch = 0)            */
+    const float* bias;
+    int64_t bias_pitch;
+    /* role        in0                  in1                      out
+     * EARLY       h_l (read at t-d)    cond (ring = n_steps)    partial pre-acts (ring 2; raw lane layout)
+     * LATE        h_l (t)              partial pre-acts         z_l     (ptr at this pair's channels)
+     * RES         z_l                  h_l (t), own channels    h_{l+1} (t), own channels
+     * SKIP        z_l                  skip sum (NULL: layer 0) skip sum, own channels (fp32)
+     * POST1       skip sum (fp32)      -                        relu(post1) bf16, own channels
+     * POST2       relu(post1)          -                        logits fp32, own channels
+     * SAMPLE      logits               -                        h_0 (written at t+1)                        */
+    aew_sbuf_t in0, in1, out;
+    aew_sbuf_t out2;             /* POST2: optional copy of the logits (ring = n_steps), ptr NULL = off     */
+    int32_t n_quant;             /* SAMPLE: Q (multiple of 16, <= 256); streams [index*4, index*4+4)        */
+    int32_t row_bytes;           /* SAMPLE: bytes of one base-table row (= h_0 row)                         */
+} aew_actor_t;
+
+typedef struct {
+    const aew_actor_t* actors;   /* DEVICE array [n_slots]; slot L runs as workgroup L (XCD L % 8)          */
+    int32_t n_slots;
+    int32_t n_batches;           /* stream-batches of 16 streams                                          */
+    int32_t n_steps;             /* T: positions 0..T-1; position 0 is always forced                       */
+    int32_t flag_stride;         /* uint32 words between consecutive flags                                 */
+    int32_t kr_max;              /* 12 or 16: compiled bound on nk of EARLY / LATE                         */
+    int32_t spin_max;            /* polls before an actor gives up (0 = default)                           */
+    uint32_t* flags;             /* [n_slots * flag_stride]; zeroed by aew_sampler_run                      */
+    uint32_t* status;            /* [4] device words: abort flag, slot, t, b of the first give-up          */
+    const int32_t* forced;       /* [n_streams][n_steps]: value fed at position t if >= 0, else the draw   */
+    int32_t* wav_out;            /* [n_streams][n_steps] the sequence that was fed (forced or drawn)       */
+    uint64_t seed;               /* u(stream, t) = mix64-counter uniform, see oracle/jitter_rng.py         */
+} aew_sampler_t;
+
+/* Enqueue one generation on `stream`.  Returns AEW_E_UNSUP if the device cannot keep n_slots
+ * wavefront-workgroups resident at once (the actors wait on each other). */
+int aew_sampler_run(const aew_sampler_t* s, void* stream);
 
 /* Human-readable string for a return code. */
 const char* aew_strerror(int code);
