@@ -24,6 +24,37 @@ struct SmpEnv {
     int slot;
 };
 
+// Activation rows and flags travel between wavefronts on different CUs / XCDs.  They are read and written with
+// relaxed AGENT-scope atomics (global_load / global_store ... sc1: coherent at the device level, never served from a
+// stale L2 line, written through), so publishing a row needs no cache maintenance: the producer waits for its stores
+// (s_waitcnt vmcnt(0)) and then stores the flag.  The fence form (buffer_wbl2 / buffer_inv, what an acquire / release
+// pair costs on a multi-XCD device) walks the L2 and serialises all ~130 actors of an XCD: 6.7 us per hand-off
+// measured, against 0.6-0.9 us for the flag itself.
+__device__ __forceinline__ unsigned long long smp_ld8(const void* p) {
+    typedef const __attribute__((address_space(1))) unsigned long long* gptr;            // global, not flat
+    return __hip_atomic_load((gptr)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void smp_st8(void* p, unsigned long long v) {
+    typedef __attribute__((address_space(1))) unsigned long long* gptr;
+    __hip_atomic_store((gptr)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct SmpU16 { unsigned long long lo, hi; };
+__device__ __forceinline__ SmpU16 smp_ld16(const void* p) {
+    SmpU16 r;
+    r.lo = smp_ld8(p);
+    r.hi = smp_ld8(reinterpret_cast<const char*>(p) + 8);
+    return r;
+}
+__device__ __forceinline__ void smp_st16(void* p, const SmpU16& v) {
+    smp_st8(p, v.lo);
+    smp_st8(reinterpret_cast<char*>(p) + 8, v.hi);
+}
+__device__ __forceinline__ f32x4_t smp_ld_f4(const void* p) { return __builtin_bit_cast(f32x4_t, smp_ld16(p)); }
+__device__ __forceinline__ void smp_st_f4(void* p, const f32x4_t& v) { smp_st16(p, __builtin_bit_cast(SmpU16, v)); }
+__device__ __forceinline__ bf16x8_t smp_ld_x(const void* p) { return __builtin_bit_cast(bf16x8_t, smp_ld16(p)); }
+__device__ __forceinline__ uint2 smp_ld_u2(const void* p) { return __builtin_bit_cast(uint2, smp_ld8(p)); }
+__device__ __forceinline__ void smp_st_u2(void* p, uint2 v) { smp_st8(p, __builtin_bit_cast(unsigned long long, v)); }
+
 __device__ __forceinline__ char* sbuf_at(const aew_sbuf_t& s, int b, int t) {
     return reinterpret_cast<char*>(s.ptr) + (int64_t)b * s.bstride + (int64_t)(t % s.ring) * s.entry;
 }
@@ -44,8 +75,8 @@ __device__ __forceinline__ bool smp_wait(const aew_actor_t& a, const SmpEnv& e, 
             if (!__any(v < need)) { ok = true; break; }
             if ((spin & 63) == 63 &&
                 __hip_atomic_load(e.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            __builtin_amdgcn_s_sleep(1);
-        }
+            __builtin_amdgcn_s_sleep(1);                // (keeping several polls in flight was measured slower: ~1000
+        }                                               //  waiting wavefronts then congest the path the flags travel)
         if (!ok) {
             if (e.lane == 0 && atomicCAS(e.status, 0u, 1u) == 0u) {
                 e.status[1] = (uint32_t)e.slot; e.status[2] = (uint32_t)t; e.status[3] = (uint32_t)b;
@@ -53,12 +84,12 @@ __device__ __forceinline__ bool smp_wait(const aew_actor_t& a, const SmpEnv& e, 
             return false;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("" ::: "memory");                      // the row loads below are coherent (sc1) and stay below
     return true;
 }
 
 __device__ __forceinline__ void smp_signal(const aew_actor_t& a, const SmpEnv& e, uint32_t seq) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the whole wave's stores, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the whole wave's (write-through) stores, then the flag
     if (e.lane == 0) __hip_atomic_store(a.flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -83,7 +114,7 @@ __device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, c
     bf16x8_t x[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < nk) x[k] = *reinterpret_cast<const bf16x8_t*>(row + k * 64 + g * 16);
+        if (k < nk) x[k] = smp_ld_x(row + k * 64 + g * 16);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < nk) {
@@ -122,9 +153,9 @@ __device__ void smp_early(const aew_actor_t& a, const SmpEnv& e, int T) {
                 }
             const float* bp = a.bias + (int64_t)(b * 16 + e.i) * a.bias_pitch + e.g * 4;
             const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp), b1 = *reinterpret_cast<const f32x4_t*>(bp + 16);
-            f32x4_t* op = reinterpret_cast<f32x4_t*>(sbuf_at(a.out, b, t) + e.lane * 32);
-            op[0] = acc[0] + b0;
-            op[1] = acc[1] + b1;
+            char* op = sbuf_at(a.out, b, t) + e.lane * 32;
+            smp_st_f4(op, acc[0] + b0);
+            smp_st_f4(op + 16, acc[1] + b1);
             smp_signal(a, e, (uint32_t)(t * e.nb + b + 1));
         }
 }
@@ -136,13 +167,13 @@ __device__ void smp_late(const aew_actor_t& a, const SmpEnv& e, int T) {
     for (int t = 0; t < T; ++t)
         for (int b = 0; b < e.nb; ++b) {
             if (!smp_wait(a, e, t, b)) return;
-            const f32x4_t* pp = reinterpret_cast<const f32x4_t*>(sbuf_at(a.in1, b, t) + e.lane * 32);
-            f32x4_t acc[2] = {pp[0], pp[1]};
+            const char* pp = sbuf_at(a.in1, b, t) + e.lane * 32;
+            f32x4_t acc[2] = {smp_ld_f4(pp), smp_ld_f4(pp + 16)};
             smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t) + e.i * a.in0.pitch, a.nk, e.g);
             f32x4_t z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = tanh_f(acc[0][r]) * sigmoid_f(acc[1][r]);
-            *reinterpret_cast<uint2*>(sbuf_at(a.out, b, t) + e.i * a.out.pitch + e.g * 8) = smp_pack4(z);
+            smp_st_u2(sbuf_at(a.out, b, t) + e.i * a.out.pitch + e.g * 8, smp_pack4(z));
             smp_signal(a, e, (uint32_t)(t * e.nb + b + 1));
         }
 }
@@ -167,8 +198,8 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
 #pragma unroll
                 for (int k = 0; k < SMP_KD_MAX; ++k)
                     if (k < a.nk) {
-                        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(row + k * 128 + e.g * 32);
-                        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(row + k * 128 + e.g * 32 + 16);
+                        const f32x4_t lo = smp_ld_f4(row + k * 128 + e.g * 32);
+                        const f32x4_t hi = smp_ld_f4(row + k * 128 + e.g * 32 + 16);
                         uint4 u;
                         u.x = pack2_bf16(fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f));
                         u.y = pack2_bf16(fmaxf(lo[2], 0.f), fmaxf(lo[3], 0.f));
@@ -190,19 +221,19 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
             for (int n = 0; n < 2; ++n) {
                 if (n >= a.nt) break;
                 if (MODE == AEW_ACT_RES) {                           // h_{l+1} = h_l + W z            (wavenet.py:108-110)
-                    const uint2 r = *reinterpret_cast<const uint2*>(sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + n * 32 + e.g * 8);
-                    *reinterpret_cast<uint2*>(orow + n * 32 + e.g * 8) = smp_pack4(acc[n] + smp_unpack4(r));
+                    const uint2 r = smp_ld_u2(sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + n * 32 + e.g * 8);
+                    smp_st_u2(orow + n * 32 + e.g * 8, smp_pack4(acc[n] + smp_unpack4(r)));
                 } else if (MODE == AEW_ACT_SKIP) {                   // running skip sum, fp32       (wavenet.py:458)
                     f32x4_t prev = {0.f, 0.f, 0.f, 0.f};
-                    if (a.in1.ptr) prev = *reinterpret_cast<const f32x4_t*>(sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + n * 64 + e.g * 16);
-                    *reinterpret_cast<f32x4_t*>(orow + n * 64 + e.g * 16) = acc[n] + prev;
+                    if (a.in1.ptr) prev = smp_ld_f4(sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + n * 64 + e.g * 16);
+                    smp_st_f4(orow + n * 64 + e.g * 16, acc[n] + prev);
                 } else if (MODE == AEW_ACT_POST1) {                  // relu(post1(relu(skip)))      (wavenet.py:461-462)
                     f32x4_t v = acc[n];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    *reinterpret_cast<uint2*>(orow + n * 32 + e.g * 8) = smp_pack4(v);
+                    smp_st_u2(orow + n * 32 + e.g * 8, smp_pack4(v));
                 } else {                                             // logits
-                    *reinterpret_cast<f32x4_t*>(orow + n * 64 + e.g * 16) = acc[n];
+                    smp_st_f4(orow + n * 64 + e.g * 16, acc[n]);
                     if (a.out2.ptr)
                         *reinterpret_cast<f32x4_t*>(sbuf_at(a.out2, b, t) + e.i * a.out2.pitch + n * 64 + e.g * 16) = acc[n];
                 }
@@ -223,7 +254,7 @@ __device__ void smp_sample(const aew_actor_t& a, const SmpEnv& e, const aew_samp
         if (l16 == 0) s.wav_out[(int64_t)stream * T + t] = value;
         const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (int64_t)value * a.row_bytes);
         uint4* dst = reinterpret_cast<uint4*>(sbuf_at(a.out, b, t) + (a.index * 4 + sub) * a.out.pitch);
-        for (int c = l16; c < chunks; c += 16) dst[c] = src[c];
+        for (int c = l16; c < chunks; c += 16) smp_st16(dst + c, __builtin_bit_cast(SmpU16, src[c]));
     };
     for (int b = 0; b < e.nb; ++b) {                                 // position 0 is given
         const int stream = b * 16 + a.index * 4 + sub;
@@ -243,7 +274,19 @@ __device__ void smp_sample(const aew_actor_t& a, const SmpEnv& e, const aew_samp
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    if (k < per) { v[k] = lp[k]; mx = fmaxf(mx, v[k]); }
+                    if (k < per) {
+                        if (!(k & 1)) {                              // coherent 8-byte loads (per is even: Q % 32 == 0) or
+                            if (k + 1 < per) {                       // a single trailing word
+                                const unsigned long long w = smp_ld8(lp + k);
+                                v[k] = __uint_as_float((unsigned)w);
+                                v[k + 1] = __uint_as_float((unsigned)(w >> 32));
+                            } else {
+                                v[k] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(lp + k), __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT));
+                            }
+                        }
+                        mx = fmaxf(mx, v[k]);
+                    }
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
                 float part = 0.f;

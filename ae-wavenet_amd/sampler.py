@@ -134,14 +134,15 @@ class Sampler:
 
     # ---- one generation ----------------------------------------------------------------------------------------
     def generate(self, cond: torch.Tensor, bias: torch.Tensor, forced: torch.Tensor, seed: int = 0,
-                 want_logits: bool = False, spin_max: int = 0, stream: int = 0):
+                 want_logits: bool = False, spin_max: int = 0, stream: int = 0, timing: bool = False):
         """cond   bf16 [n_streams][>= T][>= Ck] (zero-padded channels; any row / stream strides that are multiples
                   of 8 elements): the upsampled local conditioning at every position (engine: dec.cond)
         bias   fp32 [n_streams][NL][>= n_pairs*32]: per-stream gated bias, (16 filt | 16 gate) per channel tile,
                   speaker term folded in (engine: dec.bias_bl as written by the spk_bias op)
         forced int32 [n_streams][T]: >= 0 feeds that value at the position, < 0 draws; column 0 must be >= 0
         Returns (wav int32 [n_streams][T], logits fp32 [n_streams][T][Q] or None).  logits[:, t] is the
-        distribution of position t+1 given positions <= t."""
+        distribution of position t+1 given positions <= t.  timing: HIP-event time of the kernel in self.last
+        (stream must be torch's current stream, i.e. 0 = the default stream)."""
         g = self.g
         n_streams, T = forced.shape
         if n_streams % 16:
@@ -202,9 +203,11 @@ class Sampler:
             return self.blob.data_ptr() + 2 * self.off[key]
 
         kr, kc, kd = g.Rk // 32, g.Ck // 32, g.Dk // 32
-        post_xcd = g.NL % 8
+        # consecutive layers share an XCD (its L2 serves their hand-offs); only every third hand-off crosses XCDs
+        xcd_layer = [(l * 8) // (g.NL + 1) for l in range(g.NL + 1)]
+        post_xcd = xcd_layer[g.NL]
         for l, d in enumerate(g.dils):
-            x = l % 8
+            x = xcd_layer[l]
             group("early", l, g.n_pairs)
             for pi in range(g.n_pairs):
                 a = new(L.ACT_EARLY, l, pi, x)
@@ -317,7 +320,14 @@ class Sampler:
         sp.flags, sp.status = flags.data_ptr(), status.data_ptr()
         sp.forced, sp.wav_out, sp.seed = forced.data_ptr(), wav_out.data_ptr(), seed & ((1 << 64) - 1)
         self.last = dict(n_slots=n_slots, n_actors=n_act, depth=depth)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timing else None
+        if ev:
+            ev[0].record()
         L.check(self.lib.aew_sampler_run(C.byref(sp), stream), "aew_sampler_run")
+        if ev:
+            ev[1].record()
+            ev[1].synchronize()
+            self.last["kernel_ms"] = ev[0].elapsed_time(ev[1])
         st = status.cpu().tolist()                                   # synchronises; keeps every buffer above alive
         if st[0]:
             raise L.AewError(f"sampler: actor in slot {st[1]} gave up waiting at t={st[2]}, batch {st[3]}")

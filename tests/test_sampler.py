@@ -78,7 +78,8 @@ TINY = dict(n_res=40, n_dil=16, n_skp=20, n_post=12, n_lc_out=8, n_global_embed=
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,over,B,w,tol", [("full-width", {}, 16, 48, 0.08), ("ragged-tiles", TINY, 32, 40, 0.03)])
+@pytest.mark.parametrize("name,over,B,w,tol", [("full-width", {}, 16, 48, 0.08), ("ragged-tiles", TINY, 32, 40, 0.03),
+                                               ("deep", dict(n_blocks=3, n_res=512), 16, 32, 0.1)])
 def test_teacher_forced_logits_match_training_forward(name, over, B, w, tol):
     hps, eng, wts, emb, inp = _engine(B, w, seed=5, **over)
     smp = S.from_engine(eng)
@@ -95,7 +96,7 @@ def test_teacher_forced_logits_match_training_forward(name, over, B, w, tol):
     print(f"{name}: sampler vs training forward, logit max abs err {err:.4f} (scale {train.abs().max().item():.2f}), "
           f"relative rms {rms:.2e}; {smp.last}")
     assert err <= tol and rms < 2e-2
-    if over:                                                        # small case: also straight against the fp32 oracle
+    if name == "ragged-tiles":                                      # small case: also straight against the fp32 oracle
         from oracle import ref_model as R
         with torch.no_grad():
             sd = {k: torch.from_numpy(v) for k, v in wts.items()}
