@@ -10,7 +10,6 @@ voice, jitter)`), with the semantics of autoencoder_model.py:206-259.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from .surface import HipModelBase, _BottleneckFacade, _EncoderFacade
@@ -34,24 +33,26 @@ class AutoEncoder(HipModelBase):
         (autoencoder_model.py:171-199).  `data_source` yields (wav, mel, voice, jitter, ...)."""
         if self.bn_type not in ("vqvae", "vqvae-ema"):
             raise RuntimeError("init_codebook only applies to the vqvae model types")
-        from scipy.cluster.vq import kmeans
+        from . import kmeans as KM
         d, K = self.hps.bn_n_out, self.hps.bn_vq_n_embed
-        samples = np.empty((n_samples, d), dtype=np.float64)
-        e = 0
+        samples, e = None, 0
         with torch.no_grad():
             while e != n_samples:
                 batch = next(data_source)
                 wav, mel, voice, jitter = batch[:4]
                 eng = self._ensure_engine(wav.shape[0])
+                if samples is None:
+                    samples = torch.empty(n_samples, d, dtype=torch.float32, device=eng.device)
                 eng.set_inputs(wav, mel, voice, jitter)
                 eng.fwd_a.run(eng._stream())
                 ze = eng.lin.tensor()[:, :, :d].reshape(-1, d)
                 c = min(n_samples - e, ze.shape[0])
-                samples[e:e + c] = ze[:c].cpu().numpy()
+                samples[e:e + c] = ze[:c]                        # stays in HBM
                 e += c
-        km, _ = kmeans(samples, K)
+        # Lloyd iterations on the device (kmeans.py); the reference calls scipy.cluster.vq.kmeans on the host here
+        codes, self.init_codebook_distortion, self.init_codebook_iters = KM.kmeans(samples, K, seed=getattr(self, "kmeans_seed", 0))
         eng = self._engine
-        emb = torch.from_numpy(km).float().to(eng.device)
+        emb = codes
         if self.bn_type == "vqvae-ema":
             eng.emb[:emb.shape[0]].copy_(emb)
             eng.init_ema_from_emb()

@@ -233,7 +233,8 @@ __global__ void k_vq_ema(const aew_vq_ema_t p) {
     const float nu = __fadd_rn(__fmul_rn(p.gamma, p.numer[e]), __fmul_rn(p.gamma_comp, p.z_sum[e]));
     const float de = __fadd_rn(__fmul_rn(p.gamma, p.denom[k]), __fmul_rn(p.gamma_comp, p.n_sum[k]));
     p.numer[e] = nu;
-    if (p.update_codebook) p.emb[e] = __fdiv_rn(nu, de);
+    // update_codebook 2 = k-means centroid step: a code that owns no sample keeps its position
+    if (p.update_codebook == 1 || (p.update_codebook == 2 && de > 0.f)) p.emb[e] = __fdiv_rn(nu, de);
     // every thread of row k computes the same `de`; the write is deferred to a second kernel so
     // no thread reads denom[k] after another thread of the row has overwritten it
     (void)j;

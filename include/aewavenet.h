@@ -188,7 +188,9 @@ typedef struct {                 /* z_sum/n_sum, deterministic order (vqema_bn.p
 
 typedef struct {                 /* EMA + optional codebook refresh (vqema_bn.py:190-195,216) */
     float* numer; float* denom; const float* z_sum; const float* n_sum;
-    float* emb;                  /* written when update_codebook != 0                         */
+    float* emb;                  /* written when update_codebook != 0; 2 = only rows with denom > 0 (with
+                                    gamma = 0, gamma_comp = 1 that is the centroid step of Lloyd's k-means,
+                                    autoencoder_model.py:171-199)                              */
     int32_t K, d, update_codebook;
     float gamma, gamma_comp;
 } aew_vq_ema_t;
