@@ -21,7 +21,7 @@ EF_RELU_POST = 1 << 9
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
- OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER) = range(1, 21)
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG) = range(1, 22)
 
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -161,12 +161,18 @@ class Jitter(C.Structure):
                 ("seed", C.c_uint64), ("step", C.c_uint64)]
 
 
+class VqDiag(C.Structure):
+    _fields_ = [("ze", vp), ("Q", i32), ("d", i32), ("d_pitch", i32), ("emb", vp), ("K", i32), ("hist", vp),
+                ("n_sum", vp), ("logits", vp), ("bs", i64), ("pitch", i32), ("B", i32), ("w", i32),
+                ("n_quant", i32), ("scratch", vp), ("out", vp)]
+
+
 class _OpU(C.Union):
     _fields_ = [("nt", GemmNT), ("tn", GemmTN), ("copy", CopyTable), ("vqn", VqNearest),
                 ("vqs", VqStats), ("vqe", VqEma), ("vqb", VqBwd), ("lcg", LcGather),
                 ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
                 ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
-                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter)]
+                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag)]
 
 
 class Op(C.Structure):
@@ -177,7 +183,8 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_VQ_STATS: "vqs", OP_VQ_EMA: "vqe", OP_VQ_BWD: "vqb", OP_LC_GATHER: "lcg",
             OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
-            OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit"}
+            OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit",
+            OP_VQ_DIAG: "diag"}
 
 # ---- autoregressive sampler (aew_actor_t / aew_sampler_t) ----
 ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMPLE = -1, 0, 1, 2, 3, 4, 5, 6
@@ -242,7 +249,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 8:
+    if lib.aew_abi_version() != 9:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

@@ -688,6 +688,129 @@ __global__ void k_jitter(const aew_jitter_t j) {
 }
 
 // =============================================================================================
+// per-step diagnostics (vqema_bn.py:155-160, 251-264; util.py:98-105) as two small kernels
+// =============================================================================================
+// scratch: double[2] = sum, sum of squares of the peak log-probability; float[256] at byte 16 = arg-max counts
+__global__ __launch_bounds__(256) void k_diag_peak(const aew_vq_diag_t p) {
+    __shared__ float bins[256];
+    __shared__ double part[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bins[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int64_t n_pos = (int64_t)p.B * (p.w - 1);
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t pos = (int64_t)blockIdx.x * 4 + wv; pos < n_pos; pos += (int64_t)gridDim.x * 4) {
+        const int b = (int)(pos / (p.w - 1)), u = (int)(pos % (p.w - 1));
+        const float* lg = p.logits + (int64_t)b * p.bs + (int64_t)u * p.pitch;
+        float mx = -INFINITY;
+        int am = 0;
+        for (int c = lane; c < p.n_quant; c += 64) {
+            const float v = lg[c];
+            if (v > mx) { mx = v; am = c; }                   // first maximum per lane (ascending c)
+        }
+        const float wmx = wave_max(mx);
+        // lowest class index among the lanes that hold the maximum (torch.max returns the first)
+        int cand = (mx == wmx) ? am : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+        float se = 0.f;
+        for (int c = lane; c < p.n_quant; c += 64) se += __expf(lg[c] - wmx);
+        se = wave_sum(se);
+        const float pk = -__logf(se);                         // max - logsumexp
+        if (lane == 0) {
+            s1 += (double)pk; s2 += (double)pk * (double)pk;
+            atomicAdd(&bins[cand & 255], 1.f);
+        }
+    }
+    if (lane == 0) { part[wv][0] = s1; part[wv][1] = s2; }
+    __syncthreads();
+    double* acc = reinterpret_cast<double*>(p.scratch);
+    float* gb = reinterpret_cast<float*>(reinterpret_cast<char*>(p.scratch) + 16);
+    if (threadIdx.x == 0) {
+        atomicAdd(acc, part[0][0] + part[1][0] + part[2][0] + part[3][0]);
+        atomicAdd(acc + 1, part[0][1] + part[1][1] + part[2][1] + part[3][1]);
+    }
+    if (bins[threadIdx.x] != 0.f) atomicAdd(gb + threadIdx.x, bins[threadIdx.x]);
+}
+
+__device__ __forceinline__ float block_red(float v, bool is_max, float* sh) {    // 1024 threads
+    v = is_max ? wave_max(v) : -wave_max(-v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < 16; ++i) r = is_max ? fmaxf(r, sh[i]) : fminf(r, sh[i]);
+    return r;
+}
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < 16; ++i) r += sh[i];
+    return r;
+}
+__global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
+    __shared__ float shf[16];
+    __shared__ double shd[16];
+    const int tid = threadIdx.x;
+    float o[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.ze) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int q = tid; q < p.Q; q += 1024) {
+            const float* z = p.ze + (int64_t)q * p.d_pitch;
+            float ss = 0.f;
+            for (int j = 0; j < p.d; ++j) ss += z[j] * z[j];
+            const float nr = sqrtf(ss);
+            lo = fminf(lo, nr); hi = fmaxf(hi, nr);
+        }
+        o[0] = block_red(lo, false, shf); o[1] = block_red(hi, true, shf);
+    }
+    if (p.emb) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int k = tid; k < p.K; k += 1024) {
+            const float* c = p.emb + (int64_t)k * p.d;
+            float ss = 0.f;
+            for (int j = 0; j < p.d; ++j) ss += c[j] * c[j];
+            const float nr = sqrtf(ss);
+            lo = fminf(lo, nr); hi = fmaxf(hi, nr);
+        }
+        o[2] = block_red(lo, false, shf); o[3] = block_red(hi, true, shf);
+    }
+    if (p.hist) {                                             // -sum n log2 n, n = hist / sum(hist); 0 log 0 = 0
+        double s = 0.0;
+        for (int k = tid; k < p.K; k += 1024) s += (double)p.hist[k];
+        const double tot = block_sum(s, shd);
+        double e = 0.0;
+        for (int k = tid; k < p.K; k += 1024) {
+            const double n = (double)p.hist[k] / tot;
+            if (n > 0.0) e -= n * log2(n);
+        }
+        o[4] = (float)block_sum(e, shd);
+    }
+    if (p.n_sum) {
+        double c = 0.0;
+        for (int k = tid; k < p.K; k += 1024) c += p.n_sum[k] > 0.f ? 1.0 : 0.0;
+        o[5] = (float)block_sum(c, shd);
+    }
+    if (p.logits) {
+        const double* acc = reinterpret_cast<const double*>(p.scratch);
+        const float* gb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scratch) + 16);
+        const double n = (double)p.B * (p.w - 1);
+        const double mean = acc[0] / n;
+        o[6] = (float)mean;
+        o[7] = n > 1.0 ? (float)sqrt(fmax((acc[1] - n * mean * mean) / (n - 1.0), 0.0)) : 0.f;   // torch.std: unbiased
+        double c = tid < 256 && gb[tid] > 0.f ? 1.0 : 0.0;
+        o[8] = (float)block_sum(c, shd);
+    }
+    if (tid < 9) p.out[tid] = o[tid];
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -744,6 +867,17 @@ static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_base_gather, dim3(cdiv64(cmax / 4, 64), p.T, p.B), dim3(64), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_vq_diag(const aew_vq_diag_t& p, hipStream_t st) {
+    if (!p.out || (p.logits && (!p.scratch || p.n_quant < 1 || p.n_quant > 256 || p.w < 2))) return AEW_E_ARG;
+    if (p.logits) {
+        hipError_t e = hipMemsetAsync(p.scratch, 0, 16 + 256 * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        const int64_t n_pos = (int64_t)p.B * (p.w - 1);
+        hipLaunchKernelGGL(k_diag_peak, dim3((unsigned)min((int64_t)1024, cdiv64(n_pos, 4))), dim3(256), 0, st, p);
+    }
+    hipLaunchKernelGGL(k_diag_final, dim3(1), dim3(1024), 0, st, p);
     return (int)hipGetLastError();
 }
 static int launch_softmax(const aew_softmax_nll_t& p, hipStream_t st) {

@@ -221,6 +221,22 @@ class TrainEngine:
             self._red_index = len(fb.ops)
         red.out = self.loss_buf.data_ptr()
         fb.add(L.OP_REDUCE, red, "loss", TAG_LOSS)
+        # per-step diagnostics the reference's loss modules report (vqema_bn.py:251-264): one fused reduction op,
+        # off the critical chain
+        self.diag = ws.alloc("diag.out", 16, torch.float32)
+        self.diag_scratch = ws.alloc("scratch.diag", 512, torch.float32)
+        dg = L.VqDiag()
+        if bn in ("vqvae-ema", "vqvae"):
+            dg.ze, dg.Q, dg.d, dg.d_pitch = self.lin.ptr, self.Q, hps.bn_n_out, self.lin.pitch
+            dg.K = hps.bn_vq_n_embed
+            dg.emb = self.emb.data_ptr() if bn == "vqvae-ema" else ps.ptr("bottleneck.emb")
+            if bn == "vqvae-ema":
+                dg.hist, dg.n_sum = self.ind_hist.data_ptr(), self.n_sum.data_ptr()
+        lgm = self.dec.logits
+        dg.logits, dg.bs, dg.pitch, dg.B, dg.w, dg.n_quant = lgm.ptr, lgm.bs, lgm.pitch, B, w, hps.n_quant
+        dg.scratch, dg.out = self.diag_scratch.data_ptr(), self.diag.data_ptr()
+        with fb.side(1):
+            fb.add(L.OP_VQ_DIAG, dg, "diagnostics", TAG_LOSS)
         # ===== backward
         self.bwd = bw = Plan("bwd")
         bw.zero(ws, "grads")

@@ -313,10 +313,16 @@ class HipModelBase(nn.Module):
         m = self.objective.metrics
         m["rec"] = eng.dec.nll[:B * w].sum() / n_pos
         self.tprb_m = eng.dec.ptgt[:B * w].sum() / n_pos            # chassis.py:266-270
+        dg = eng.diag                                              # AEW_OP_VQ_DIAG: one fused reduction op per step
+        m["pk_m"], m["pk_sd"], m["pk_nuq"] = dg[6], dg[7], dg[8]    # vqema_bn.py:261-263
         if eng.bn_type in ("vqvae-ema", "vqvae"):
             md = eng.min_dist[:eng.Q]
             m["com"] = (md * self.hps.bn_vq_gamma).mean()
-            m["nunq"] = eng.ind[:eng.Q].unique().numel
+            m["min_ze"], m["max_ze"], m["min_emb"], m["max_emb"] = dg[0], dg[1], dg[2], dg[3]   # vqema_bn.py:254-257
+            if eng.bn_type == "vqvae-ema":
+                m["hst_ent"], m["nunq"] = dg[4], dg[5]              # vqema_bn.py:258-260
+            else:
+                m["nunq"] = eng.ind[:eng.Q].unique().numel
         elif eng.bn_type == "vae":
             m["kl_div_loss"], m["log_pred_loss"] = eng.loss_buf[2], m["rec"]
         elif eng.bn_type == "ae":

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 8
+#define AEW_ABI_VERSION 9
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -270,6 +270,22 @@ typedef struct {                 /* fused log-softmax + NLL (+ gradient)  wavene
     int32_t backward;
 } aew_softmax_nll_t;
 
+typedef struct {                 /* per-step diagnostics of the reference's loss module as fused reductions
+                                    (vqema_bn.py:155-160 and :251-264, util.py:98-105; chassis.py:180-185 reads them):
+                                    out[0..1] min / max ||ze||, [2..3] min / max ||emb||, [4] entropy (bits) of the
+                                    normalised index histogram, [5] codes used this step, [6] mean, [7] unbiased std
+                                    of the peak log-probability over the positions that carry loss, [8] number of
+                                    distinct arg-max classes.  Groups with a NULL pointer are skipped (zeros).   */
+    const float* ze; int32_t Q, d, d_pitch;
+    const float* emb; int32_t K;
+    const float* hist;           /* accumulated index histogram [K] (aew_vq_stats_t.hist)      */
+    const float* n_sum;          /* this step's counts [K]                                     */
+    const float* logits; int64_t bs; int32_t pitch;         /* fp32 [B][w][>= n_quant]; u = w-1 is dropped */
+    int32_t B, w, n_quant;       /* n_quant <= 256                                             */
+    void* scratch;               /* >= 2 KiB, cleared by the op                                */
+    float* out;                  /* [12]                                                       */
+} aew_vq_diag_t;
+
 typedef struct {                 /* column sums over rows: out[b][n] (+)= sum_m x[b][m][n]     */
     aew_seg_t x; int32_t dtype; int32_t M, N, batch;
     float* out; int64_t out_bs; int32_t accumulate;
@@ -340,7 +356,7 @@ enum {
     AEW_OP_GEMM_NT = 1, AEW_OP_GEMM_TN, AEW_OP_COPY_TABLE, AEW_OP_VQ_NEAREST, AEW_OP_VQ_STATS,
     AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
     AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
-    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER
+    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
@@ -364,7 +380,7 @@ typedef struct {
         aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;
         aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
         aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
-        aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit;
+        aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit; aew_vq_diag_t diag;
     } u;
 } aew_op_t;
 

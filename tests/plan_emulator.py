@@ -215,8 +215,12 @@ class Emu:
         de = p.gamma * self.rd(p.denom, k) + p.gamma_comp * self.rd(p.n_sum, k)
         self.wr(p.numer, kd, nu)
         self.wr(p.denom, k, de)
-        if p.update_codebook:
+        if p.update_codebook == 1:
             self.wr(p.emb, kd, (nu.view(p.K, p.d) / de[:, None]).reshape(-1))
+        elif p.update_codebook == 2:                             # k-means centroid step: empty codes stay
+            old = self.rd(p.emb, kd).view(p.K, p.d)
+            new = torch.where(de[:, None] > 0, nu.view(p.K, p.d) / de[:, None].clamp_min(1e-30), old)
+            self.wr(p.emb, kd, new.reshape(-1))
 
     def op_7(self, p):   # VQ_BWD
         idx = torch.arange(p.Q)[:, None] * p.d_pitch + torch.arange(p.d)[None, :]
@@ -434,3 +438,26 @@ class Emu:
         idx = jitter_rng.device_indices(p.seed, p.step, p.B, p.n, p.p, p.mode)
         for b in range(p.B):
             self.wr(p.out, torch.arange(p.n) + b * p.out_pitch, torch.from_numpy(idx[b]))
+
+    def op_21(self, p):  # VQ_DIAG (vqema_bn.py:155-160, 251-264; util.py:98-105)
+        o = torch.zeros(9)
+        if p.ze:
+            z = self.rd(p.ze, torch.arange(p.Q)[:, None] * p.d_pitch + torch.arange(p.d)[None, :])
+            nr = (z ** 2).sum(1).sqrt()
+            o[0], o[1] = nr.min(), nr.max()
+        if p.emb:
+            e = self.rd(p.emb, torch.arange(p.K * p.d)).view(p.K, p.d)
+            nr = (e ** 2).sum(1).sqrt()
+            o[2], o[3] = nr.min(), nr.max()
+        if p.hist:
+            h = self.rd(p.hist, torch.arange(p.K)).double()
+            n = h / h.sum()
+            o[4] = -(n * torch.where(n == 0, torch.zeros_like(n), torch.log2(n))).sum()
+        if p.n_sum:
+            o[5] = (self.rd(p.n_sum, torch.arange(p.K)) > 0).sum()
+        if p.logits:
+            idx = (torch.arange(p.B)[:, None, None] * p.bs + torch.arange(p.w - 1)[None, :, None] * p.pitch
+                   + torch.arange(p.n_quant)[None, None, :])
+            pk, am = torch.log_softmax(self.rd(p.logits, idx).double(), -1).max(-1)
+            o[6], o[7], o[8] = pk.mean(), pk.std(), am.unique().numel()
+        self.wr(p.out, torch.arange(9), o)

@@ -256,7 +256,7 @@ def run_pair(ec, eg, z, eps=None):
     torch.cuda.synchronize()
 
 
-def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.")):
+def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.", "scratch.")):
     """First buffers (in allocation order) whose GPU content deviates from the interpreter."""
     bad = []
     for n, tc in ec.ws.bufs.items():
@@ -322,6 +322,8 @@ def test_autoencoder_step(golden_dir, name, gtag, ltag, kw):
         np.testing.assert_array_equal(eg.n_sum.cpu().numpy(), z["n_sum"])
         np.testing.assert_allclose(eg.z_sum.cpu().numpy(), z["z_sum"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(eg.ema_numer.cpu().numpy(), z["ema_numer"], rtol=1e-5, atol=1e-7)
+        from tests.test_plan_cpu import check_diagnostics
+        check_diagnostics(eg.diag.cpu().numpy(), z, exact=False)
         eg.update_codebook()
         np.testing.assert_allclose(eg.emb.cpu().numpy(), z["emb1"], rtol=1e-4, atol=1e-6)
 

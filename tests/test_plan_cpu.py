@@ -135,6 +135,21 @@ def test_autoencoder_vqema_plan(golden_dir, mode, jk, loss_mode, gtag, ltag):
     cnt = eng.enc.zero_cnt[:9].numpy().astype(np.float64)
     numel = np.array([eng.B * eng.geom.enc_lens[i + 1] * hps.enc_n_out for i in range(9)], np.float64)
     np.testing.assert_allclose(cnt / numel, z["enc_frac_zero"], atol=1e-9)
+    check_diagnostics(eng.diag.numpy(), z, exact=(mode == "wide"))
+
+
+def check_diagnostics(dg, z, exact):
+    """AEW_OP_VQ_DIAG against the metrics the reference's VQEMALoss reported (vqema_bn.py:251-264) and, for the
+    peak statistics (not stored in the fixtures), the same formulas on the reference's own `pred`."""
+    for i, k in enumerate(("min_ze", "max_ze", "min_emb", "max_emb", "hst_ent")):
+        np.testing.assert_allclose(dg[i], z["metric." + k], rtol=1e-4, err_msg=k)
+    assert dg[5] == float(z["metric.nunq"])
+    lp = torch.log_softmax(torch.from_numpy(z["pred"]).double(), 1)          # (B, Q, w-1)
+    pk, am = lp.max(dim=1)
+    tol_ = 1e-4 if exact else 3e-2
+    np.testing.assert_allclose(dg[6], float(pk.mean()), rtol=tol_, atol=tol_)
+    np.testing.assert_allclose(dg[7], float(pk.std()), rtol=tol_, atol=tol_)
+    assert abs(dg[8] - am.unique().numel()) <= (0 if exact else 3)
 
 
 def test_unfolded_wgrad_and_ones_channel_colsum(golden_dir, monkeypatch):
