@@ -28,6 +28,10 @@ class AutoEncoder(HipModelBase):
         except Exception:
             self.mfcc = None
 
+    @property
+    def decoder(self):                          # model.decoder.set_n_replicas(n) / .n_quant (wavenet.py:296)
+        return self
+
     def init_codebook(self, data_source, n_samples):
         """k-means initialisation of the codebook from encoder outputs
         (autoencoder_model.py:171-199).  `data_source` yields (wav, mel, voice, jitter, ...)."""

@@ -395,6 +395,23 @@ class TrainEngine:
         else:
             plan.run(self._stream())
 
+    def conditioning(self):
+        """Encoder / bottleneck and the conditioning half of the decoder forward only (jitter gather, lc_conv,
+        upsampler, speaker bias): what the autoregressive sampler needs (wavenet.py:379-391).  No EMA update, no
+        loss.  Returns (cond bf16 [B][T][Cp], gated bias fp32 [B][NL][2*Dp])."""
+        if getattr(self, "_cond_plan", None) is None:
+            fb = self.fwd_b
+            stop = fb.labels.index("G1.0") if "G1.0" in fb.labels else next(
+                i for i, l in enumerate(fb.labels) if l.startswith("G1.0"))
+            keep = [i for i in range(stop) if fb.labels[i] != "vq.ema"]
+            cp = Plan("conditioning")
+            cp.ops, cp.labels = [fb.ops[i] for i in keep], [fb.labels[i] for i in keep]
+            self._cond_plan = cp
+        self._run(self.fwd_a, False)
+        self._run(self._cond_plan, False)
+        d = self.dec
+        return d.cond.tensor(), d.bias_bl[:self.B * d.NL * 2 * d.Dp].view(self.B, d.NL, 2 * d.Dp)
+
     def forward(self, ema_allreduce=None, timing=False):
         """timing=True forces eager launches (the per-op event timing needs them).
         ema_allreduce(z_sum, n_sum): cross-rank sum of the EMA statistics.  If it returns a work handle

@@ -98,6 +98,11 @@ class HipModelBase(nn.Module):
         self._ema_allreduce = None
         self._dp = None
         self.objective = Objective(self)
+        # inference surface (chassis.py:296, 313: model.wavenet.set_n_replicas / .n_quant; `model.wavenet` of the
+        # MFCC inverter is the model itself here)
+        self.n_quant, self.n_replicas = hps.n_quant, 1
+        self.sample_seed = 0
+        self._sampler = None
         self._anchor = torch.zeros((), requires_grad=True)
         # geometry attributes of the reference classes (autoencoder_model.py:119-146,
         # mfcc_inverter.py:38-65)
@@ -105,6 +110,9 @@ class HipModelBase(nn.Module):
         # Parameters exist from construction (Checkpoint builds Adam before .to(device),
         # checkpoint.py:48-50); they are re-homed into the engine's flat buffer on first use.
         self._make_cpu_params()
+
+    def set_n_replicas(self, n_replicas):                       # wavenet.py:296-297
+        self.n_replicas = int(n_replicas)
 
     # ---- geometry / harness queries ------------------------------------------------------
     def _set_geometry(self, w):
@@ -285,11 +293,44 @@ class HipModelBase(nn.Module):
         return pred, target, loss
 
     def forward(self, wav, mel, voice, jitter):
-        """Logits (B, Q, w) for the batch (teacher-forced)."""
+        """train(): logits (B, Q, w) for the batch (teacher-forced).  eval(): the reference's inference call
+        (mfcc_inverter.py:80-85 -> WaveNet.forward_test, wavenet.py:367-531): generates `n_replicas` continuations
+        of the single input window and returns (1 + n_replicas, dec_in_len) mu-law values, row 0 = the input."""
+        if not self.training:
+            return self.sample(wav, mel, voice, jitter)
         eng = self._ensure_engine(wav.shape[0])
         eng.set_inputs(wav, mel, voice, jitter)
         eng.forward(self._ema_allreduce)
         return eng.logits().permute(0, 2, 1)
+
+    def sample(self, wav, mel, voice, jitter, n_prime: Optional[int] = None, seed: Optional[int] = None):
+        """Autoregressive generation on the persistent-kernel sampler (sampler.py).  The first n_prime positions of
+        the decoder window are fed from `wav` (default: receptive field + 1, like the reference, which starts
+        drawing at base_global_rf, wavenet.py:423-431); the rest are drawn.  One input window (B = 1); replicas are
+        parallel streams (wavenet.py:378-381)."""
+        from . import sampler as S
+        if wav.shape[0] != 1:
+            raise L.AewError("sampling takes one window; replicas come from set_n_replicas()")
+        R = max(1, int(self.n_replicas))
+        with torch.no_grad():
+            eng = self._ensure_engine(1)
+            eng.set_inputs(wav, mel, voice, jitter)
+            cond, bias = eng.conditioning()
+            stamp = (id(eng), eng.ps.params._version)
+            if self._sampler is None or self._sampler[0] != stamp:       # weights are re-packed when they changed
+                self._sampler = (stamp, S.from_engine(eng))
+            smp = self._sampler[1]
+            g = eng.geom
+            T, rf = g.dec_in_len, smp.g.rf()
+            n16 = (R + 15) // 16 * 16
+            given = wav[:, g.trim_dec_in[0]:g.trim_dec_in[0] + T].to(torch.int32)
+            forced = given.expand(n16, -1).clone()
+            forced[:, min(T, rf + 1 if n_prime is None else max(1, n_prime)):] = -1
+            if seed is None:
+                seed, self.sample_seed = self.sample_seed, self.sample_seed + 1
+            out, _ = smp.generate(cond.expand(n16, -1, -1).contiguous(), bias.expand(n16, -1, -1).contiguous(),
+                                  forced.contiguous(), seed=seed)
+            return torch.cat([given, out[:R]], 0).float()
 
     def _after_backward(self, g):
         eng = self._engine

@@ -623,8 +623,51 @@ def gen_jitter():
     print("wrote jitter_stats.json", os.path.getsize(os.path.join(HERE, "jitter_stats.json")), "bytes")
 
 
+def gen_sampler():
+    """The reference's own autoregressive sampler (WaveNet.forward_test, wavenet.py:367-531) on a tiny MfccInverter:
+    the sequence it generates for 2 replicas and the probabilities it handed to torch.multinomial at every step
+    (captured by wrapping torch.multinomial; the draw itself uses a seeded generator).  Only the first N_KEEP
+    steps' probabilities are stored."""
+    N_KEEP, R, W = 96, 2, 80
+    hps = make_hps(**{**TINY, "n_win_batch": W}, n_lc_in=7)
+    torch.manual_seed(0)
+    m = mfcc_inverter.MfccInverter(hps)
+    w = load_np_weights(m, 11)
+    m.eval()
+    m.wavenet.set_n_replicas(R)
+    g = torch.Generator().manual_seed(3)
+    n_mel = m.embed_len
+    wav = torch.randint(0, hps.n_quant, (1, m.enc_in_len), generator=g).float()
+    mel = torch.randn(1, hps.n_lc_in, n_mel, generator=g)
+    voice = torch.randint(0, hps.n_speakers, (1,), generator=g)
+    jitter = torch.arange(n_mel).repeat(1, 1)
+    probs, orig, dg = [], torch.multinomial, torch.Generator().manual_seed(17)
+
+    def spy(p, n, replacement=False, **kw):
+        if len(probs) < N_KEEP:
+            probs.append(t2n(p).copy())
+        return orig(p, n, replacement, generator=dg)
+    torch.multinomial = spy
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = m(wav, mel, voice, jitter)
+    finally:
+        torch.multinomial = orig
+    wn = m.wavenet
+    res = dict(wav=t2n(wav), mel=t2n(mel), voice=t2n(voice), jitter=t2n(jitter),
+               out=t2n(out).astype(np.int16), probs=np.stack(probs).astype(np.float32),
+               rf=np.array(int(wn.base_global_rf)), wav_cond_offset=np.array([int(v) for v in wn.wav_cond_offset]),
+               n_win_batch=np.array(W),
+               hps_json=np.array(json.dumps({k: hps[k] for k in list(TINY) + ["n_lc_in", "lc_upsample_strides",
+                                             "lc_upsample_filt_sizes", "filter_sz", "mfcc_win_sz", "mfcc_hop_sz", "bias"]})))
+    res.update({"w." + k: v for k, v in w.items()})
+    save("mi_tiny_sampler.npz", **res)
+
+
 def main():
-    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt", "jitter"]
+    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt", "jitter", "sampler"]
+    if "sampler" in which:
+        gen_sampler()
     if "jitter" in which:
         gen_jitter()
     if "ckpt" in which:

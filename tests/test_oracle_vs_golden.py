@@ -339,3 +339,42 @@ def test_adam_matches_torch():
         opt.step()
         q, m, v = R.adam_step(q, g, m, v, step, 1e-3)
         np.testing.assert_allclose(q.numpy(), p.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------
+# the reference's autoregressive sampler (WaveNet.forward_test, wavenet.py:367-531)
+# ------------------------------------------------------------------------------------------
+def sampler_case(golden_dir):
+    """Fixture mi_tiny_sampler.npz: the sequences the unmodified reference sampler generated for two replicas and
+    the probabilities it passed to torch.multinomial at its first 96 steps.  Returns what both the oracle test
+    below and the GPU sampler test need."""
+    z = load(golden_dir, "mi_tiny_sampler.npz")
+    hps, _ = tiny_hps(z, global_model="mfcc_inverter", n_win_batch=int(z["n_win_batch"]))
+    geom = geometry.model_geometry(hps, False, hps.n_win_batch)
+    rf = int(z["rf"]) - 1                                      # reference counts the current sample in its "rf"
+    assert [geom.trim_dec_in[0], geom.trim_dec_in[0] + geom.dec_in_len] == z["wav_cond_offset"].tolist()
+    assert geom.dec_in_len == geom.n_win + rf
+    out = z["out"].astype(np.int64)                            # [1 + R][n_ts]: row 0 = the given wav
+    assert np.array_equal(out[0], z["wav"][0, geom.trim_dec_in[0]:].astype(np.int64))
+    assert np.array_equal(out[1:, :rf + 1], np.repeat(out[:1, :rf + 1], out.shape[0] - 1, 0))   # primed with rf + 1 samples
+    return z, hps, geom, rf, out
+
+
+def test_reference_sampler_is_the_training_graph_run_incrementally(golden_dir):
+    """What the parity of the MI355X sampler rests on: the probabilities the reference sampler draws from at
+    position c are softmax of the TRAINING graph's output (the oracle's decoder_forward, itself pinned above) for
+    the sequence generated so far.  Step s of the reference draws position rf + 1 + s."""
+    z, hps, geom, rf, out = sampler_case(golden_dir)
+    sd = {k: v.detach() for k, v in sd_from(z).items()}
+    mel, voice, jitter = torch.from_numpy(z["mel"]), torch.from_numpy(z["voice"]), torch.from_numpy(z["jitter"])
+    n = geom.n_win
+    for r in range(out.shape[0] - 1):
+        wav = torch.from_numpy(z["wav"]).clone()
+        o = geom.trim_dec_in[0]
+        wav[0, o:o + geom.dec_in_len] = torch.from_numpy(out[1 + r, :geom.dec_in_len]).float()
+        with torch.no_grad():
+            quant = R.decoder_forward(sd, "wavenet.", hps, wav, mel, voice, jitter, o, geom.dec_in_len,
+                                      geom.trim_ups_out, take_compat=True)
+        p = torch.softmax(quant[0], 0).t().numpy()             # [n_win][Q]; row i: position i + rf + 1
+        steps = min(n, z["probs"].shape[0])
+        np.testing.assert_allclose(p[:steps], z["probs"][:steps, r], rtol=2e-4, atol=1e-7)

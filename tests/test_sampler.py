@@ -1,13 +1,16 @@
 """Autoregressive sampler (ae_wavenet_amd/sampler.py, csrc/aew_sampler.hip) — replaces WaveNet.forward_test
 (wavenet.py:367-531).
 
-The reference sampler cannot run at HEAD (it reads attributes the current WaveNet class no longer has: n_replicas,
-base_global_rf, set_full/set_incremental, layer.global_rf - SURVEY 3.5), so parity is anchored on what it is
-defined to compute: at every position the distribution of the NEXT sample given the samples so far is the
-training graph's output (wavenet.py:323-364) for that prefix.  Teacher-forcing the sampler over a sequence must
-therefore reproduce the training forward's logits, which are themselves pinned against the reference goldens and
-the fp32 oracle (tests/test_gpu_parity.py).  The draw is checked against a numpy restatement of the inverse-CDF
-rule fed with the device's own logits and the counter RNG of oracle/jitter_rng.py.
+Pinning.  tests/golden/mi_tiny_sampler.npz holds what the UNMODIFIED reference sampler did on a tiny MfccInverter:
+the sequences it generated for two replicas and the probabilities it passed to torch.multinomial at every step.
+  * CPU (tests/test_oracle_vs_golden.py): those probabilities are softmax of the training graph's output
+    (oracle decoder_forward) for the sequence generated so far - the reference sampler IS the training graph run
+    incrementally (rtol 2e-4 over 160 steps).
+  * GPU, here: teacher-forcing the MI355X sampler with the reference's sequences reproduces the reference's
+    probabilities; at full width, where the reference loop is too slow to generate fixtures, teacher-forcing must
+    reproduce the engine's training forward (itself pinned to the reference goldens and the fp32 oracle).
+torch.multinomial's random stream is not reproduced: the draw is an inverse-CDF lookup on a counter RNG, checked
+against a numpy restatement fed with the device's own logits (oracle/jitter_rng.py).
 """
 import numpy as np
 import pytest
@@ -150,3 +153,61 @@ def test_free_running_generation():
     pick = np.take_along_axis(lp[:, n_prime - 1:T - 1], wv[:, n_prime:T, None].astype(np.int64), axis=2)[..., 0]
     ent = (np.exp(lp[:, n_prime - 1:T - 1]) * lp[:, n_prime - 1:T - 1]).sum(-1)
     assert abs(pick.mean() - ent.mean()) < 0.35, (pick.mean(), ent.mean())
+
+
+@pytest.mark.gpu
+def test_reference_sampler_probabilities(golden_dir):
+    """Teacher-forced with the sequences the reference sampler generated, the MI355X sampler computes the
+    probabilities the reference drew from (fixture captured from WaveNet.forward_test, wavenet.py:463-464)."""
+    from tests.test_oracle_vs_golden import sampler_case
+    z, hps, geom, rf, out = sampler_case(golden_dir)
+    eng = M.TrainEngine(hps, B=1, device=DEV, n_mel=hps.n_lc_in, take_compat=True)
+    for k in eng.ps.names():
+        eng.ps.view(k).copy_(torch.from_numpy(z["w." + k]))
+    eng.set_inputs(*[torch.from_numpy(z[k]).to(DEV) for k in ("wav", "mel", "voice", "jitter")])
+    eng.forward()
+    smp = S.from_engine(eng)
+    assert smp.g.rf() == rf
+    cond, bias = S.engine_conditioning(eng)
+    T = geom.dec_in_len
+    # the reference's n_replicas = repeated stream rows (wavenet.py:378-381)
+    cond16, bias16 = cond.expand(16, -1, -1).contiguous(), bias.expand(16, -1, -1).contiguous()
+    forced = torch.from_numpy(np.stack([out[1 + (i % 2), :T] for i in range(16)])).to(torch.int32).to(DEV)
+    wav, logits = smp.generate(cond16, bias16, forced, want_logits=True)
+    p = torch.softmax(logits.double(), -1).cpu().numpy()            # [16][T][Q]; row t: position t + 1
+    steps = min(geom.n_win, z["probs"].shape[0])
+    worst = 0.0
+    for i in range(16):
+        ref = z["probs"][:steps, i % 2]
+        got = p[i, rf:rf + steps]
+        worst = max(worst, np.abs(got - ref).max() / ref.max())
+        np.testing.assert_allclose(got, ref, rtol=4e-2, atol=2e-4)
+    print("sampler vs reference forward_test probabilities: worst |dp| / max p =", worst)
+
+
+@pytest.mark.gpu
+def test_module_surface_eval_forward_samples(golden_dir):
+    """The reference's inference call (chassis.py:296, 325-330): model.wavenet.set_n_replicas(n); model.eval();
+    wav = model(wav, mel, voice, jitter) -> (1 + n, T), row 0 the input, the rest generated after rf + 1 primed
+    samples."""
+    from ae_wavenet_amd import mfcc_inverter as mi
+    from tests.test_oracle_vs_golden import sampler_case
+    z, hps, geom, rf, out = sampler_case(golden_dir)
+    m = mi.MfccInverter(hps, take_compat=True)
+    m.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("w.")})
+    m = m.to(DEV)
+    m.eval()
+    m.wavenet.set_n_replicas(2)
+    args = [torch.from_numpy(z[k]).to(DEV) for k in ("wav", "mel", "voice", "jitter")]
+    got = m(*args)
+    T = geom.dec_in_len
+    assert got.shape == (3, T) and got.dtype == torch.float32
+    given = torch.from_numpy(out[0, :T]).float().to(DEV)
+    assert torch.equal(got[0], given)
+    assert torch.equal(got[1:, :rf + 1], given[None, :rf + 1].expand(2, -1))
+    assert not torch.equal(got[1], got[2]) and 0 <= float(got.min()) and float(got.max()) < 256
+    again = m.sample(*args, seed=0)                                 # the first call used seed 0
+    assert torch.equal(again, got)
+    assert not torch.equal(m(*args), got)                           # the next call draws afresh
+    m.train()
+    assert m(*args).shape == (1, 256, geom.n_win)                   # train(): teacher-forced logits as before
