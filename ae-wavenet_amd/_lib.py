@@ -208,7 +208,7 @@ class Actor(C.Structure):
 class Sampler(C.Structure):
     _fields_ = [("actors", vp), ("n_slots", i32), ("n_batches", i32), ("n_steps", i32), ("flag_stride", i32),
                 ("kr_max", i32), ("spin_max", i32), ("flags", vp), ("status", vp), ("forced", vp),
-                ("wav_out", vp), ("seed", C.c_uint64)]
+                ("wav_out", vp), ("seed", C.c_uint64), ("nap_eighths", i32), ("pad", i32), ("prof", vp)]
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaewavenet_hip.so")

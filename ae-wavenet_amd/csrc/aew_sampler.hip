@@ -22,6 +22,25 @@ struct SmpEnv {
     int nb, fstride, spin_max;
     uint32_t* status;
     int slot;
+    // Napping.  ~1000 actors polling at once saturate the memory-side path their flags and rows travel on (a row load
+    // took 2 us under that load, 0.2 us without).  An actor's items arrive periodically (once per sample per batch), so
+    // after publishing one it sleeps through `nap_num`/8 of the running average of its own period before it polls.
+    mutable unsigned long long t_pub, period;
+    int nap_num;
+    uint64_t* prof;                                    // optional phase clock of this actor (aew_sampler_t.prof)
+    mutable unsigned long long t_mark, acc_wait, acc_work, acc_pub, items;
+    __device__ __forceinline__ void lap(int phase) const {       // 0 after the wait, 1 after the stores, 2 after the flag
+        if (!prof) return;
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        const unsigned long long d = now - t_mark;
+        t_mark = now;
+        if (phase == 0) acc_wait += d;
+        else if (phase == 1) acc_work += d;
+        else { acc_pub += d; ++items; }
+    }
+    __device__ __forceinline__ void dump() const {
+        if (prof && lane == 0) { prof[0] = acc_wait; prof[1] = acc_work; prof[2] = acc_pub; prof[3] = items; }
+    }
 };
 
 // Activation rows and flags travel between wavefronts on different CUs / XCDs.  They are read and written with
@@ -68,6 +87,10 @@ __device__ __forceinline__ bool smp_wait(const aew_actor_t& a, const SmpEnv& e, 
     const int tt = t - lag;
     const uint32_t need = (fl && j < n && tt >= 0) ? (uint32_t)(tt * e.nb + b + 1) : 0u;
     const uint32_t* p = fl ? fl + (int64_t)j * e.fstride : nullptr;
+    if (e.nap_num > 0 && e.period != 0ull) {
+        const unsigned long long wake = e.t_pub + ((e.period * (unsigned long long)e.nap_num) >> 3);
+        for (int n = 0; n < 4096 && __builtin_amdgcn_s_memtime() < wake; ++n) __builtin_amdgcn_s_sleep(16);
+    }
     if (__any(need != 0u)) {
         bool ok = false;
         for (int spin = 0; spin < e.spin_max; ++spin) {
@@ -85,12 +108,23 @@ __device__ __forceinline__ bool smp_wait(const aew_actor_t& a, const SmpEnv& e, 
         }
     }
     asm volatile("" ::: "memory");                      // the row loads below are coherent (sc1) and stay below
+    e.lap(0);
     return true;
 }
 
 __device__ __forceinline__ void smp_signal(const aew_actor_t& a, const SmpEnv& e, uint32_t seq) {
+    if (e.prof) { asm volatile("s_nop 0" ::: "memory"); e.lap(1); }   // stores issued (work = loads + MFMAs + issue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the whole wave's (write-through) stores, then the flag
     if (e.lane == 0) __hip_atomic_store(a.flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e.nap_num > 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (e.t_pub != 0ull) {
+            const unsigned long long d = now - e.t_pub;
+            e.period = e.period == 0ull ? d : (e.period * 3 + d) >> 2;
+        }
+        e.t_pub = now;
+    }
+    e.lap(2);
 }
 
 template <int KMAX>
@@ -112,6 +146,19 @@ struct SmpW {                                          // register-resident weig
 template <int KMAX>
 __device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, const char* row, int nk, int g) {
     bf16x8_t x[KMAX];
+    if (nk == KMAX) {
+        // the usual case (full-width decoder), written without the per-tile `k < nk` tests: with them every K tile is
+        // its own basic block and the compiler waits for each block's loads before issuing the next block's
+        // (8 trips to memory for a POST1 row, 2 for a RES row; measured in the ISA), instead of one
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) x[k] = smp_ld_x(row + k * 64 + g * 16);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][0], x[k], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][1], x[k], acc[1], 0, 0, 0);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < nk) x[k] = smp_ld_x(row + k * 64 + g * 16);
@@ -195,11 +242,26 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
             const char* row = sbuf_at(a.in0, b, t) + e.i * a.in0.pitch;
             if (MODE == AEW_ACT_POST1) {                             // fp32 skip sum -> relu -> bf16 fragments
                 bf16x8_t x[SMP_KD_MAX];
+                f32x4_t raw[SMP_KD_MAX][2];
+                if (a.nk == SMP_KD_MAX) {                            // all 16 loads in flight (see smp_mm)
+#pragma unroll
+                    for (int k = 0; k < SMP_KD_MAX; ++k) {
+                        raw[k][0] = smp_ld_f4(row + k * 128 + e.g * 32);
+                        raw[k][1] = smp_ld_f4(row + k * 128 + e.g * 32 + 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < SMP_KD_MAX; ++k)
+                        if (k < a.nk) {
+                            raw[k][0] = smp_ld_f4(row + k * 128 + e.g * 32);
+                            raw[k][1] = smp_ld_f4(row + k * 128 + e.g * 32 + 16);
+                        }
+                }
 #pragma unroll
                 for (int k = 0; k < SMP_KD_MAX; ++k)
                     if (k < a.nk) {
-                        const f32x4_t lo = smp_ld_f4(row + k * 128 + e.g * 32);
-                        const f32x4_t hi = smp_ld_f4(row + k * 128 + e.g * 32 + 16);
+                        const f32x4_t lo = raw[k][0];
+                        const f32x4_t hi = raw[k][1];
                         uint4 u;
                         u.x = pack2_bf16(fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f));
                         u.y = pack2_bf16(fmaxf(lo[2], 0.f), fmaxf(lo[3], 0.f));
@@ -324,8 +386,9 @@ __device__ void smp_sample(const aew_actor_t& a, const SmpEnv& e, const aew_samp
         }
 }
 
+// two actors per SIMD must fit (a DEEP decoder has 1684): at most 256 registers per wavefront
 template <int KR>
-__global__ __launch_bounds__(64) void k_sampler(const aew_sampler_t s) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sampler(const aew_sampler_t s) {
     const int slot = blockIdx.x;
     const aew_actor_t a = s.actors[slot];               // by value: wave-uniform, lives in SGPRs
     const int role = __builtin_amdgcn_readfirstlane(a.role);
@@ -334,6 +397,11 @@ __global__ __launch_bounds__(64) void k_sampler(const aew_sampler_t s) {
     e.lane = threadIdx.x; e.i = e.lane & 15; e.g = e.lane >> 4;
     e.nb = s.n_batches; e.fstride = s.flag_stride; e.spin_max = s.spin_max > 0 ? s.spin_max : SMP_SPIN_DEFAULT;
     e.status = s.status; e.slot = slot;
+    e.t_pub = e.period = 0ull;
+    e.nap_num = s.nap_eighths < 0 ? 0 : (s.nap_eighths > 7 ? 7 : s.nap_eighths);
+    e.prof = s.prof ? s.prof + (int64_t)slot * 4 : nullptr;
+    e.acc_wait = e.acc_work = e.acc_pub = e.items = 0;
+    e.t_mark = s.prof ? __builtin_amdgcn_s_memtime() : 0ull;
     switch (role) {
         case AEW_ACT_EARLY: smp_early<KR>(a, e, s.n_steps); break;
         case AEW_ACT_LATE: smp_late<KR>(a, e, s.n_steps); break;
@@ -344,6 +412,7 @@ __global__ __launch_bounds__(64) void k_sampler(const aew_sampler_t s) {
         case AEW_ACT_SAMPLE: smp_sample(a, e, s); break;
         default: break;
     }
+    e.dump();
 }
 
 static int launch_sampler(const aew_sampler_t& s, hipStream_t st) {

@@ -76,6 +76,7 @@ class Sampler:
         self.g = g = SamplerGeometry(hps)
         self.hps, self.pre, self.dev = hps, pre, torch.device(device)
         self.flag_stride = flag_stride
+        self.nap_eighths = 0                                       # napping between items: measured neutral (r01_sampler.txt)
         self.lib = L.load()
         self._pack(ps)
 
@@ -134,7 +135,8 @@ class Sampler:
 
     # ---- one generation ----------------------------------------------------------------------------------------
     def generate(self, cond: torch.Tensor, bias: torch.Tensor, forced: torch.Tensor, seed: int = 0,
-                 want_logits: bool = False, spin_max: int = 0, stream: int = 0, timing: bool = False):
+                 want_logits: bool = False, spin_max: int = 0, stream: int = 0, timing: bool = False,
+                 profile: bool = False):
         """cond   bf16 [n_streams][>= T][>= Ck] (zero-padded channels; any row / stream strides that are multiples
                   of 8 elements): the upsampled local conditioning at every position (engine: dec.cond)
         bias   fp32 [n_streams][NL][>= n_pairs*32]: per-stream gated bias, (16 filt | 16 gate) per channel tile,
@@ -319,6 +321,9 @@ class Sampler:
         sp.flag_stride, sp.kr_max, sp.spin_max = fs, g.kr_max, spin_max
         sp.flags, sp.status = flags.data_ptr(), status.data_ptr()
         sp.forced, sp.wav_out, sp.seed = forced.data_ptr(), wav_out.data_ptr(), seed & ((1 << 64) - 1)
+        sp.nap_eighths = self.nap_eighths
+        prof = torch.zeros(n_slots, 4, dtype=torch.int64, device=dev) if profile else None
+        sp.prof = prof.data_ptr() if profile else None
         self.last = dict(n_slots=n_slots, n_actors=n_act, depth=depth)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timing else None
         if ev:
@@ -329,6 +334,17 @@ class Sampler:
             ev[1].synchronize()
             self.last["kernel_ms"] = ev[0].elapsed_time(ev[1])
         st = status.cpu().tolist()                                   # synchronises; keeps every buffer above alive
+        if profile:                                                  # per-role phase clock (s_memtime runs at 100 MHz)
+            pc = prof.cpu()
+            roles: Dict[int, List[int]] = {}
+            for sl in range(n_slots):
+                if table[sl].role >= 0 and int(pc[sl, 3]) > 0:
+                    roles.setdefault((table[sl].role, min(table[sl].layer, 1)), []).append(sl)
+            names = {0: "EARLY", 1: "LATE", 2: "RES", 3: "SKIP", 4: "POST1", 5: "POST2", 6: "SAMPLE"}
+            self.last["profile"] = {
+                f"{names[r]}{'' if r > 3 else ('.0' if l0 == 0 else '.l')}": [
+                    float(pc[sl_list, c].double().mean() / pc[sl_list, 3].double().mean()) * 0.01 for c in range(3)]
+                for (r, l0), sl_list in sorted(roles.items())}           # us per item: wait, work, publish
         if st[0]:
             raise L.AewError(f"sampler: actor in slot {st[1]} gave up waiting at t={st[2]}, batch {st[3]}")
         return wav_out, logits_out

@@ -525,6 +525,12 @@ typedef struct {
     const int32_t* forced;       /* [n_streams][n_steps]: value fed at position t if >= 0, else the draw   */
     int32_t* wav_out;            /* [n_streams][n_steps] the sequence that was fed (forced or drawn)       */
     uint64_t seed;               /* u(stream, t) = mix64-counter uniform, see oracle/jitter_rng.py         */
+    int32_t nap_eighths;         /* 0..7: after publishing an item an actor sleeps through this many eighths of the
+                                    running average of its own item period before it polls again (fewer pollers
+                                    on the memory-side path); 0 = poll at once                                */
+    int32_t pad;
+    uint64_t* prof;              /* optional [n_slots][4]: s_memtime cycles (100 MHz) each actor spent waiting,
+                                    loading + computing, publishing; [3] = items.  NULL = off               */
 } aew_sampler_t;
 
 /* Enqueue one generation on `stream`.  Returns AEW_E_UNSUP if the device cannot keep n_slots

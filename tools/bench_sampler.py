@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--batches", default="1,2,4,8,16,32")
     ap.add_argument("--flag-stride", type=int, default=16)
+    ap.add_argument("--nap", type=int, default=-1, help="nap_eighths override (0..7)")
+    ap.add_argument("--profile", action="store_true", help="per-role phase clock for the 1-batch run")
     ap.add_argument("--deep", action="store_true", help="30 layers x 512 residual channels")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -38,6 +40,8 @@ def main():
             t.uniform_(-0.1, 0.1, generator=gen)
         ps.view(k).copy_(t)
     smp = S.Sampler(hps, ps, "decoder.", dev, flag_stride=args.flag_stride)
+    if args.nap >= 0:
+        smp.nap_eighths = args.nap
     g = smp.g
     T = args.steps
     hops = 2 * g.NL + 4
@@ -54,6 +58,10 @@ def main():
         for _ in range(3):
             wav, _ = smp.generate(cond, bias, forced, seed=2, timing=True)
             best = min(best, smp.last["kernel_ms"])
+        if args.profile and nb == 1:
+            smp.generate(cond, bias, forced, seed=2, profile=True)
+            for k, v in smp.last["profile"].items():
+                print(f"    {k:9s} us per item: wait {v[0]:7.2f}  load+compute {v[1]:6.2f}  publish {v[2]:6.2f}")
         us = best * 1e3 / T
         print(f"batches {nb:3d} ({n:4d} streams): {us:8.2f} us/step  {1e6 / us:9.0f} samples/s/stream  "
               f"{n * 1e6 / us / 1e6:8.3f} M samples/s total   ({us / nb:6.2f} us per batch-step, "
