@@ -134,12 +134,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # AEW_BENCH_SHARE_GPU=1 + AEW_BENCH_BACKEND=gloo: all ranks on cuda:0 over gloo - a functional check of the
+    # multi-process path on a one-GPU box (tools/measure_round.sh), not a measurement
+    share = os.environ.get("AEW_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("AEW_BENCH_BACKEND", "nccl")
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dp = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         from ae_wavenet_amd.dp import DataParallel
         dp = DataParallel()
 
