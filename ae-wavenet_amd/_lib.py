@@ -21,7 +21,7 @@ EF_RELU_POST = 1 << 9
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
- OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG) = range(1, 22)
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC) = range(1, 23)
 
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -167,12 +167,19 @@ class VqDiag(C.Structure):
                 ("n_quant", i32), ("scratch", vp), ("out", vp)]
 
 
+class Mfcc(C.Structure):
+    _fields_ = [("wav", vp), ("wav_bs", i64), ("n", i32), ("B", i32), ("win", i32), ("hop", i32), ("n_bins", i32),
+                ("n_mels", i32), ("n_mfcc", i32), ("left_pad", i32), ("trim_left", i32), ("trim_right", i32),
+                ("n_frames", i32), ("window", vp), ("twiddle", vp), ("melw", vp), ("dct", vp), ("sg", vp),
+                ("scratch", vp), ("out", vp), ("out_bs", i64), ("out_pitch", i32)]
+
+
 class _OpU(C.Union):
     _fields_ = [("nt", GemmNT), ("tn", GemmTN), ("copy", CopyTable), ("vqn", VqNearest),
                 ("vqs", VqStats), ("vqe", VqEma), ("vqb", VqBwd), ("lcg", LcGather),
                 ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
                 ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
-                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag)]
+                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag), ("mfcc", Mfcc)]
 
 
 class Op(C.Structure):
@@ -184,7 +191,7 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
             OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit",
-            OP_VQ_DIAG: "diag"}
+            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc"}
 
 # ---- autoregressive sampler (aew_actor_t / aew_sampler_t) ----
 ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMPLE = -1, 0, 1, 2, 3, 4, 5, 6
@@ -249,7 +256,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 9:
+    if lib.aew_abi_version() != 10:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

@@ -811,6 +811,102 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
 }
 
 // =============================================================================================
+// MFCC front-end (mfcc.py:39-76).  Tiny and latency-bound: a B x 74-frame batch is 93 MFLOP.
+// =============================================================================================
+// grid (n_frames, B): one frame per block.  scratch: [B][n_frames][n_mels] dB | [B][n_frames] frame max
+__global__ __launch_bounds__(256) void k_mfcc_mel(const aew_mfcc_t p) {
+    __shared__ float s[1024];
+    __shared__ float pw[520];
+    __shared__ float red[4];
+    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int Ly = p.left_pad + p.n;
+    const float* wav = p.wav + (int64_t)b * p.wav_bs;
+    for (int n = tid; n < p.win; n += 256) {
+        int i = f * p.hop + n - p.win / 2;                    // index into y, reflected at both ends (center=True)
+        if (i < 0) i = -i;
+        if (i >= Ly) i = 2 * (Ly - 1) - i;
+        const float v = (i >= p.left_pad && i < Ly && i >= 0) ? wav[i - p.left_pad] : 0.f;
+        s[n] = v * p.window[n];
+    }
+    __syncthreads();
+    for (int k = tid; k < p.n_bins; k += 256) {
+        float re = 0.f, im = 0.f;
+        int idx = 0;
+        for (int n = 0; n < p.win; ++n) {
+            const float2 w = reinterpret_cast<const float2*>(p.twiddle)[idx];
+            re += s[n] * w.x;
+            im -= s[n] * w.y;
+            idx += k;
+            if (idx >= p.win) idx -= p.win;
+        }
+        pw[k] = re * re + im * im;
+    }
+    __syncthreads();
+    float db = -INFINITY;
+    if (tid < p.n_mels) {
+        const float* w = p.melw + (int64_t)tid * p.n_bins;
+        float a = 0.f;
+        for (int k = 0; k < p.n_bins; ++k) a += w[k] * pw[k];
+        db = 10.f * log10f(fmaxf(a, 1e-10f));
+        p.scratch[((int64_t)b * p.n_frames + f) * p.n_mels + tid] = db;
+    }
+    const float m = wave_max(db);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0)
+        p.scratch[(int64_t)p.B * p.n_frames * p.n_mels + (int64_t)b * p.n_frames + f] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// grid (B): top_db floor, DCT, trim, derivatives
+__global__ __launch_bounds__(256) void k_mfcc_finish(const aew_mfcc_t p) {
+    __shared__ float red[4];
+    __shared__ float thr_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* db = p.scratch + (int64_t)b * p.n_frames * p.n_mels;
+    const float* fmx = p.scratch + (int64_t)p.B * p.n_frames * p.n_mels + (int64_t)b * p.n_frames;
+    float* cep = p.scratch + (int64_t)p.B * p.n_frames * (p.n_mels + 1) + (int64_t)b * p.n_frames * p.n_mfcc;   // [n_mfcc][n_frames]
+    float m = -INFINITY;
+    for (int f = tid; f < p.n_frames; f += 256) m = fmaxf(m, fmx[f]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) thr_s = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - 80.f;
+    __syncthreads();
+    const float thr = thr_s;
+    for (int e = tid; e < p.n_frames * 16; e += 256) {
+        const int f = e >> 4, c = e & 15;
+        if (c >= p.n_mfcc) continue;
+        const float* d = p.dct + (int64_t)c * p.n_mels;
+        const float* x = db + (int64_t)f * p.n_mels;
+        float a = 0.f;
+        for (int j = 0; j < p.n_mels; ++j) a += d[j] * fmaxf(x[j], thr);
+        cep[(int64_t)c * p.n_frames + f] = a;
+    }
+    __syncthreads();                                          // (block-scope visibility of the global writes above)
+    const int Ft = p.n_frames - p.trim_left - p.trim_right;
+    float* out = p.out + (int64_t)b * p.out_bs;
+    for (int e = tid; e < Ft * 16; e += 256) {
+        const int f = e >> 4, c = e & 15;
+        if (c >= p.n_mfcc) continue;
+        const float* x = cep + (int64_t)c * p.n_frames + p.trim_left;       // trimmed series of coefficient c
+        out[(int64_t)c * p.out_pitch + f] = x[f];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {                         // Savitzky-Golay width 9, mode='interp' at the edges
+            const float* sg = p.sg + o * 81;
+            float a = 0.f;
+            if (f < 4) {
+                for (int j = 0; j < 9; ++j) a += sg[9 + f * 9 + j] * x[j];
+            } else if (f >= Ft - 4) {
+                for (int j = 0; j < 9; ++j) a += sg[45 + (f - (Ft - 4)) * 9 + j] * x[Ft - 9 + j];
+            } else {
+                for (int j = 0; j < 9; ++j) a += sg[j] * x[f - 4 + j];
+            }
+            out[(int64_t)((o + 1) * p.n_mfcc + c) * p.out_pitch + f] = a;
+        }
+    }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -878,6 +974,18 @@ static int launch_vq_diag(const aew_vq_diag_t& p, hipStream_t st) {
         hipLaunchKernelGGL(k_diag_peak, dim3((unsigned)min((int64_t)1024, cdiv64(n_pos, 4))), dim3(256), 0, st, p);
     }
     hipLaunchKernelGGL(k_diag_final, dim3(1), dim3(1024), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_mfcc(const aew_mfcc_t& p, hipStream_t st) {
+    if (!p.wav || !p.out || !p.scratch || !p.window || !p.twiddle || !p.melw || !p.dct || !p.sg) return AEW_E_ARG;
+    if (p.win < 2 || p.win > 1024 || p.n_bins != p.win / 2 + 1 || p.n_mels < 1 || p.n_mels > 128 || p.n_mfcc < 1 ||
+        p.n_mfcc > 16 || p.hop < 1 || p.B < 1)
+        return AEW_E_ARG;
+    if (p.n_frames != 1 + (p.left_pad + p.n) / p.hop || p.left_pad + p.n <= p.win / 2) return AEW_E_ARG;
+    const int Ft = p.n_frames - p.trim_left - p.trim_right;
+    if (Ft < 9 || Ft > p.out_pitch) return AEW_E_ARG;
+    hipLaunchKernelGGL(k_mfcc_mel, dim3(p.n_frames, p.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_mfcc_finish, dim3(p.B), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 static int launch_softmax(const aew_softmax_nll_t& p, hipStream_t st) {

@@ -6,7 +6,9 @@ copied with `non_blocking=True` on a dedicated copy stream while the previous st
 stream waits on the copy's event only (no host sync).  With `jitter=DeviceJitter(...)` the jitter indices
 (4th item) are generated on the device for the batch's (B, frames) instead of being shipped from the host
 (the reference builds them element by element with numpy.random.choice in the collate function,
-data.py:232-233).
+data.py:232-233).  With `mfcc=DeviceMfcc(...)` the conditioning input `mel` (2nd item) is computed on the device from
+the staged wav windows (AEW_OP_MFCC) instead of by librosa in the collate function (data.py:230, mfcc.py:39-76); the
+host then only ships the wav bytes and the batch's 2nd item may be None.
 
     for wav, mel, voice, jitter, *rest in DevicePrefetcher(loader, "cuda:0", jitter=DeviceJitter(0.12, seed)):
         pred, target, loss = model.run(wav, mel, voice, jitter)
@@ -20,7 +22,7 @@ import torch
 
 
 class DevicePrefetcher:
-    def __init__(self, batches: Iterable, device, depth: int = 2, jitter=None):
+    def __init__(self, batches: Iterable, device, depth: int = 2, jitter=None, mfcc=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("DevicePrefetcher stages batches for a cuda device")
@@ -29,6 +31,7 @@ class DevicePrefetcher:
         self.it = iter(batches)
         self.depth = depth
         self.jitter = jitter
+        self.mfcc = mfcc
         self.copy_stream = torch.cuda.Stream(self.device)
         self._pinned = [dict() for _ in range(depth + 1)]      # slot -> {(item index): pinned tensor}
         self._slot = 0
@@ -52,12 +55,15 @@ class DevicePrefetcher:
         out = []
         with torch.cuda.stream(self.copy_stream):
             for i, x in enumerate(items):
-                if torch.is_tensor(x) and not (self.jitter is not None and i == 3):
+                skip = (self.jitter is not None and i == 3) or (self.mfcc is not None and i == 1)
+                if torch.is_tensor(x) and not skip:
                     out.append(self._stage(slot, i, x).to(self.device, non_blocking=True))
                 else:
                     out.append(x)
+            if self.mfcc is not None:
+                out[1] = self.mfcc(out[0].float())                # on the copy stream, behind the wav copy
             if self.jitter is not None and len(items) > 3:
-                mel = items[1]
+                mel = out[1]
                 out[3] = self.jitter(mel.shape[0], mel.shape[2], self.device)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 9
+#define AEW_ABI_VERSION 10
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -270,6 +270,23 @@ typedef struct {                 /* fused log-softmax + NLL (+ gradient)  wavene
     int32_t backward;
 } aew_softmax_nll_t;
 
+typedef struct {                 /* MFCC + delta + delta-delta front-end on the device (mfcc.py:39-76: librosa.feature.mfcc
+                                    and librosa.feature.delta on the host in the reference's DataLoader, data.py:230).
+                                    Frame f of the call covers y[f*hop - win/2, f*hop + win/2), y = left_pad zeros + wav,
+                                    reflected at both ends; |DFT|^2 -> mel -> dB (floor max - 80 over the whole call)
+                                    -> DCT-II -> trim -> Savitzky-Golay derivatives (width 9).  Tables come from the host. */
+    const float* wav; int64_t wav_bs; int32_t n;            /* [B][n] samples (float-encoded)                  */
+    int32_t B, win, hop, n_bins, n_mels, n_mfcc;            /* win <= 1024, n_bins = win/2 + 1, n_mels <= 128, n_mfcc <= 16 */
+    int32_t left_pad, trim_left, trim_right, n_frames;      /* n_frames = 1 + (left_pad + n) / hop, before trimming */
+    const float* window;         /* [win]                                                      */
+    const float* twiddle;        /* [win][2]  cos, sin (2 pi j / win)                          */
+    const float* melw;           /* [n_mels][n_bins]                                           */
+    const float* dct;            /* [n_mfcc][n_mels]                                           */
+    const float* sg;             /* [2][81]: per derivative 9 interior taps, 4x9 left-edge and 4x9 right-edge rows */
+    float* scratch;              /* B * n_frames * (n_mels + 1 + n_mfcc) floats                */
+    float* out; int64_t out_bs; int32_t out_pitch;          /* [B][3*n_mfcc][out_pitch]; frames n_frames - trims (>= 9) */
+} aew_mfcc_t;
+
 typedef struct {                 /* per-step diagnostics of the reference's loss module as fused reductions
                                     (vqema_bn.py:155-160 and :251-264, util.py:98-105; chassis.py:180-185 reads them):
                                     out[0..1] min / max ||ze||, [2..3] min / max ||emb||, [4] entropy (bits) of the
@@ -356,7 +373,7 @@ enum {
     AEW_OP_GEMM_NT = 1, AEW_OP_GEMM_TN, AEW_OP_COPY_TABLE, AEW_OP_VQ_NEAREST, AEW_OP_VQ_STATS,
     AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
     AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
-    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG
+    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG, AEW_OP_MFCC
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
@@ -380,7 +397,7 @@ typedef struct {
         aew_vq_stats_t vqs; aew_vq_ema_t vqe; aew_vq_bwd_t vqb; aew_lc_gather_t lcg;
         aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
         aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
-        aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit; aew_vq_diag_t diag;
+        aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit; aew_vq_diag_t diag; aew_mfcc_t mfcc;
     } u;
 } aew_op_t;
 
