@@ -699,28 +699,45 @@ __global__ __launch_bounds__(256) void k_diag_peak(const aew_vq_diag_t p) {
     __syncthreads();
     const int64_t n_pos = (int64_t)p.B * (p.w - 1);
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t pos = (int64_t)blockIdx.x * 4 + wv; pos < n_pos; pos += (int64_t)gridDim.x * 4) {
-        const int b = (int)(pos / (p.w - 1)), u = (int)(pos % (p.w - 1));
-        const float* lg = p.logits + (int64_t)b * p.bs + (int64_t)u * p.pitch;
+    // 16 lanes per position, 4 positions per wave and iteration, the row read ONCE into registers (the first version
+    // walked one position per wave with two dependent passes over its row: 159 us for 40 k positions)
+    const int sub = lane >> 4, l16 = lane & 15;
+    const int per = (p.n_quant + 15) >> 4;                        // <= 16 classes per lane, contiguous
+    for (int64_t pos0 = ((int64_t)blockIdx.x * 4 + wv) * 4; pos0 < n_pos; pos0 += (int64_t)gridDim.x * 16) {
+        const int64_t pos = pos0 + sub;
+        const bool live = pos < n_pos;
+        const int64_t pc = live ? pos : n_pos - 1;
+        const int b = (int)(pc / (p.w - 1)), u = (int)(pc % (p.w - 1));
+        const float* lg = p.logits + (int64_t)b * p.bs + (int64_t)u * p.pitch + l16 * per;
+        float v[16];
         float mx = -INFINITY;
         int am = 0;
-        for (int c = lane; c < p.n_quant; c += 64) {
-            const float v = lg[c];
-            if (v > mx) { mx = v; am = c; }                   // first maximum per lane (ascending c)
-        }
-        const float wmx = wave_max(mx);
-        // lowest class index among the lanes that hold the maximum (torch.max returns the first)
-        int cand = (mx == wmx) ? am : 0x7fffffff;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+        for (int k = 0; k < 16; ++k) {
+            v[k] = (k < per && l16 * per + k < p.n_quant) ? lg[k] : -INFINITY;
+            if (v[k] > mx) { mx = v[k]; am = l16 * per + k; }       // first maximum of the lane (ascending class)
+        }
+        float gmx = mx;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, o, 16));
+        int cand = (mx == gmx) ? am : 0x7fffffff;                 // lowest class among the lanes holding the maximum
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) cand = min(cand, __shfl_xor(cand, o, 16));
         float se = 0.f;
-        for (int c = lane; c < p.n_quant; c += 64) se += __expf(lg[c] - wmx);
-        se = wave_sum(se);
-        const float pk = -__logf(se);                         // max - logsumexp
-        if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) se += __expf(v[k] - gmx);     // exp(-inf) = 0 for the padding
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o, 16);
+        const float pk = -__logf(se);                             // max - logsumexp
+        if (live && l16 == 0) {
             s1 += (double)pk; s2 += (double)pk * (double)pk;
             atomicAdd(&bins[cand & 255], 1.f);
         }
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {                           // the four position slots of the wave
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
     }
     if (lane == 0) { part[wv][0] = s1; part[wv][1] = s2; }
     __syncthreads();
@@ -759,26 +776,37 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
     __shared__ double shd[16];
     const int tid = threadIdx.x;
     float o[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.ze) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int q = tid; q < p.Q; q += 1024) {
-            const float* z = p.ze + (int64_t)q * p.d_pitch;
+    // row norms: 8 lanes per row, one float4 each per 32 channels (a thread-per-row walk touches 64 cache lines per
+    // load instruction and made this single block the whole cost of the op: 0.13 ms for 4096 codes)
+    auto norms = [&](const float* base, int rows, int pitch, float& lo, float& hi) {
+        lo = INFINITY; hi = -INFINITY;
+        const int part = tid & 7;
+        for (int r0 = 0; r0 < rows; r0 += 128) {
+            const int r = r0 + (tid >> 3);
             float ss = 0.f;
-            for (int j = 0; j < p.d; ++j) ss += z[j] * z[j];
-            const float nr = sqrtf(ss);
-            lo = fminf(lo, nr); hi = fmaxf(hi, nr);
+            if (r < rows) {
+                const float* x = base + (int64_t)r * pitch;
+                if ((p.d & 3) == 0 && (pitch & 3) == 0) {
+                    for (int j = part * 4; j < p.d; j += 32) {
+                        const float4 v = *reinterpret_cast<const float4*>(x + j);
+                        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    }
+                } else {
+                    for (int j = part; j < p.d; j += 8) ss += x[j] * x[j];
+                }
+            }
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+            if (r < rows) { const float nr = sqrtf(ss); lo = fminf(lo, nr); hi = fmaxf(hi, nr); }
         }
+    };
+    if (p.ze) {
+        float lo, hi;
+        norms(p.ze, p.Q, p.d_pitch, lo, hi);
         o[0] = block_red(lo, false, shf); o[1] = block_red(hi, true, shf);
     }
     if (p.emb) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int k = tid; k < p.K; k += 1024) {
-            const float* c = p.emb + (int64_t)k * p.d;
-            float ss = 0.f;
-            for (int j = 0; j < p.d; ++j) ss += c[j] * c[j];
-            const float nr = sqrtf(ss);
-            lo = fminf(lo, nr); hi = fmaxf(hi, nr);
-        }
+        float lo, hi;
+        norms(p.emb, p.K, p.d, lo, hi);
         o[2] = block_red(lo, false, shf); o[3] = block_red(hi, true, shf);
     }
     if (p.hist) {                                             // -sum n log2 n, n = hist / sum(hist); 0 log 0 = 0
@@ -787,8 +815,8 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
         const double tot = block_sum(s, shd);
         double e = 0.0;
         for (int k = tid; k < p.K; k += 1024) {
-            const double n = (double)p.hist[k] / tot;
-            if (n > 0.0) e -= n * log2(n);
+            const float n = (float)((double)p.hist[k] / tot);
+            if (n > 0.f) e -= (double)(n * log2f(n));
         }
         o[4] = (float)block_sum(e, shd);
     }
@@ -971,7 +999,7 @@ static int launch_vq_diag(const aew_vq_diag_t& p, hipStream_t st) {
         hipError_t e = hipMemsetAsync(p.scratch, 0, 16 + 256 * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
         const int64_t n_pos = (int64_t)p.B * (p.w - 1);
-        hipLaunchKernelGGL(k_diag_peak, dim3((unsigned)min((int64_t)1024, cdiv64(n_pos, 4))), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_diag_peak, dim3((unsigned)min((int64_t)512, cdiv64(n_pos, 16))), dim3(256), 0, st, p);
     }
     hipLaunchKernelGGL(k_diag_final, dim3(1), dim3(1024), 0, st, p);
     return (int)hipGetLastError();
