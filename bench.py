@@ -256,6 +256,12 @@ def main():
                 "tn_bf16": {"achieved": round((fl["step"] / 3.0) / (cls_ms.get(2, 1e9) * 1e-3) / 1e12, 2),
                             "ms_per_step": round(cls_ms.get(2, 0.0), 4)},
                 "ms_per_step_by_class": {str(k): round(v, 4) for k, v in sorted(cls_ms.items())}}
+        # the same launches against the HBM roofline: measured bytes per launch (PMC) / measured time per launch.  At
+        # K = 256..1024 with 3-4 activation tensors in and out the stack's intensity (~240 FLOP/B) is below the ridge
+        # (2500 / 8 = 312), see profiles/r01_op_roofline.txt
+        if roof["traffic"]:
+            tbps = roof["traffic"]["bytes_per_launch"] / (nt_ms / n_launch * 1e-3) / 1e12
+            roof["hbm_view"] = {"achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
 
     cpu = None
     if world > 1:
