@@ -150,20 +150,23 @@ class Packer:
     pack   params(fp32)        -> packed weights (bf16 / f32)
     unpack wgrad slabs (fp32)  -> flat grads (fp32), summing `slabs` partials."""
 
-    def __init__(self, ps: ParamStore, pack_tbl: CopyTableBuilder, unpack_tbl: CopyTableBuilder):
+    def __init__(self, ps: ParamStore, pack_tbl: CopyTableBuilder, unpack_tbl: CopyTableBuilder,
+                 late_tbl: Optional[CopyTableBuilder] = None):
         self.ps, self.pack_tbl, self.unpack_tbl = ps, pack_tbl, unpack_tbl
+        self.late_tbl = late_tbl            # packs that only the backward reads (dgrad layouts): off the forward's start
 
     def rec(self, pname: str, p_off: int, p_strides: Sequence[int], dims: Sequence[int],
             w_mat: Optional[Mat], w_off: int, w_strides: Sequence[int],
             g_ptr: int = 0, g_strides: Optional[Sequence[int]] = None, slabs: int = 0, slab_stride: int = 0,
-            g_off: Optional[int] = None):
+            g_off: Optional[int] = None, late: bool = False):
         """One rectangular piece.  p_* address the parameter tensor (elements, relative to the
         parameter), w_* the packed forward matrix, g_* the wgrad slab (defaults to the same
         layout as the packed matrix)."""
         ps = self.ps
         if w_mat is not None:
-            self.pack_tbl.add(ps.ptr(pname) + 4 * p_off, w_mat.ptr + w_off * ESIZE[w_mat.dtype],
-                              dims, p_strides, w_strides, F3, w_mat.dtype)
+            tbl = self.late_tbl if (late and self.late_tbl is not None) else self.pack_tbl
+            tbl.add(ps.ptr(pname) + 4 * p_off, w_mat.ptr + w_off * ESIZE[w_mat.dtype],
+                    dims, p_strides, w_strides, F3, w_mat.dtype)
         if g_ptr:
             gs = list(g_strides if g_strides is not None else w_strides)
             go = w_off if g_off is None else g_off
@@ -742,14 +745,15 @@ class EncoderPlan:
             self.W.append(Wm)
             if s == 1:
                 WT = Mat.new(ws, f"enc.wpT.{i}", 1, cinp, f * Ep, F3)
-                packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], WT, 0, [1, f * Ep, Ep])
+                packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], WT, 0, [1, f * Ep, Ep], late=True)
                 self.WT.append([WT])
             else:
                 phs = []
                 for ph in range(s):
                     WT = Mat.new(ws, f"enc.wpT.{i}.{ph}", 1, cinp, (f // s) * Ep, F3)
                     # [ci][j*Ep + co] <- W[co][ci][ph + s*j]
-                    packer.rec(nm + "weight", ph, [cin * f, f, s], [E, cin, f // s], WT, 0, [1, (f // s) * Ep, Ep])
+                    packer.rec(nm + "weight", ph, [cin * f, f, s], [E, cin, f // s], WT, 0, [1, (f // s) * Ep, Ep],
+                               late=True)
                     phs.append(WT)
                 self.WT.append(phs)
             bt = ws.alloc(f"enc.wp.bias{i}", Ep, torch.float32)

@@ -73,7 +73,8 @@ class TrainEngine:
         self.pack_dec = CopyTableBuilder(ws, "tbl.pack_dec")
         self.unpack_dec = CopyTableBuilder(ws, "tbl.unpack_dec")
         self.in_tbl = CopyTableBuilder(ws, "tbl.in")
-        self.pk = Packer(ps, self.pack_tbl, self.unpack_tbl)
+        self.pack_late = CopyTableBuilder(ws, "tbl.pack_late")      # dgrad layouts of the encoder weights: backward only
+        self.pk = Packer(ps, self.pack_tbl, self.unpack_tbl, late_tbl=self.pack_late)
         self.pk_dec = Packer(ps, self.pack_dec, self.unpack_dec)
         Mp = ru(self.n_mel, 64)
         self.mel_cl = Mat.new(ws, "mel_cl", B, g.mel_len, Mp, F3)
@@ -196,6 +197,10 @@ class TrainEngine:
                 an = self._ae_norm_op(False)
                 fa.add(L.OP_AE_NORM, an, "ae.norm", TAG_VQ)
         # ===== forward, part B: decoder + loss
+        with fb.side(2):                                       # only the backward reads these: hidden under the decoder
+            self.pack_late.emit(fb, "pack weights (backward layouts)")
+        for op in fb.ops[-1:] if self.pack_late.recs else []:
+            op.tag = TAG_PACK
         self.dec.build_forward(fb)
         red = L.Reduce()
         nll_ptr = self.dec.nll.data_ptr()
