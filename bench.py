@@ -91,7 +91,7 @@ def cpu_baseline(hps, eng, seconds_budget=40.0):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    """HBM bytes per launch (a number, as the bench contract asks) of the dominant kernel from the committed PMC passes
     (profiles/r01_pmc_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     same command, FETCH doubled per MI355X_MICROARCH.md).  bench.py cannot collect PMCs itself."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
@@ -103,7 +103,7 @@ def pmc_traffic():
                 k = float(r["launches"])
                 n += k
                 tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
-        return {"bytes_per_launch": round(tot / n), "source": "profiles/r01_pmc_hbm_traffic.csv"} if n else None
+        return round(tot / n) if n else None
     except Exception:
         return None
 
@@ -259,8 +259,9 @@ def main():
         # the same launches against the HBM roofline: measured bytes per launch (PMC) / measured time per launch.  At
         # K = 256..1024 with 3-4 activation tensors in and out the stack's intensity (~240 FLOP/B) is below the ridge
         # (2500 / 8 = 312), see profiles/r01_op_roofline.txt
+        roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2)"
         if roof["traffic"]:
-            tbps = roof["traffic"]["bytes_per_launch"] / (nt_ms / n_launch * 1e-3) / 1e12
+            tbps = roof["traffic"] / (nt_ms / n_launch * 1e-3) / 1e12
             roof["hbm_view"] = {"achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
 
     cpu = None
