@@ -136,7 +136,7 @@ class Sampler:
     # ---- one generation ----------------------------------------------------------------------------------------
     def generate(self, cond: torch.Tensor, bias: torch.Tensor, forced: torch.Tensor, seed: int = 0,
                  want_logits: bool = False, spin_max: int = 0, stream: int = 0, timing: bool = False,
-                 profile: bool = False):
+                 profile: bool = False, dry_run: bool = False):
         """cond   bf16 [n_streams][>= T][>= Ck] (zero-padded channels; any row / stream strides that are multiples
                   of 8 elements): the upsampled local conditioning at every position (engine: dec.cond)
         bias   fp32 [n_streams][NL][>= n_pairs*32]: per-stream gated bias, (16 filt | 16 gate) per channel tile,
@@ -144,7 +144,9 @@ class Sampler:
         forced int32 [n_streams][T]: >= 0 feeds that value at the position, < 0 draws; column 0 must be >= 0
         Returns (wav int32 [n_streams][T], logits fp32 [n_streams][T][Q] or None).  logits[:, t] is the
         distribution of position t+1 given positions <= t.  timing: HIP-event time of the kernel in self.last
-        (stream must be torch's current stream, i.e. 0 = the default stream)."""
+        (stream must be torch's current stream, i.e. 0 = the default stream).  dry_run: build the actor table only
+        (works with CPU tensors) and return a description of it - tests/test_sampler.py replays the protocol from
+        that under random schedules."""
         g = self.g
         n_streams, T = forced.shape
         if n_streams % 16:
@@ -315,6 +317,13 @@ class Sampler:
         for x in range(8):
             for pos, k in enumerate(per_xcd[x]):
                 C.memmove(C.byref(table, (x + 8 * pos) * C.sizeof(L.Actor)), C.byref(acts[k]), C.sizeof(L.Actor))
+        if dry_run:
+            bufs = {f"h{l}": hbuf[l] for l in range(g.NL)}
+            bufs.update({f"z{l}": zbuf[l] for l in range(g.NL)})
+            bufs.update({f"e{l}": epart[l] for l in range(g.NL)})
+            bufs.update(skp=skp, p1=p1, logits=logits)
+            return dict(table=table, n_slots=n_slots, nb=nb, T=T, flag_stride=fs, flags=flags.data_ptr(),
+                        buffers={k: (v.data_ptr(), v.numel() * v.element_size()) for k, v in bufs.items()}, keep=bufs)
         raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
         sp = L.Sampler()
         sp.actors, sp.n_slots, sp.n_batches, sp.n_steps = raw.data_ptr(), n_slots, nb, T

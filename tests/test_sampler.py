@@ -211,3 +211,127 @@ def test_module_surface_eval_forward_samples(golden_dir):
     assert not torch.equal(m(*args), got)                           # the next call draws afresh
     m.train()
     assert m(*args).shape == (1, 256, geom.n_win)                   # train(): teacher-forced logits as before
+
+
+# ---- the actor protocol, replayed on the CPU -------------------------------------------------------------------------
+def _replay(desc, seed, max_rounds=100000):
+    """Executes the actor table as a set of state machines under a RANDOM schedule: an actor may run its next item
+    only when its wait sets are satisfied (the rule of smp_wait), running an item publishes its flag (smp_signal).
+    Checks (1) nobody starves (no deadlock), (2) every row an actor reads still holds the item it expects - i.e. the
+    flags it waited for really cover its inputs, and no producer has overwritten a ring slot a reader still needs."""
+    import random
+    rnd = random.Random(seed)
+    tbl, nb, T, fs, f0 = desc["table"], desc["nb"], desc["T"], desc["flag_stride"], desc["flags"]
+    bufs = sorted((p, p + n, k) for k, (p, n) in desc["buffers"].items())
+
+    def buf_of(ptr):
+        for lo, hi, k in bufs:
+            if lo <= ptr < hi:
+                return k
+        raise AssertionError("pointer outside every sampler buffer")
+
+    acts = [tbl[i] for i in range(desc["n_slots"]) if tbl[i].role >= 0]
+    flag = {a.flag: 0 for a in acts}
+    for a in acts:
+        if a.role == L.ACT_SAMPLE:
+            flag[a.flag] = nb                                       # prologue: h_0(0, b) for every b
+    content = {}                                                    # (buffer, batch, slot, writer key) -> item written
+    writers = {}                                                    # buffer -> writer keys
+    for b in range(nb):
+        for a in acts:
+            if a.role == L.ACT_SAMPLE:
+                content[(buf_of(a.out.ptr), b, 0, ("smp", a.index))] = (0, 0)
+    pos = [0] * len(acts)
+
+    def ready(a, t, b):
+        for w in a.wait:
+            if w.flags and t - w.lag >= 0:
+                need = (t - w.lag) * nb + b + 1
+                if any(flag[w.flags + 4 * fs * j] < need for j in range(w.n)):
+                    return False
+        return True
+
+    def wkey(a):
+        return {L.ACT_EARLY: "e", L.ACT_LATE: "l", L.ACT_RES: "r", L.ACT_SKIP: "k", L.ACT_POST1: "p1", L.ACT_POST2: "p2",
+                L.ACT_SAMPLE: "smp"}[a.role], a.index
+
+    def wrote(a, sb, b, t, tag=0):
+        name = buf_of(sb.ptr)
+        key = wkey(a) if name != "skp" else ("k", a.index)         # the skip sum is rewritten in place, layer by layer
+        content[(name, b, t % sb.ring, key)] = (t, tag)
+        writers.setdefault(name, set()).add(key)
+
+    def expect(sb, b, t, keys=None, tag=0):
+        name = buf_of(sb.ptr)
+        for key in (keys if keys is not None else writers.get(name, ())):
+            got = content.get((name, b, t % sb.ring, key))
+            assert got == (t, tag), (name, b, t, key, got)
+
+    done, rounds, idle = 0, 0, False
+    while done < len(acts) and rounds < max_rounds:
+        rounds += 1
+        progressed = False
+        order = list(range(len(acts)))
+        rnd.shuffle(order)
+        # a random subset per round; after an idle round the next one sweeps everybody (an idle full sweep = deadlock)
+        for i in (order if idle else order[:max(1, len(order) // rnd.choice((1, 2, 7)))]):
+            a = acts[i]
+            if pos[i] >= T * nb:
+                continue
+            t, b = divmod(pos[i], nb)
+            if not ready(a, t, b):
+                continue
+            if a.role == L.ACT_EARLY:
+                if t >= a.dil:
+                    expect(a.in0, b, t - a.dil)
+                wrote(a, a.out, b, t)
+            elif a.role == L.ACT_LATE:
+                expect(a.in0, b, t)
+                expect(a.in1, b, t, keys=[("e", a.index)])
+                wrote(a, a.out, b, t)
+            elif a.role == L.ACT_RES:
+                expect(a.in0, b, t)
+                expect(a.in1, b, t)
+                wrote(a, a.out, b, t)
+            elif a.role == L.ACT_SKIP:
+                expect(a.in0, b, t)
+                if a.in1.ptr:
+                    expect(a.in1, b, t, keys=[("k", a.index)], tag=a.layer - 1)
+                wrote(a, a.out, b, t, tag=a.layer)
+            elif a.role == L.ACT_POST1:
+                expect(a.in0, b, t, tag=max(x.layer for x in acts if x.role == L.ACT_SKIP))
+                wrote(a, a.out, b, t)
+            elif a.role == L.ACT_POST2:
+                expect(a.in0, b, t)
+                wrote(a, a.out, b, t)
+            else:
+                expect(a.in0, b, t)
+                if t + 1 < T:
+                    wrote(a, a.out, b, t + 1)
+            flag[a.flag] = (t + 1) * nb + b + 1 if a.role == L.ACT_SAMPLE else t * nb + b + 1
+            pos[i] += 1
+            progressed = True
+            if pos[i] == T * nb:
+                done += 1
+        assert progressed or not idle, ("deadlock", [(acts[i].role, acts[i].layer, acts[i].index, divmod(pos[i], nb))
+                                                     for i in range(len(acts)) if pos[i] < T * nb][:6])
+        idle = not progressed
+    assert done == len(acts)
+
+
+@pytest.mark.parametrize("nb,seed", [(1, 0), (2, 1), (3, 2)])
+def test_actor_protocol_has_no_deadlock_and_no_stale_reads(nb, seed):
+    from ae_wavenet_amd.engine import ParamStore, decoder_param_specs
+    from ae_wavenet_amd.plan import Workspace
+    hps = config.make_hps("vqvae-ema", n_res=40, n_dil=16, n_skp=20, n_post=12, n_lc_out=8, n_global_embed=4,
+                          n_speakers=5, n_blocks=2, n_block_layers=3)
+    ws = Workspace("cpu")
+    ps = ParamStore(ws, decoder_param_specs(hps, hps.bn_n_out, "decoder."))
+    smp = S.Sampler(hps, ps, "decoder.", "cpu")
+    n, T = 16 * nb, 40                                              # rf = 14: rings of 2..5 rows wrap many times
+    cond = torch.zeros(n, T, 32, dtype=torch.bfloat16)
+    bias = torch.zeros(n, smp.g.NL, smp.g.n_pairs * 32)
+    forced = torch.zeros(n, T, dtype=torch.int32)
+    desc = smp.generate(cond, bias, forced, dry_run=True)
+    assert sum(1 for i in range(desc["n_slots"]) if desc["table"][i].role >= 0) == smp.g.n_actors()
+    _replay(desc, seed)
