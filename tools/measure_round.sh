@@ -1,6 +1,7 @@
 #!/bin/bash
 # Full measurement pass for profiles/: bench line (+per-op), rocprofv3 kernel stats (serial plan order,
 # --lanes 0, so that per-kernel durations are not inflated by side-lane overlap), PMC HBM traffic.
+# Then the per-op roofline table and the sampler bench.
 # usage (on the GPU box): tools/measure_round.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-rXX}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
@@ -49,3 +50,8 @@ with open(O + "/pmc_mfma_util.csv", "w", newline="") as fh:
         cw.writerow([k, n, f"{mf:.0f}", f"{ga:.0f}", f"{mf / (1024.0 * ga):.4f}" if ga > 0 else "", f"{lc:.4f}"])
 print(open(O + "/bench.json").read()[:600])
 PY
+# per-op MFMA / HBM view of the step and the sampler's throughput table
+cd $R
+python tools/op_roofline.py $O/per_op_ms.txt > $O/op_roofline.txt 2>&1
+python tools/bench_sampler.py --steps 3000 --batches 1,4,16,32 > $O/sampler.txt 2>&1
+tail -5 $O/sampler.txt
