@@ -25,8 +25,10 @@ class AutoEncoder(HipModelBase):
             import mfcc as _mfcc                # noqa: F401  (librosa-based, CPU; mfcc.py:39-76)
             self.mfcc = _mfcc.ProcessWav(sample_rate=hps.sample_rate, win_sz=hps.mfcc_win_sz,
                                          hop_sz=hps.mfcc_hop_sz, n_mels=hps.n_mels, n_mfcc=hps.n_mfcc)
-        except Exception:
-            self.mfcc = None
+        except Exception:                       # librosa absent: the same callable on the device (AEW_OP_MFCC)
+            from .mfcc import ProcessWav
+            self.mfcc = ProcessWav(sample_rate=hps.sample_rate, win_sz=hps.mfcc_win_sz, hop_sz=hps.mfcc_hop_sz,
+                                   n_mels=hps.n_mels, n_mfcc=hps.n_mfcc)
 
     @property
     def decoder(self):                          # model.decoder.set_n_replicas(n) / .n_quant (wavenet.py:296)

@@ -117,3 +117,22 @@ class DeviceMfcc:
         buf[:B * n].view(B, n).copy_(wav)
         p.run(torch.cuda.current_stream(self.dev).cuda_stream)
         return out[:B * self.n_out * Ft].view(B, self.n_out, Ft).clone()
+
+
+class ProcessWav:
+    """Drop-in for the reference's `mfcc.ProcessWav` (mfcc.py:27-76): same constructor arguments and attributes, same
+    call - a 1-D numpy window in, a (3 * n_mfcc, frames) numpy array out - computed by AEW_OP_MFCC instead of librosa.
+    It is what `model.mfcc` is when the reference's librosa front-end cannot be imported, so `DataProcessor(hps, dat,
+    model.mfcc, ...)` (checkpoint.py:42) keeps working in the main process (n_loader_workers = 0); with worker
+    processes use `DevicePrefetcher(..., mfcc=DeviceMfcc(...))`, which computes whole batches on the copy stream."""
+
+    def __init__(self, sample_rate=16000, win_sz=400, hop_sz=160, n_mels=80, n_mfcc=13, name=None, device="cuda:0"):
+        self.sample_rate, self.window_sz, self.hop_sz, self.n_mels, self.n_mfcc = sample_rate, win_sz, hop_sz, n_mels, n_mfcc
+        self.n_out = n_mfcc * 3
+        self.name, self._device, self._dm = name, device, None
+
+    def __call__(self, wav):
+        if self._dm is None:
+            self._dm = DeviceMfcc(self._device, self.sample_rate, self.window_sz, self.hop_sz, self.n_mels, self.n_mfcc)
+        x = torch.as_tensor(np.ascontiguousarray(wav), dtype=torch.float32).reshape(1, -1).to(self._dm.dev)
+        return self._dm(x)[0].cpu().numpy()

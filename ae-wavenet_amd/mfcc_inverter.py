@@ -12,8 +12,10 @@ class MfccInverter(HipModelBase):
             import mfcc as _mfcc                # the reference's librosa front-end (mfcc.py:39-76)
             self.mfcc = _mfcc.ProcessWav(sample_rate=hps.sample_rate, win_sz=hps.mfcc_win_sz,
                                          hop_sz=hps.mfcc_hop_sz, n_mels=hps.n_mels, n_mfcc=hps.n_mfcc)
-        except Exception:
-            self.mfcc = None
+        except Exception:                       # librosa absent: the same callable on the device (AEW_OP_MFCC)
+            from .mfcc import ProcessWav
+            self.mfcc = ProcessWav(sample_rate=hps.sample_rate, win_sz=hps.mfcc_win_sz, hop_sz=hps.mfcc_hop_sz,
+                                   n_mels=hps.n_mels, n_mfcc=hps.n_mfcc)
 
     @property
     def wavenet(self):

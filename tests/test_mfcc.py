@@ -82,3 +82,17 @@ def test_prefetcher_computes_mel_on_the_device():
         assert torch.equal(wav.cpu(), src[0]) and torch.equal(voice.cpu(), src[2])
         seen += 1
     assert seen == 3
+
+
+@pytest.mark.gpu
+def test_model_mfcc_is_the_reference_callable():
+    """model.mfcc(window) -> (39, F) numpy, the call data.Collate makes (data.py:230); librosa is not importable here,
+    so the models carry the device front-end behind the reference's ProcessWav surface."""
+    from ae_wavenet_amd import config, mfcc_inverter as mi
+    m = mi.MfccInverter(config.make_hps("mi"))
+    assert m.mfcc.n_out == 39 and m.mfcc.window_sz == 400 and m.mfcc.hop_sz == 160
+    wav = np.random.RandomState(4).randint(0, 256, 6960).astype(np.float32)
+    got = m.mfcc(wav)
+    ref = R.mfcc_and_deltas(wav)
+    assert got.shape == ref.shape == (39, 42)
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref[:13]).max()
