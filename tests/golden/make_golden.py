@@ -279,7 +279,20 @@ def gen_geometry():
 # ------------------------------------------------------------------------------------
 # B. MfccInverter end-to-end (the model that runs unmodified at HEAD)
 # ------------------------------------------------------------------------------------
-def run_mi(hps, seed, B, jitter_kind):
+def real_windows(B, n, seed):
+    """B windows of n mu-law samples cut from the reference's own data file (dat/librispeech.some.dat, the file
+    BASELINE configs[0] names; data.py:119-126 format), one per utterance."""
+    import data as ref_data
+    d = ref_data.load_data(os.path.join(REF, "dat", "librispeech.some.dat"))
+    rs = np.random.RandomState(seed)
+    rows = []
+    for s in [d["samples"][i] for i in rs.choice(len(d["samples"]), B, replace=False)]:
+        b0 = rs.randint(s.wav_b, s.wav_e - n)
+        rows.append(np.asarray(d["snd_data"][b0:b0 + n]).astype(np.float32))
+    return torch.from_numpy(np.stack(rows))
+
+
+def run_mi(hps, seed, B, jitter_kind, real_audio=False):
     torch.manual_seed(0)
     m = mfcc_inverter.MfccInverter(hps)
     m.train()
@@ -287,6 +300,8 @@ def run_mi(hps, seed, B, jitter_kind):
     g = torch.Generator().manual_seed(seed)
     n_mel = m.embed_len
     wav = torch.randint(0, hps.n_quant, (B, m.enc_in_len), generator=g).float()
+    if real_audio:
+        wav = real_windows(B, m.enc_in_len, seed)
     mel = torch.randn(B, hps.n_lc_in, n_mel, generator=g)
     voice = torch.randint(0, hps.n_speakers, (B,), generator=g)
     if jitter_kind == "identity":
@@ -334,6 +349,17 @@ def gen_mi():
     keep["param_names"] = np.array(json.dumps(
         {k: list(v.shape) for k, v in m.named_parameters()}))
     save("mi_full.npz", **keep)
+    # BASELINE configs[0] as named: windows of real mu-law audio from dat/librispeech.some.dat (mel stays synthetic:
+    # the MFCC needs librosa)
+    res, m = run_mi(hps, 5, 2, "identity", real_audio=True)
+    real = dict(wav=res["wav"].astype(np.uint8), mel=res["mel"], voice=res["voice"], jitter=res["jitter"],
+                loss=res["loss"], target=res["target"], pred_sub=res["pred"][:, :, ::9], mel_grad=res["mel_grad"],
+                seed=np.array(5), param_names=keep["param_names"])
+    for k in keep:
+        if k.startswith("grad.") or k.startswith("gradslice."):
+            full = res["grad." + k.split(".", 1)[1]]
+            real[k] = full if k.startswith("grad.") else full[:8, :8]
+    save("mi_full_real.npz", **real)
 
 
 # ------------------------------------------------------------------------------------

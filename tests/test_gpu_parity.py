@@ -453,11 +453,14 @@ def test_full_window_forward_vs_oracle():
     assert abs(loss / float(out["loss"]) - 1) < 1e-2
 
 
-def test_mfcc_inverter_full_width_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("fixture", ["mi_full.npz", "mi_full_real.npz"])
+def test_mfcc_inverter_full_width_vs_reference_golden(golden_dir, fixture):
     """BASELINE configs[0] shape (mfcc-inverter, B=2, w=100, full width, 13.5 M parameters):
     the GPU path against tensors captured from the UNMODIFIED reference MfccInverter.run
-    (tests/golden/mi_full.npz; weights regenerated from the recorded seed)."""
-    z = load(golden_dir, "mi_full.npz")
+    (tests/golden/mi_full.npz; weights regenerated from the recorded seed).  mi_full_real.npz: the same with
+    windows of real mu-law audio cut from the reference's dat/librispeech.some.dat, the file configs[0] names."""
+    z = load(golden_dir, fixture)
+    z["wav"] = z["wav"].astype(np.float32)
     hps = config.make_hps("mi", n_win_batch=100)
     eng = M.TrainEngine(hps, B=2, device=DEV, n_mel=39, take_compat=True)
     shapes = json.loads(str(z["param_names"]))

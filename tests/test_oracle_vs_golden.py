@@ -291,9 +291,12 @@ def wavenet_param_shapes(hps, n_lc_in, prefix=""):
     return {prefix + k: v for k, v in s.items()}
 
 
-def test_mfcc_inverter_full_width(golden_dir):
-    """Full-width (13.5 M parameter) MfccInverter, B=2, w=100: loss, logits, gradients."""
-    z = load(golden_dir, "mi_full.npz")
+@pytest.mark.parametrize("fixture", ["mi_full.npz", "mi_full_real.npz"])
+def test_mfcc_inverter_full_width(golden_dir, fixture):
+    """Full-width (13.5 M parameter) MfccInverter, B=2, w=100: loss, logits, gradients.  mi_full_real.npz: windows of
+    real mu-law audio from the reference's dat/librispeech.some.dat (BASELINE configs[0])."""
+    z = load(golden_dir, fixture)
+    z["wav"] = z["wav"].astype(np.float32)
     hps = config.make_hps("mi", n_win_batch=100)
     shapes = json.loads(str(z["param_names"]))
     assert shapes == {k: list(v) for k, v in wavenet_param_shapes(hps, 39, "wavenet.").items()}
