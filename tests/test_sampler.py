@@ -213,6 +213,33 @@ def test_module_surface_eval_forward_samples(golden_dir):
     assert m(*args).shape == (1, 256, geom.n_win)                   # train(): teacher-forced logits as before
 
 
+@pytest.mark.gpu
+def test_autoencoder_eval_forward_samples_without_touching_the_codebook():
+    """The autoencoder's inference call: conditioning from encoder -> VQ -> upsampler (TrainEngine.conditioning: no EMA
+    accumulation, no codebook refresh, no loss), then the sampler; training continues afterwards."""
+    from ae_wavenet_amd import autoencoder_model as ae
+    hps = config.make_hps("vqvae-ema", n_res=64, n_dil=64, n_skp=64, n_post=64, n_lc_out=32, enc_n_out=64,
+                          bn_n_out=16, bn_vq_n_embed=128, n_win_batch=96, n_blocks=2, n_block_layers=4)
+    torch.manual_seed(0)
+    m = ae.AutoEncoder(hps, n_mel=39).to(DEV)
+    g = m.geom
+    gen = torch.Generator().manual_seed(1)
+    args = (torch.randint(0, 256, (1, g.enc_in_len), generator=gen).float().to(DEV),
+            torch.randn(1, 39, g.mel_len, generator=gen).to(DEV), torch.randint(0, 40, (1,), generator=gen).to(DEV),
+            torch.arange(g.embed_len).repeat(1, 1).to(DEV))
+    m.eval()
+    m.decoder.set_n_replicas(3)
+    eng = m._ensure_engine(1)
+    emb0, numer0 = eng.emb.clone(), eng.ema_numer.clone()
+    out = m(*args)
+    rf = 2 * 15
+    assert out.shape == (4, g.dec_in_len) and torch.equal(out[1:, :rf + 1], out[:1, :rf + 1].expand(3, -1))
+    assert torch.equal(eng.emb, emb0) and torch.equal(eng.ema_numer, numer0)
+    m.train()
+    pred, target, loss = m.run(*args)
+    assert torch.isfinite(loss) and pred.shape == (1, 256, 95)
+
+
 # ---- the actor protocol, replayed on the CPU -------------------------------------------------------------------------
 def _replay(desc, seed, max_rounds=400000):
     """Executes the actor table as a set of state machines under a RANDOM schedule: an actor may run its next item
