@@ -1082,7 +1082,10 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
 #define NF_BM 16
 #define NF_BN 64
 #define NF_BK 32
-#define NF_STAGES 3
+// 5 stages and TWO K tiles per barrier: the step is bound by its own chain (16 ds_read_b32 -> wait -> 8 dependent
+// v_mfma_f32_16x16x4 -> barrier), not by the LDS-DMA; with two tiles per iteration the 32 fragment reads go out
+// together and there is one barrier / one vmcnt wait per 64 channels of K.  The order of the chain is unchanged.
+#define NF_STAGES 5
 #define NF_STAGE_BYTES ((NF_BM + NF_BN) * 128)      // 10 KiB
 
 struct NfPtrs {
@@ -1143,14 +1146,27 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
         slot = (slot + 1 == NF_STAGES) ? 0 : slot + 1;
         --left;
     };
-    issue_next();
-    if (nkt > 1) issue_next();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < nkt) issue_next();                               // tiles 0, 1, 2
     const int fi = lane & 15, kq = lane >> 4;
     const int rw = wave * 16 + fi;
     int stage = 0;
-    for (int t = 0; t < nkt; ++t) {
-        // waves 0,1 have 3 loads per tile in flight, waves 2,3 have 2
-        if (t + 1 < nkt) {
+    auto tile = [&](const char* xs) {                            // one K tile: 8 MFMA steps of the chain, k ascending
+        const char* ws = xs + NF_BM * 128;
+        float wv[8], xv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            wv[ks] = *reinterpret_cast<const float*>(ws + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
+            xv[ks] = *reinterpret_cast<const float*>(xs + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], xv[ks], acc, 0, 0, 0);
+    };
+    for (int t = 0; t < nkt; t += 2) {
+        // tiles t and t+1 have landed once only tile t+2 (issued last) may be outstanding: 3 loads on waves 0,1
+        // (X piece + two W pieces), 2 on waves 2,3
+        if (t + 2 < nkt) {
             if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
@@ -1158,15 +1174,30 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < nkt) issue_next();
-        const char* xs = smem + stage * NF_STAGE_BYTES;
-        const char* ws = xs + NF_BM * 128;
+        if (t + 3 < nkt) issue_next();                           // into the stages of tiles t-2, t-1: every wave is past them
+        if (t + 4 < nkt) issue_next();
+        const char* x0 = smem + stage * NF_STAGE_BYTES;
         stage = (stage + 1 == NF_STAGES) ? 0 : stage + 1;
+        const char* x1 = smem + stage * NF_STAGE_BYTES;
+        stage = (stage + 1 == NF_STAGES) ? 0 : stage + 1;
+        if (t + 1 < nkt) {
+            const char* w0 = x0 + NF_BM * 128;
+            const char* w1 = x1 + NF_BM * 128;
+            float wv[16], xv[16];                                // both tiles' fragments in flight at once
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const float wv = *reinterpret_cast<const float*>(ws + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
-            const float xv = *reinterpret_cast<const float*>(xs + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                wv[ks] = *reinterpret_cast<const float*>(w0 + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
+                xv[ks] = *reinterpret_cast<const float*>(x0 + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                wv[8 + ks] = *reinterpret_cast<const float*>(w1 + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
+                xv[8 + ks] = *reinterpret_cast<const float*>(x1 + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], xv[ks], acc, 0, 0, 0);
+        } else {
+            tile(x0);                                            // odd tile count: the last one alone
         }
     }
     unsigned zc = 0;
@@ -1606,6 +1637,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8, 2>), (NtCfg<8, 2>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
 #undef AEW_SET_NT
+    AEW_SET_LDS(k_gemm_nt_f32, NF_STAGES * NF_STAGE_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
 #undef AEW_SET_LDS
@@ -1703,6 +1735,8 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         }
 #undef AEW_NT_GO
     } else {
+        const int rc = ensure_big_lds();
+        if (rc) return rc;
         dim3 grid((g.M + NF_BM - 1) / NF_BM, g.N_pad / NF_BN, g.batch);
         hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), NF_STAGES * NF_STAGE_BYTES, st, g);
     }
