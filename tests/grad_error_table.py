@@ -1,6 +1,7 @@
 """Per-tensor gradient error of the full-width step against the fp32 oracle (same setup as
 tests/test_gpu_parity.py::test_full_width_step_vs_oracle): max-normalised error, cosine, and where the worst
-element sits."""
+element sits.  A diagnostic script (python tests/grad_error_table.py on the GPU box), kept under tests/ because it
+uses the oracle."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
