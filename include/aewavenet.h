@@ -422,15 +422,18 @@ int aew_graph_destroy(void* exec);
 int aew_timing_enable(int on);
 int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
 
-/* Wave shape of the bf16 NT kernel: 128 (default; 4 waves of 128x64 per 256x128 tile) or 64
- * (8 waves of 64x64).  Same results bit for bit; tuning / A-B aid. */
+/* Tile / wave shape of the bf16 NT kernel.  Same results bit for bit; tuning / A-B aid (profiles/r01_notes.md).
+ *   64  (default) 256x128 tiles, 8 waves of 64x64, K tiles of 32; per launch the 192x128 or 64x128 shapes where
+ *       the cost model prefers them (aew_set_nt_rows192, aew_set_nt_small_tiles)
+ *   128 256x128 tiles, 4 waves of 128x64          256 256x256 tiles, 8 waves of 128x64 (N_pad % 256 == 0)
+ *   0   128x128 tiles with K tiles of 64          1   256x128 tiles with K tiles of 64 */
 int aew_set_nt_wave_rows(int rows);
-/* 1 (default): shapes 128 / 256 run the software-pipelined kernel; 0: the plain loop. */
+/* Shapes 128 / 256 only: 1 (default) the register-double-buffered loop, 2 K tiles of 64, 0 the plain loop. */
 int aew_set_nt_pipe(int on);
 /* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
 int aew_set_nt_small_tiles(int n);
-/* default NT shape only: 192 x 128 tiles (6 waves) instead of 256 x 128 — 0 never, 1 (default) where the
- * tile-wave cost model prefers them, 2 always.  Results are bit-identical either way. */
+/* default NT shape only: 192 x 128 tiles (8 waves of 48x64) instead of 256 x 128 — 0 never, 1 (default) where the
+ * per-CU cost model prefers them, 2 always.  Results are bit-identical either way. */
 int aew_set_nt_rows192(int mode);
 /* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
 int aew_set_lanes(int on);
