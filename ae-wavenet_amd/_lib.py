@@ -240,6 +240,10 @@ def load():
         raise AewError(f"HIP extension not built: {LIB_PATH} is missing "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
                        "There is no CPU fallback for the product path.")
+    if torch.cuda.is_available():
+        arch = getattr(torch.cuda.get_device_properties(0), "gcnArchName", "")
+        if arch and not arch.startswith("gfx950"):
+            raise AewError(f"libaewavenet_hip.so is built for gfx950 (MI355X) only; device 0 is {arch}")
     lib = C.CDLL(LIB_PATH)
     lib.aew_strerror.restype = C.c_char_p
     lib.aew_run_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
