@@ -72,7 +72,7 @@ class Sampler:
 
     ps: ParamStore (fp32 parameters by reference name), pre: 'decoder.' / 'wavenet.' prefix."""
 
-    def __init__(self, hps, ps, pre: str, device, flag_stride: int = 16):
+    def __init__(self, hps, ps, pre: str, device, flag_stride: int = 64):
         self.g = g = SamplerGeometry(hps)
         self.hps, self.pre, self.dev = hps, pre, torch.device(device)
         self.flag_stride = flag_stride
@@ -359,7 +359,7 @@ class Sampler:
         return wav_out, logits_out
 
 
-def from_engine(eng, flag_stride: int = 16) -> Sampler:
+def from_engine(eng, flag_stride: int = 64) -> Sampler:
     """Sampler over the decoder of a TrainEngine (same parameters, same prefix)."""
     return Sampler(eng.hps, eng.ps, eng.dec.pre, eng.device, flag_stride)
 

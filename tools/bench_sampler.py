@@ -1,6 +1,6 @@
 """Throughput / latency of the autoregressive sampler at arch.vqvae-ema width (synthetic weights and conditioning).
 
-  python tools/bench_sampler.py [--steps 4000] [--batches 1,2,4,8,16] [--flag-stride 16]
+  python tools/bench_sampler.py [--steps 4000] [--batches 1,2,4,8,16] [--flag-stride 64]
 
 Prints, per number of 16-stream batches in flight: us per time step (all batches), samples/s per stream and in total,
 and the implied hand-off time (step time / 44 hand-offs on the critical path with one batch).  Free-running
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--batches", default="1,2,4,8,16,32")
-    ap.add_argument("--flag-stride", type=int, default=16)
+    ap.add_argument("--flag-stride", type=int, default=64)
     ap.add_argument("--nap", type=int, default=-1, help="nap_eighths override (0..7)")
     ap.add_argument("--profile", action="store_true", help="per-role phase clock for the 1-batch run")
     ap.add_argument("--deep", action="store_true", help="30 layers x 512 residual channels")
