@@ -198,7 +198,7 @@ ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMP
 
 
 class Sbuf(C.Structure):
-    _fields_ = [("ptr", vp), ("bstride", i64), ("entry", i64), ("pitch", i64), ("ring", i32), ("pad", i32)]
+    _fields_ = [("ptr", vp), ("bstride", i64), ("entry", i64), ("pitch", i64), ("ring", i32), ("layout", i32)]
 
 
 class Wait(C.Structure):
@@ -260,7 +260,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 10:
+    if lib.aew_abi_version() != 11:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

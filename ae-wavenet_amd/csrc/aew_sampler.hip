@@ -142,16 +142,23 @@ struct SmpW {                                          // register-resident weig
     }
 };
 
-// acc[n] += W[.. n ..] * row, row = one stream's bf16 activation row (lane reads 16 B per K tile)
+// acc[n] += W[.. n ..] * x, x = the 16-stream bf16 activations of one entry (`base`) in the buffer's layout: per K tile
+// (32 channels) the lane reads the 16 bytes of stream i, channel chunk g (see aew_sbuf_t)
 template <int KMAX>
-__device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, const char* row, int nk, int g) {
+__device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, const char* base, const aew_sbuf_t& sb,
+                                       int nk, const SmpEnv& e) {
+    const char* lp;
+    int ks;
+    if (sb.layout == 1) { lp = base + e.i * 64 + e.g * 16; ks = 1024; }
+    else if (sb.layout == 2) { lp = base + (e.g >> 1) * 512 + e.i * 32 + (e.g & 1) * 16; ks = 1024; }
+    else { lp = base + e.i * sb.pitch + e.g * 16; ks = 64; }
     bf16x8_t x[KMAX];
     if (nk == KMAX) {
         // the usual case (full-width decoder), written without the per-tile `k < nk` tests: with them every K tile is
         // its own basic block and the compiler waits for each block's loads before issuing the next block's
         // (8 trips to memory for a POST1 row, 2 for a RES row; measured in the ISA), instead of one
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) x[k] = smp_ld_x(row + k * 64 + g * 16);
+        for (int k = 0; k < KMAX; ++k) x[k] = smp_ld_x(lp + k * ks);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][0], x[k], acc[0], 0, 0, 0);
@@ -161,7 +168,7 @@ __device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, c
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < nk) x[k] = smp_ld_x(row + k * 64 + g * 16);
+        if (k < nk) x[k] = smp_ld_x(lp + k * ks);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < nk) {
@@ -189,7 +196,7 @@ __device__ void smp_early(const aew_actor_t& a, const SmpEnv& e, int T) {
         for (int b = 0; b < e.nb; ++b) {
             if (!smp_wait(a, e, t, b)) return;
             f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (t >= a.dil) smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t - a.dil) + e.i * a.in0.pitch, a.nk, e.g);
+            if (t >= a.dil) smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t - a.dil), a.in0, a.nk, e);
             const char* crow = sbuf_at(a.in1, b, t) + e.i * a.in1.pitch;
 #pragma unroll
             for (int k = 0; k < SMP_KC_MAX; ++k)
@@ -216,7 +223,7 @@ __device__ void smp_late(const aew_actor_t& a, const SmpEnv& e, int T) {
             if (!smp_wait(a, e, t, b)) return;
             const char* pp = sbuf_at(a.in1, b, t) + e.lane * 32;
             f32x4_t acc[2] = {smp_ld_f4(pp), smp_ld_f4(pp + 16)};
-            smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t) + e.i * a.in0.pitch, a.nk, e.g);
+            smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);
             f32x4_t z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = tanh_f(acc[0][r]) * sigmoid_f(acc[1][r]);
@@ -276,7 +283,7 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
                         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][1], x[k], acc[1], 0, 0, 0);
                     }
             } else {
-                smp_mm<SMP_KD_MAX>(acc, W, row, a.nk, e.g);
+                smp_mm<SMP_KD_MAX>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);
             }
             char* orow = sbuf_at(a.out, b, t) + e.i * a.out.pitch;
 #pragma unroll
@@ -315,8 +322,9 @@ __device__ void smp_sample(const aew_actor_t& a, const SmpEnv& e, const aew_samp
         const int stream = b * 16 + a.index * 4 + sub;
         if (l16 == 0) s.wav_out[(int64_t)stream * T + t] = value;
         const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (int64_t)value * a.row_bytes);
-        uint4* dst = reinterpret_cast<uint4*>(sbuf_at(a.out, b, t) + (a.index * 4 + sub) * a.out.pitch);
-        for (int c = l16; c < chunks; c += 16) smp_st16(dst + c, __builtin_bit_cast(SmpU16, src[c]));
+        char* dst = sbuf_at(a.out, b, t) + (a.index * 4 + sub) * 64;           // layout 1: [group][stream][32 ch]
+        for (int c = l16; c < chunks; c += 16)
+            smp_st16(dst + (c >> 2) * 1024 + (c & 3) * 16, __builtin_bit_cast(SmpU16, src[c]));
     };
     for (int b = 0; b < e.nb; ++b) {                                 // position 0 is given
         const int stream = b * 16 + a.index * 4 + sub;

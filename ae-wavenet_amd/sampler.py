@@ -175,18 +175,20 @@ class Sampler:
         logits_out = z(n_streams, T, g.Q, dt=torch.float32) if want_logits else None
         forced = forced.to(dev).contiguous()
 
-        def sbuf(t: Optional[torch.Tensor], byte_off=0, *, bstride=0, entry=0, pitch=0, ring=1) -> L.Sbuf:
+        def sbuf(t: Optional[torch.Tensor], byte_off=0, *, bstride=0, entry=0, pitch=0, ring=1, layout=0) -> L.Sbuf:
             s = L.Sbuf()
             s.ptr = (t.data_ptr() + byte_off) if t is not None else None
-            s.bstride, s.entry, s.pitch, s.ring = bstride, entry, pitch, ring
+            s.bstride, s.entry, s.pitch, s.ring, s.layout = bstride, entry, pitch, ring, layout
             return s
 
-        def h_at(l, ch=0):                                           # h_l rows, optionally at a channel offset
-            return sbuf(hbuf[l], 2 * ch, bstride=rings[l] * 16 * g.Rk * 2, entry=16 * g.Rk * 2, pitch=g.Rk * 2,
-                        ring=rings[l])
+        # rows written by several actors are producer-contiguous (aew_sbuf_t layouts 1 / 2): h_l and relu(post1) as
+        # [32-channel group][stream][32 ch], z_l as [16-channel pair][stream][16 ch]
+        def h_at(l, group=0):                                        # h_l entry, or the block of one 32-channel group
+            return sbuf(hbuf[l], 1024 * group, bstride=rings[l] * 16 * g.Rk * 2, entry=16 * g.Rk * 2, pitch=64,
+                        ring=rings[l], layout=1)
 
-        def z_at(l, ch=0):
-            return sbuf(zbuf[l], 2 * ch, bstride=16 * g.Dk * 2, pitch=g.Dk * 2)
+        def z_at(l, pair=0):
+            return sbuf(zbuf[l], 512 * pair, bstride=16 * g.Dk * 2, pitch=32, layout=2)
 
         # ---- actors, grouped so that each producer group owns consecutive flags --------------------------------
         acts: List[L.Actor] = []
@@ -230,14 +232,14 @@ class Sampler:
                 a.w = wptr(("late", l, pi))
                 a.in0 = h_at(l)
                 a.in1 = sbuf(epart[l], pi * 2048, bstride=2 * g.n_pairs * 2048, entry=g.n_pairs * 2048, ring=2)
-                a.out = z_at(l, 16 * pi)
+                a.out = z_at(l, pi)
             if l < g.NL - 1:
                 group("res", l, g.n_res)
                 for qi in range(g.n_res):
                     a = new(L.ACT_RES, l, qi, x)
                     a.nk, a.nt = kd, min(2, _ru(g.R, 16) // 16 - 2 * qi)
                     a.w = wptr(("res", l, qi))
-                    a.in0, a.in1, a.out = z_at(l), h_at(l, 32 * qi), h_at(l + 1, 32 * qi)
+                    a.in0, a.in1, a.out = z_at(l), h_at(l, qi), h_at(l + 1, qi)
             group("skip", l, g.n_skp)
             for qi in range(g.n_skp):
                 a = new(L.ACT_SKIP, l, qi, x)
@@ -253,13 +255,13 @@ class Sampler:
             a.nk, a.nt = g.Sk // 32, min(2, _ru(g.P, 16) // 16 - 2 * qi)
             a.w, a.bias = wptr(("post1", 0, qi)), self.b1.data_ptr() + 4 * 32 * qi
             a.in0 = sbuf(skp, bstride=16 * g.Sk * 4, pitch=g.Sk * 4)
-            a.out = sbuf(p1, 2 * 32 * qi, bstride=16 * g.Pk * 2, pitch=g.Pk * 2)
+            a.out = sbuf(p1, 1024 * qi, bstride=16 * g.Pk * 2, pitch=64, layout=1)
         group("post2", 0, g.n_p2)
         for qi in range(g.n_p2):
             a = new(L.ACT_POST2, g.NL, qi, post_xcd)
             a.nk, a.nt = g.Pk // 32, min(2, g.Q // 16 - 2 * qi)
             a.w, a.bias = wptr(("post2", 0, qi)), self.b2.data_ptr() + 4 * 32 * qi
-            a.in0 = sbuf(p1, bstride=16 * g.Pk * 2, pitch=g.Pk * 2)
+            a.in0 = sbuf(p1, bstride=16 * g.Pk * 2, pitch=64, layout=1)
             a.out = sbuf(logits, 4 * 32 * qi, bstride=16 * g.Q * 4, pitch=g.Q * 4)
             if logits_out is not None:
                 a.out2 = sbuf(logits_out, 4 * 32 * qi, bstride=16 * T * g.Q * 4, entry=g.Q * 4, pitch=T * g.Q * 4, ring=T)

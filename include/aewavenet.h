@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 10
+#define AEW_ABI_VERSION 11
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -482,15 +482,19 @@ int aew_set_tn_safe(int on);
 #define AEW_ACT_POST2  5
 #define AEW_ACT_SAMPLE 6
 
-/* 16-stream activation buffer.  Row of stream i of stream-batch b at time t (BYTES):
- *     ptr + b*bstride + (t % ring)*entry + i*pitch */
+/* 16-stream activation buffer.  Entry of stream-batch b at time t (BYTES): ptr + b*bstride + (t % ring)*entry.
+ * layout 0 (rows): stream i's channels are contiguous, row at + i*pitch.
+ * Rows that several actors write are stored PRODUCER-CONTIGUOUS instead, so that every actor writes whole cache
+ * lines of its own and a consumer's K tile (32 channels x 16 streams) is one 1 KiB block:
+ * layout 1 (h_l, relu(post1)): [32-channel group][stream][32 ch]  -> channel c of stream i at (c/32)*1024 + i*64 + (c%32)*2
+ * layout 2 (z_l):              [16-channel pair ][stream][16 ch]  -> (c/16)*512 + i*32 + (c%16)*2 */
 typedef struct {
     void*   ptr;
     int64_t bstride;
     int64_t entry;
     int64_t pitch;
     int32_t ring;                /* >= 1 */
-    int32_t pad;
+    int32_t layout;
 } aew_sbuf_t;
 
 /* wait until flags[j*flag_stride] >= seq(t - lag, b) for j < n (skipped while t < lag) */
