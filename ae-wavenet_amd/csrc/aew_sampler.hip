@@ -64,9 +64,11 @@ __device__ __forceinline__ SmpU16 smp_ld16(const void* p) {
     r.hi = smp_ld8(reinterpret_cast<const char*>(p) + 8);
     return r;
 }
-__device__ __forceinline__ void smp_st16(void* p, const SmpU16& v) {
-    smp_st8(p, v.lo);
-    smp_st8(reinterpret_cast<char*>(p) + 8, v.hi);
+__device__ __forceinline__ void smp_st16(void* p, const SmpU16& v) {     // one write-through 16-byte store
+    // (the s_nop covers the "VALU write of the data registers right after a >8-byte VMEM store" hazard, which the
+    // compiler pads for its own stores but cannot see inside inline asm - without it the rows were corrupted)
+    const f32x4_t d = __builtin_bit_cast(f32x4_t, v);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
 __device__ __forceinline__ f32x4_t smp_ld_f4(const void* p) { return __builtin_bit_cast(f32x4_t, smp_ld16(p)); }
 __device__ __forceinline__ void smp_st_f4(void* p, const f32x4_t& v) { smp_st16(p, __builtin_bit_cast(SmpU16, v)); }
@@ -142,6 +144,28 @@ struct SmpW {                                          // register-resident weig
     }
 };
 
+// Full-width rows: one coherent 16-byte load per K tile (global_load_dwordx4 sc1; the 8-byte agent-scope atomics of
+// smp_ld8 need two), all in flight, then ONE wait that also ties the registers to the MFMAs behind it (the compiler
+// does not count loads issued from inline asm).  The data is complete before its flag, so no atomicity is needed here,
+// only coherence.
+__device__ __forceinline__ void smp_issue16(bf16x8_t& x, const char* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(x) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void smp_landed(bf16x8_t (&x)[4]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+}
+__device__ __forceinline__ void smp_landed(bf16x8_t (&x)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+__device__ __forceinline__ void smp_landed(bf16x8_t (&x)[12]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                 "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+}
+__device__ __forceinline__ void smp_landed(bf16x8_t (&x)[16]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                 "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+}
+
 // acc[n] += W[.. n ..] * x, x = the 16-stream bf16 activations of one entry (`base`) in the buffer's layout: per K tile
 // (32 channels) the lane reads the 16 bytes of stream i, channel chunk g (see aew_sbuf_t)
 template <int KMAX>
@@ -158,7 +182,8 @@ __device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, c
         // its own basic block and the compiler waits for each block's loads before issuing the next block's
         // (8 trips to memory for a POST1 row, 2 for a RES row; measured in the ISA), instead of one
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) x[k] = smp_ld_x(lp + k * ks);
+        for (int k = 0; k < KMAX; ++k) smp_issue16(x[k], lp + k * ks);
+        smp_landed(x);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][0], x[k], acc[0], 0, 0, 0);
@@ -222,8 +247,20 @@ __device__ void smp_late(const aew_actor_t& a, const SmpEnv& e, int T) {
         for (int b = 0; b < e.nb; ++b) {
             if (!smp_wait(a, e, t, b)) return;
             const char* pp = sbuf_at(a.in1, b, t) + e.lane * 32;
-            f32x4_t acc[2] = {smp_ld_f4(pp), smp_ld_f4(pp + 16)};
-            smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);
+            f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (a.nk == KR) {                                        // EARLY's partial sums ride along with the row loads
+                bf16x8_t p0, p1;
+                smp_issue16(p0, pp);
+                smp_issue16(p1, pp + 16);
+                smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);     // its wait covers every load in flight
+                asm volatile("" : "+v"(p0), "+v"(p1));               // (and nothing reads p0 / p1 before this point)
+                acc[0] += __builtin_bit_cast(f32x4_t, p0);
+                acc[1] += __builtin_bit_cast(f32x4_t, p1);
+            } else {
+                acc[0] = smp_ld_f4(pp);
+                acc[1] = smp_ld_f4(pp + 16);
+                smp_mm<KR>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);
+            }
             f32x4_t z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = tanh_f(acc[0][r]) * sigmoid_f(acc[1][r]);
@@ -251,10 +288,17 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
                 bf16x8_t x[SMP_KD_MAX];
                 f32x4_t raw[SMP_KD_MAX][2];
                 if (a.nk == SMP_KD_MAX) {                            // all 16 loads in flight (see smp_mm)
+                    bf16x8_t r16[16];
 #pragma unroll
                     for (int k = 0; k < SMP_KD_MAX; ++k) {
-                        raw[k][0] = smp_ld_f4(row + k * 128 + e.g * 32);
-                        raw[k][1] = smp_ld_f4(row + k * 128 + e.g * 32 + 16);
+                        smp_issue16(r16[2 * k], row + k * 128 + e.g * 32);
+                        smp_issue16(r16[2 * k + 1], row + k * 128 + e.g * 32 + 16);
+                    }
+                    smp_landed(r16);
+#pragma unroll
+                    for (int k = 0; k < SMP_KD_MAX; ++k) {
+                        raw[k][0] = __builtin_bit_cast(f32x4_t, r16[2 * k]);
+                        raw[k][1] = __builtin_bit_cast(f32x4_t, r16[2 * k + 1]);
                     }
                 } else {
 #pragma unroll
@@ -342,9 +386,21 @@ __device__ void smp_sample(const aew_actor_t& a, const SmpEnv& e, const aew_samp
                 const float* lp = reinterpret_cast<const float*>(sbuf_at(a.in0, b, t) + (a.index * 4 + sub) * a.in0.pitch) + l16 * per;
                 float v[16];
                 float mx = -3.0e38f;
+                if (per == 16) {                                     // Q = 256: four 16-byte loads per lane
+                    bf16x8_t r4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) smp_issue16(r4[q], reinterpret_cast<const char*>(lp) + q * 16);
+                    smp_landed(r4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t f = __builtin_bit_cast(f32x4_t, r4[q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[q * 4 + r] = f[r]; mx = fmaxf(mx, f[r]); }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    if (k < per) {
+                    if (per != 16 && k < per) {
                         if (!(k & 1)) {                              // coherent 8-byte loads (per is even: Q % 32 == 0) or
                             if (k + 1 < per) {                       // a single trailing word
                                 const unsigned long long w = smp_ld8(lp + k);
