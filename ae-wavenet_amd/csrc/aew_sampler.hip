@@ -283,6 +283,9 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
         for (int b = 0; b < e.nb; ++b) {
             if (!smp_wait(a, e, t, b)) return;
             f32x4_t acc[2] = {bias[0], bias[1]};
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            u32x2_t res[2] = {{0u, 0u}, {0u, 0u}};
+            bool res_ready = false;
             const char* row = sbuf_at(a.in0, b, t) + e.i * a.in0.pitch;
             if (MODE == AEW_ACT_POST1) {                             // fp32 skip sum -> relu -> bf16 fragments
                 bf16x8_t x[SMP_KD_MAX];
@@ -326,6 +329,15 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][0], x[k], acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][1], x[k], acc[1], 0, 0, 0);
                     }
+            } else if (MODE == AEW_ACT_RES && a.nk == SMP_KD_MAX) {
+                // the residual taps h_l(t) ride along with the z loads (issued first, tied after the row's wait) instead
+                // of costing a second trip to memory after the MFMAs
+                const char* rp = sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + e.g * 8;
+                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(res[0]) : "v"(rp) : "memory");
+                if (a.nt > 1) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(res[1]) : "v"(rp + 32) : "memory");
+                smp_mm<SMP_KD_MAX>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);
+                asm volatile("" : "+v"(res[0]), "+v"(res[1]));
+                res_ready = true;
             } else {
                 smp_mm<SMP_KD_MAX>(acc, W, sbuf_at(a.in0, b, t), a.in0, a.nk, e);
             }
@@ -334,7 +346,8 @@ __device__ void smp_dense(const aew_actor_t& a, const SmpEnv& e, int T) {
             for (int n = 0; n < 2; ++n) {
                 if (n >= a.nt) break;
                 if (MODE == AEW_ACT_RES) {                           // h_{l+1} = h_l + W z            (wavenet.py:108-110)
-                    const uint2 r = smp_ld_u2(sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + n * 32 + e.g * 8);
+                    const uint2 r = res_ready ? __builtin_bit_cast(uint2, res[n])
+                                              : smp_ld_u2(sbuf_at(a.in1, b, t) + e.i * a.in1.pitch + n * 32 + e.g * 8);
                     smp_st_u2(orow + n * 32 + e.g * 8, smp_pack4(acc[n] + smp_unpack4(r)));
                 } else if (MODE == AEW_ACT_SKIP) {                   // running skip sum, fp32       (wavenet.py:458)
                     f32x4_t prev = {0.f, 0.f, 0.f, 0.f};
