@@ -184,11 +184,18 @@ __device__ __forceinline__ void smp_mm(f32x4_t (&acc)[2], const SmpW<KMAX>& W, c
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) smp_issue16(x[k], lp + k * ks);
         smp_landed(x);
+        // even / odd K tiles into separate accumulators: four independent MFMA chains of KMAX / 2 instead of two of KMAX
+        // (a dependent v_mfma_f32_16x16x32_bf16 issues every ~38 clocks; this is on every hand-off's critical path)
+        f32x4_t odd[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KMAX; k += 2) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][0], x[k], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k][1], x[k], acc[1], 0, 0, 0);
+            odd[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k + 1][0], x[k + 1], odd[0], 0, 0, 0);
+            odd[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.w[k + 1][1], x[k + 1], odd[1], 0, 0, 0);
         }
+        acc[0] += odd[0];
+        acc[1] += odd[1];
         return;
     }
 #pragma unroll
