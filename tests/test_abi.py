@@ -1,0 +1,52 @@
+"""The C ABI (include/aewavenet.h -> ae_wavenet_amd/lib/libaewavenet_hip.so) without a GPU: the library loads, exports
+every function the header declares, reports the header's ABI version, and its struct sizes agree with the ctypes
+mirrors of ae_wavenet_amd/_lib.py.  No compute entry point is called."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ae_wavenet_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "aewavenet.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)                 # comments out
+    body = src[src.index('extern "C"'):]
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(aew_[a-z0-9_]+)\s*\(", body, flags=re.M)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_function():
+    if not os.path.exists(L.LIB_PATH):
+        pytest.fail(f"{L.LIB_PATH} missing: run __graft_entry__.build() first")
+    lib = C.CDLL(L.LIB_PATH)                                         # plain dlopen: no device needed
+    names = declared_functions()
+    assert len(names) >= 20 and "aew_run_plan" in names and "aew_sampler_run" in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # the binding's own list is the header's list
+    assert sorted(L.EXPORTS) == names, sorted(set(names) ^ set(L.EXPORTS))
+
+
+def test_abi_version_and_struct_sizes():
+    lib = L.load()                                                   # raises on version / size drift
+    version = int(re.search(r"#define\s+AEW_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.aew_abi_version() == version
+    for which, cls in ((0, L.Op), (1, L.GemmNT), (2, L.GemmTN), (3, L.Seg), (4, L.View), (5, L.CopyRec), (6, L.Actor),
+                       (7, L.Sampler)):
+        assert lib.aew_sizeof(which) == C.sizeof(cls), cls.__name__
+    assert lib.aew_sizeof(99) == -1
+    assert lib.aew_strerror(-1) and lib.aew_strerror(0)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No CPU fallback: without the .so the product path raises instead of computing something else."""
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", L.LIB_PATH + ".absent")
+    with pytest.raises(L.AewError):
+        L.load()
