@@ -292,6 +292,8 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        sys.stdout.flush()
+        dist.barrier()                      # rank 0 arrives last (per-op timing pass): everybody leaves together
         dist.destroy_process_group()
 
 
