@@ -79,7 +79,7 @@ class VqEma(C.Structure):
 class VqBwd(C.Structure):
     _fields_ = [("ze", vp), ("emb", vp), ("ind", vp), ("dzq", vp), ("Q", i32), ("d", i32),
                 ("d_pitch", i32), ("metric", i32), ("coef", f32), ("demb_coef", f32),
-                ("dze", vp), ("demb", vp)]
+                ("dze", vp), ("demb", vp), ("gmul", vp)]
 
 
 class LcGather(C.Structure):
@@ -120,7 +120,7 @@ class SoftmaxNll(C.Structure):
     _fields_ = [("logits", vp), ("bs", i64), ("pitch", i32), ("wav", vp), ("wav_pitch", i32),
                 ("tgt_off", i32), ("B", i32), ("w", i32), ("Q", i32), ("Q_pad", i32),
                 ("nll", vp), ("ptgt", vp), ("dlogits", vp), ("dl_bs", i64), ("dl_pitch", i32),
-                ("scale", f32), ("backward", i32)]
+                ("scale", f32), ("backward", i32), ("gmul", vp)]
 
 
 class Colsum(C.Structure):
@@ -148,12 +148,12 @@ class Vae(C.Structure):
     _fields_ = [("lin", vp), ("lin_pitch", i32), ("eps", vp), ("Q", i32), ("d", i32),
                 ("d_pitch", i32), ("sample", vp), ("kl_terms", vp), ("dsample", vp),
                 ("kl_coef", f32), ("kl_value", vp), ("free_nats", f32), ("dlin", vp),
-                ("backward", i32), ("kl_coef_dev", vp)]
+                ("backward", i32), ("kl_coef_dev", vp), ("gmul", vp)]
 
 
 class AeNorm(C.Structure):
     _fields_ = [("ze", vp), ("Q", i32), ("d", i32), ("d_pitch", i32), ("term", vp),
-                ("dze_in", vp), ("coef", f32), ("dze", vp), ("backward", i32)]
+                ("dze_in", vp), ("coef", f32), ("dze", vp), ("backward", i32), ("gmul", vp)]
 
 
 class Jitter(C.Structure):

@@ -50,7 +50,7 @@ class AutoEncoder(HipModelBase):
                 if samples is None:
                     samples = torch.empty(n_samples, d, dtype=torch.float32, device=eng.device)
                 eng.set_inputs(wav, mel, voice, jitter)
-                eng.fwd_a.run(eng._stream())
+                eng.encode()                                     # encoder + bottleneck.linear only (no VQ side effects)
                 ze = eng.lin.tensor()[:, :, :d].reshape(-1, d)
                 c = min(n_samples - e, ze.shape[0])
                 samples[e:e + c] = ze[:c]                        # stays in HBM

@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256) void k_vq_bwd(const aew_vq_bwd_t p) {
     }
     dd = wave_sum(dd); zz = wave_sum(zz); qq = wave_sum(qq);
     const float u = sqrtf(dd), zn = sqrtf(zz), v = zn + sqrtf(qq);
+    const float gm = p.gmul ? p.gmul[0] : 1.0f;        // upstream gradient of this backward call
+    const float coef = p.coef * gm, demb_coef = p.demb_coef * gm;
     for (int j = lane; j < p.d_pitch; j += 64) {
         float gr = 0.f;
         if (j < p.d) {
@@ -270,8 +272,8 @@ __global__ __launch_bounds__(256) void k_vq_bwd(const aew_vq_bwd_t p) {
             float dj;
             if (p.metric == 0) dj = (u > 0.f ? t / (u * v) : 0.f) - (zn > 0.f ? u * z[j] / (v * v * zn) : 0.f);
             else dj = 2.0f * t;
-            gr = p.dzq[(int64_t)q * p.d_pitch + j] + p.coef * dj;
-            if (p.demb) atomicAdd(p.demb + k * p.d + j, p.demb_coef * (-2.0f * t));
+            gr = p.dzq[(int64_t)q * p.d_pitch + j] + coef * dj;
+            if (p.demb) atomicAdd(p.demb + k * p.d + j, demb_coef * (-2.0f * t));
         }
         p.dze[(int64_t)q * p.d_pitch + j] = gr;
     }
@@ -289,7 +291,12 @@ __global__ void k_lc_gather(const aew_lc_gather_t p) {
     const int b = (int)(e / ((int64_t)p.C_pad * p.N));
     float v = 0.f;
     if (c < p.C) {
-        const int64_t j = p.jitter[(int64_t)b * p.jit_pitch + t];
+        // The reference's Jitter emits t-1+x (x in 0..2) for every t < n (jitter.py:29-33), so the last entry may be n,
+        // one past the end; and a jitter row made for the mel frames is longer than the encoder output it indexes here.
+        // torch.gather would raise on such an index; the intended neighbour is the last row, so indices are clamped
+        // (reads and the matching gradient scatter stay inside the source matrix for every input).
+        int64_t j = p.jitter[(int64_t)b * p.jit_pitch + t];
+        j = j < 0 ? 0 : (j > p.N - 1 ? p.N - 1 : j);
         if (p.take_compat) {
             // torch.take on the flattened (B, C, N) tensor with index b*N + j, expanded over c:
             // flat index -> (b', c', n') of the NCL tensor
@@ -312,7 +319,8 @@ __global__ void k_lc_scatter(const aew_lc_scatter_t p) {
     const int t = (int)((e / p.C) % p.N);
     const int b = (int)(e / ((int64_t)p.C * p.N));
     const float g = p.d[(int64_t)b * p.d_bs + (int64_t)t * p.d_pitch + c];
-    const int64_t j = p.jitter[(int64_t)b * p.jit_pitch + t];
+    int64_t j = p.jitter[(int64_t)b * p.jit_pitch + t];
+    j = j < 0 ? 0 : (j > p.N - 1 ? p.N - 1 : j);          // same clamp as k_lc_gather
     if (p.take_compat) {
         const int64_t flat = (int64_t)b * p.N + j;
         const int64_t bb = flat / ((int64_t)p.C * p.N), cc = (flat / p.N) % p.C, nn = flat % p.N;
@@ -468,9 +476,10 @@ __global__ __launch_bounds__(256) void k_softmax_nll(const aew_softmax_nll_t p) 
         }
     } else {
         uint16_t* dl = p.dlogits + (int64_t)b * p.dl_bs + (int64_t)u * p.dl_pitch;
+        const float scale = p.gmul ? p.scale * p.gmul[0] : p.scale;
         for (int c = lane; c < p.Q_pad; c += 64) {
             float g = 0.f;
-            if (live && c < p.Q) g = (__expf(lg[c] - lse) - (c == tgt ? 1.f : 0.f)) * p.scale;
+            if (live && c < p.Q) g = (__expf(lg[c] - lse) - (c == tgt ? 1.f : 0.f)) * scale;
             dl[c] = f2bf(g);
         }
     }
@@ -605,7 +614,7 @@ __global__ void k_vae(const aew_vae_t p) {
     const int lane = threadIdx.x;                     // 64 threads
     const float* lin = p.lin + (int64_t)q * p.lin_pitch;
     float kl = 0.f;
-    const float kl_coef = p.kl_coef_dev ? p.kl_coef_dev[0] : p.kl_coef;
+    const float kl_coef = (p.kl_coef_dev ? p.kl_coef_dev[0] : p.kl_coef) * ((p.backward && p.gmul) ? p.gmul[0] : 1.0f);
     float klc = kl_coef;
     if (p.backward && p.kl_value) klc = (p.kl_value[0] >= p.free_nats) ? kl_coef : 0.f;
     for (int j = lane; j < p.d_pitch; j += 64) {
@@ -645,9 +654,10 @@ __global__ void k_ae_norm(const aew_ae_norm_t p) {
         if (lane == 0) p.term[q] = fabsf(nrm - 1.0f);
     } else {
         const float sgn = nrm > 1.0f ? 1.f : (nrm < 1.0f ? -1.f : 0.f);
+        const float coef = p.gmul ? p.coef * p.gmul[0] : p.coef;
         for (int j = lane; j < p.d_pitch; j += 64) {
             float g = 0.f;
-            if (j < p.d) g = p.dze_in[(int64_t)q * p.d_pitch + j] + (nrm > 0.f ? p.coef * sgn * z[j] / nrm : 0.f);
+            if (j < p.d) g = p.dze_in[(int64_t)q * p.d_pitch + j] + (nrm > 0.f ? coef * sgn * z[j] / nrm : 0.f);
             p.dze[(int64_t)q * p.d_pitch + j] = g;
         }
     }

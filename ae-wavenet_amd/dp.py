@@ -37,8 +37,24 @@ class DataParallel:
     def grad_scale(self, mean_loss: bool) -> float:
         """Factor the optimizer applies to the summed gradient: 1/world reproduces the
         single-process gradient of a mean-type loss over the global batch; sum-type losses
-        (VQ, KL) keep the sum."""
+        (VQ) keep the sum.  The VAE mixes both (mean NLL + annealed, clamped SUM of KL, vae_bn.py:90-125):
+        prepare_vae() makes its KL part come out right under the 1/world factor."""
         return 1.0 / self.world if mean_loss else 1.0
+
+    def prepare_vae(self, eng):
+        """VAE under data parallel = the single-process objective over the global batch:
+        mean(NLL over all ranks' positions) + anneal * clamp(sum of KL over ALL ranks' windows, min=free_nats).
+        (1) the KL gradient coefficient is pre-multiplied by world (the optimizer divides the summed gradient by
+        world for the mean-type NLL); (2) the free-nats gate of the clamp must see the GLOBAL KL: allreduce_kl()
+        between forward and backward."""
+        if eng.bn_type == "vae":
+            eng.dp_world = self.world
+            eng.set_anneal_weight(eng.anneal_weight)
+
+    def allreduce_kl(self, eng):
+        """Sum the KL value the backward's clamp gate reads (loss_buf[2]) over the ranks (VAE only)."""
+        if eng.bn_type == "vae" and self.world > 1:
+            dist.all_reduce(eng.loss_buf[2:3], op=dist.ReduceOp.SUM, group=self.group)
 
     def allreduce_grads(self, eng):
         flat = eng.ps.grads[:eng.ps.numel]
@@ -90,6 +106,7 @@ class DataParallel:
             work["dec"] = dist.all_reduce(flat[lo:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
         eng.forward(self.allreduce_ema_async)
+        self.allreduce_kl(eng)
         eng.backward(after_decoder=after_decoder)
         if lo > 0:
             work["enc"] = dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -137,3 +154,5 @@ class DataParallel:
     def attach(self, model):
         model._dp = self
         model._ema_allreduce = self.allreduce_ema
+        if getattr(model, "_engine", None) is not None:
+            self.prepare_vae(model._engine)

@@ -196,6 +196,7 @@ class DecoderPlan:
                  jitter: torch.Tensor, take_compat: bool, packer: Packer, impl: int = 0):
         self.ws, self.ps, self.hps, self.g, self.B, self.pre = ws, ps, hps, geom, B, pre
         self.impl = impl
+        self.gmul_ptr = ws.bufs["loss.gmul"].data_ptr() if "loss.gmul" in ws.bufs else 0
         self.n_lc_in = n_lc_in
         self.lc_src, self.wav, self.voice, self.jitter = lc_src, wav, voice, jitter
         self.take_compat = take_compat
@@ -525,6 +526,8 @@ class DecoderPlan:
         sm.nll, sm.ptgt = self.nll.data_ptr(), self.ptgt.data_ptr()
         sm.dlogits, sm.dl_bs, sm.dl_pitch = self.dlogits.ptr, self.dlogits.bs, self.dlogits.pitch
         sm.scale, sm.backward = scale, int(backward)
+        if backward and self.gmul_ptr:
+            sm.gmul = self.gmul_ptr
         return sm
 
     # -- backward --------------------------------------------------------------------------

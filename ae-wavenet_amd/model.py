@@ -22,6 +22,9 @@ from .plan import CopyTableBuilder, Mat, Plan, Workspace, make_nt, make_tn, null
 MEAN_LOSS = {"none": True, "ae": True, "vae": True, "vqvae": False, "vqvae-ema": False}
 
 
+_SERIAL = [0]
+
+
 class TrainEngine:
     """kind: 'autoencoder' | 'mfcc_inverter'.
 
@@ -36,6 +39,9 @@ class TrainEngine:
                  take_compat: bool = False, update_codebook_every_step: bool = True, impl: int = 0,
                  n_win: Optional[int] = None, use_graphs: bool = True):
         self.hps, self.B, self.impl = hps, B, impl
+        _SERIAL[0] += 1
+        self.serial = _SERIAL[0]          # unique per engine (id() can be recycled after garbage collection)
+        self.weights_version = 0          # bumped by adam_step(): FusedAdam writes parameters by raw pointer
         self.use_graphs = use_graphs
         self.kind = hps.global_model
         self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
@@ -64,6 +70,11 @@ class TrainEngine:
         self.in_voice = ws.alloc("in.voice", B, torch.int64)[:B]
         self.in_jitter = ws.alloc("in.jitter", B * g.embed_len, torch.int64)[:B * g.embed_len].view(B, g.embed_len)
         self.loss_buf = ws.alloc("loss", 8, torch.float32)
+        # upstream gradient d(L)/d(loss) of the current backward call (autograd's `g`): the ops where the loss
+        # gradient enters the backward read it from device memory, so (loss * k).backward() scales every gradient
+        # without a host sync and without touching the captured graphs
+        self.gmul = ws.alloc("loss.gmul", 4, torch.float32)
+        self.gmul[:1].fill_(1.0)
         # ---- tables
         # encoder / bottleneck tables stay on the main lane (their packed weights are needed at once and
         # their gradients come last); the decoder's are side-lane work: its weight pack overlaps the
@@ -133,7 +144,9 @@ class TrainEngine:
             self.eps = ws.alloc("bn.eps", self.Q * d, torch.float32)[:self.Q * d].view(B, Ne, d)
             self.kl_terms = ws.alloc("bn.kl_terms", self.Q, torch.float32)
             self.anneal_weight = 0.0
-            self.anneal_buf = ws.alloc("bn.anneal", 4, torch.float32)[:1]   # read by the loss / KL-gradient ops
+            self.dp_world = 1                                                # set by dp.DataParallel (see set_anneal_weight)
+            self.anneal_buf = ws.alloc("bn.anneal", 4, torch.float32)[:1]   # read by the loss op
+            self.anneal_bwd = ws.alloc("bn.anneal_bwd", 4, torch.float32)[:1]   # read by the KL-gradient op
         elif bn == "ae":
             self.code = self.lin
             self.norm_terms = ws.alloc("bn.norm_terms", self.Q, torch.float32)
@@ -180,6 +193,12 @@ class TrainEngine:
                     st.Q, st.K, st.d, st.d_pitch = self.Q, self.K, self.d, self.nlin_p
                     st.z_sum, st.n_sum, st.hist = self.z_sum.data_ptr(), self.n_sum.data_ptr(), self.ind_hist.data_ptr()
                     fa.add(L.OP_VQ_STATS, st, "vq.stats", TAG_VQ)
+                    # the diagnostics op (side lane of fwd_b) reads this step's LOCAL code counts; a data-parallel
+                    # caller all-reduces zn_sum in place while fwd_b runs, so it gets its own copy
+                    self.n_sum_diag = ws.alloc("bn.n_sum_diag", self.K, torch.float32)
+                    ntbl = CopyTableBuilder(ws, "tbl.nsum")
+                    ntbl.add(self.n_sum.data_ptr(), self.n_sum_diag.data_ptr(), [self.K], [1], [1], F3, F3)
+                    ntbl.emit(fa, "n_sum -> diagnostics copy")
                     em = L.VqEma()
                     em.numer, em.denom = self.ema_numer.data_ptr(), self.ema_denom.data_ptr()
                     em.z_sum, em.n_sum, em.emb = self.z_sum.data_ptr(), self.n_sum.data_ptr(), self.emb.data_ptr()
@@ -236,7 +255,7 @@ class TrainEngine:
             dg.K = hps.bn_vq_n_embed
             dg.emb = self.emb.data_ptr() if bn == "vqvae-ema" else ps.ptr("bottleneck.emb")
             if bn == "vqvae-ema":
-                dg.hist, dg.n_sum = self.ind_hist.data_ptr(), self.n_sum.data_ptr()
+                dg.hist, dg.n_sum = self.ind_hist.data_ptr(), self.n_sum_diag.data_ptr()
         lgm = self.dec.logits
         dg.logits, dg.bs, dg.pitch, dg.B, dg.w, dg.n_quant = lgm.ptr, lgm.bs, lgm.pitch, B, w, hps.n_quant
         dg.scratch, dg.out = self.diag_scratch.data_ptr(), self.diag.data_ptr()
@@ -265,6 +284,7 @@ class TrainEngine:
                 vb.demb_coef = 1.0
                 vb.dze = self.dlin.ptr
                 vb.demb = ps.ptr("bottleneck.emb", True) if bn == "vqvae" else None
+                vb.gmul = self.gmul.data_ptr()
                 bw.add(L.OP_VQ_BWD, vb, "vq.bwd", TAG_VQ)
             elif bn == "vae":
                 self._vae_bwd_index = len(bw.ops)
@@ -351,10 +371,11 @@ class TrainEngine:
         if backward:
             va.dsample = dcode.ptr
             va.kl_coef = float(self.anneal_weight)
-            va.kl_coef_dev = self.anneal_buf.data_ptr()
+            va.kl_coef_dev = self.anneal_bwd.data_ptr()
             va.kl_value = self.loss_buf.data_ptr() + 4 * 2       # out[1 + term 1]
             va.free_nats = float(self.hps.bn_free_nats)
             va.dlin = self.dlin.ptr
+            va.gmul = self.gmul.data_ptr()
         return va
 
     def _ae_norm_op(self, backward: bool, dcode: Optional[Mat] = None) -> L.AeNorm:
@@ -364,6 +385,7 @@ class TrainEngine:
         an.backward = int(backward)
         if backward:
             an.dze_in, an.coef, an.dze = dcode.ptr, 0.001 / self.Q, self.dlin.ptr
+            an.gmul = self.gmul.data_ptr()
         return an
 
     # --------------------------------------------------------------------------------------
@@ -393,6 +415,9 @@ class TrainEngine:
         patched and no captured graph is invalidated."""
         self.anneal_weight = float(a)
         self.anneal_buf.fill_(float(a))
+        # Data parallel (dp.DataParallel): the optimizer scales the SUMMED gradient by 1/world (mean-type NLL), but
+        # the KL term is a sum over all windows of the global batch, so its gradient must not be divided: pre-multiply
+        self.anneal_bwd.fill_(float(a) * float(getattr(self, "dp_world", 1)))
 
     def _run(self, plan, timing=False):
         if self.use_graphs and not timing:
@@ -400,19 +425,34 @@ class TrainEngine:
         else:
             plan.run(self._stream())
 
+    def _sub_plan(self, name: str, src: Plan, keep) -> Plan:
+        """A plan made of the ops of `src` whose (index, label) passes `keep` (shares the op records)."""
+        sp = Plan(name)
+        idx = [i for i, lab in enumerate(src.labels) if keep(i, lab)]
+        sp.ops, sp.labels = [src.ops[i] for i in idx], [src.labels[i] for i in idx]
+        return sp
+
+    def encode(self):
+        """Encoder + bottleneck.linear only (what autoencoder_model.py:171-199 runs to collect k-means samples):
+        no nearest-code search, no EMA statistics, no index histogram update.  Result in `self.lin`."""
+        if getattr(self, "_encode_plan", None) is None:
+            fa = self.fwd_a
+            stop = fa.labels.index("bn.linear") + 1
+            self._encode_plan = self._sub_plan("encode", fa, lambda i, lab: i < stop)
+        self._run(self._encode_plan, False)
+
     def conditioning(self):
         """Encoder / bottleneck and the conditioning half of the decoder forward only (jitter gather, lc_conv,
-        upsampler, speaker bias): what the autoregressive sampler needs (wavenet.py:379-391).  No EMA update, no
-        loss.  Returns (cond bf16 [B][T][Cp], gated bias fp32 [B][NL][2*Dp])."""
+        upsampler, speaker bias): what the autoregressive sampler needs (wavenet.py:379-391).  No EMA statistics
+        or update, no index histogram update (vq.stats is skipped), no loss.
+        Returns (cond bf16 [B][T][Cp], gated bias fp32 [B][NL][2*Dp])."""
         if getattr(self, "_cond_plan", None) is None:
             fb = self.fwd_b
             stop = fb.labels.index("G1.0") if "G1.0" in fb.labels else next(
                 i for i, l in enumerate(fb.labels) if l.startswith("G1.0"))
-            keep = [i for i in range(stop) if fb.labels[i] != "vq.ema"]
-            cp = Plan("conditioning")
-            cp.ops, cp.labels = [fb.ops[i] for i in keep], [fb.labels[i] for i in keep]
-            self._cond_plan = cp
-        self._run(self.fwd_a, False)
+            self._cond_plan = self._sub_plan("conditioning", fb, lambda i, lab: i < stop and lab != "vq.ema")
+            self._cond_plan_a = self._sub_plan("conditioning_a", self.fwd_a, lambda i, lab: lab != "vq.stats")
+        self._run(self._cond_plan_a, False)
         self._run(self._cond_plan, False)
         d = self.dec
         return d.cond.tensor(), d.bias_bl[:self.B * d.NL * 2 * d.Dp].view(self.B, d.NL, 2 * d.Dp)
@@ -437,6 +477,13 @@ class TrainEngine:
             self._ema_work.wait()
             self._ema_work = None
             self._run(self.ema_plan, timing)
+
+    def set_upstream_grad(self, g):
+        """d(L)/d(loss) for the next backward(): a python float or a 0-d tensor (copied device-side, no sync)."""
+        if torch.is_tensor(g):
+            self.gmul[:1].copy_(g.detach().reshape(1).to(self.gmul.dtype), non_blocking=True)
+        else:
+            self.gmul[:1].fill_(float(g))
 
     def backward(self, timing=False, after_decoder=None):
         """after_decoder: optional callback invoked between the decoder part of the backward (all
@@ -464,6 +511,7 @@ class TrainEngine:
         reduced (`count=False` on all but the first range of a step)."""
         if count:
             self.step_count += 1
+        self.weights_version += 1
         hi = self.ps.numel if hi is None else hi
         assert lo % 4 == 0 and (hi % 4 == 0 or hi == self.ps.numel) and 0 <= lo < hi <= self.ps.numel
         a = self.opt.array()[0].u.adam

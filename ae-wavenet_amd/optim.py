@@ -10,7 +10,9 @@ import torch
 
 class FusedAdam(torch.optim.Optimizer):
     """The moments live in the engine's flat buffers (adam.m / adam.v, same offsets as the
-    parameters).  state_dict() / load_state_dict() speak torch.optim.Adam's format (per-parameter
+    parameters); when no engine holds them (before the first run(), after model.to() / override() / a
+    change of batch size) the model carries them (`HipModelBase._opt_carry`), so they survive every
+    engine rebuild.  state_dict() / load_state_dict() speak torch.optim.Adam's format (per-parameter
     `step`, `exp_avg`, `exp_avg_sq`, parameters numbered in model.parameters() order) so that
     checkpoints interchange with the reference (checkpoint.py:61-63,87-98)."""
 
@@ -19,80 +21,75 @@ class FusedAdam(torch.optim.Optimizer):
         params = list(model.parameters())
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = grad_scale
-        self._pending = None          # (step, {name: (exp_avg, exp_avg_sq)}) loaded before the engine exists
 
     @torch.no_grad()
     def step(self, closure=None):
         eng = self.model._engine
         if eng is None:
             raise RuntimeError("FusedAdam.step() before the first model.run()")
-        self._flush_pending(eng)
         g = self.param_groups[0]
         eng.adam_step(g["lr"], self.grad_scale, g["betas"], g["eps"])
 
     # ---- torch.optim.Adam-compatible state -------------------------------------------------
-    def _names(self):
-        return [n for n, _ in self.model.named_parameters()]
-
-    def _flush_pending(self, eng):
-        if self._pending is None:
-            return
-        step, moments = self._pending
-        for n, (m, v) in moments.items():
-            o, k = eng.ps.off[n], eng.ps.numel_of(n)
-            eng.adam_m[o:o + k].copy_(m.reshape(-1).to(eng.adam_m.device))
-            eng.adam_v[o:o + k].copy_(v.reshape(-1).to(eng.adam_v.device))
-        eng.step_count = int(step)
-        self._pending = None
+    def _layout(self):
+        """[(name, flat offset, numel, shape)] and the flat length: the ParamStore rule (engine.py), computed from
+        the parameter specs so that it is known without an engine."""
+        out, o = [], 0
+        for name, p in self.model.named_parameters():
+            k = p.numel()
+            out.append((name, o, k, tuple(p.shape)))
+            o += (k + 3) // 4 * 4
+        return out, o
 
     def state_dict(self):
-        names = self._names()
-        eng = self.model._engine
+        lay, _ = self._layout()
         g = self.param_groups[0]
         group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": list(range(len(names)))}
+                 "params": list(range(len(lay)))}
         state = {}
-        if eng is not None and self._pending is None and eng.step_count > 0:
-            torch.cuda.synchronize() if eng.adam_m.is_cuda else None
-            for i, n in enumerate(names):
-                o, k, shp = eng.ps.off[n], eng.ps.numel_of(n), eng.ps.shape[n]
-                state[i] = {"step": torch.tensor(float(eng.step_count)),
-                            "exp_avg": eng.adam_m[o:o + k].reshape(shp).detach().cpu().clone(),
-                            "exp_avg_sq": eng.adam_v[o:o + k].reshape(shp).detach().cpu().clone()}
-        elif self._pending is not None:
-            step, moments = self._pending
-            for i, n in enumerate(names):
-                if n in moments:
-                    state[i] = {"step": torch.tensor(float(step)), "exp_avg": moments[n][0].clone(),
-                                "exp_avg_sq": moments[n][1].clone()}
+        st = self.model._opt_state_flat()
+        if st is not None and int(st[0]) > 0:
+            step, m, v = st
+            m, v = m.detach().cpu(), v.detach().cpu()           # (synchronises with the stream that wrote them)
+            for i, (n, o, k, shp) in enumerate(lay):
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": m[o:o + k].reshape(shp).clone(),
+                            "exp_avg_sq": v[o:o + k].reshape(shp).clone()}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, state_dict):
-        names = self._names()
+        lay, total = self._layout()
         groups = state_dict["param_groups"]
         order = [i for g in groups for i in g["params"]]
-        if len(order) != len(names):
-            raise ValueError(f"optimizer state has {len(order)} parameters, the model {len(names)}")
+        if len(order) != len(lay):
+            raise ValueError(f"optimizer state has {len(order)} parameters, the model {len(lay)}")
         g0 = groups[0]
         for k in ("lr", "betas", "eps"):
             if k in g0:
                 self.param_groups[0][k] = tuple(g0[k]) if k == "betas" else g0[k]
         st = state_dict.get("state", {})
-        moments, step = {}, 0
+        m, v = torch.zeros(total), torch.zeros(total)
+        step, found = 0, False
         for pos, idx in enumerate(order):
             s = st.get(idx, st.get(str(idx)))
             if s is None:
                 continue
-            p_shape = tuple(dict(self.model.named_parameters())[names[pos]].shape)
-            if tuple(s["exp_avg"].shape) != p_shape:
-                raise ValueError(f"exp_avg of parameter {names[pos]} has shape {tuple(s['exp_avg'].shape)}, expected {p_shape}")
-            moments[names[pos]] = (s["exp_avg"].detach().float().cpu(), s["exp_avg_sq"].detach().float().cpu())
+            n, o, k, shp = lay[pos]
+            if tuple(s["exp_avg"].shape) != shp:
+                raise ValueError(f"exp_avg of parameter {n} has shape {tuple(s['exp_avg'].shape)}, expected {shp}")
+            m[o:o + k] = s["exp_avg"].detach().float().cpu().reshape(-1)
+            v[o:o + k] = s["exp_avg_sq"].detach().float().cpu().reshape(-1)
             step = max(step, int(float(s["step"])))
-        self._pending = (step, moments) if moments else None
-        eng = self.model._engine
-        if eng is not None and self._pending is not None:
-            self._flush_pending(eng)
+            found = True
+        if not found:
+            return
+        model = self.model
+        model._opt_carry = (step, m.to(model._device), v.to(model._device))
+        eng = model._engine
+        if eng is not None:
+            eng.adam_m[:total].copy_(model._opt_carry[1])
+            eng.adam_v[:total].copy_(model._opt_carry[2])
+            eng.step_count = step
 
     def zero_grad(self, set_to_none=True):
         # gradients are rewritten (not accumulated) by every backward; nothing to do

@@ -36,7 +36,14 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        # g = d(L)/d(loss) from autograd ((loss * k).backward(), loss scaling, ...).  It is copied device-side into
+        # the engine's `gmul` scalar, which the ops where the loss gradient enters the backward plan multiply in, so
+        # every .grad carries it.  .grad is OVERWRITTEN by each backward (the reference harness zeroes it every
+        # step, chassis.py:157-160); accumulation over several backward() calls is not supported.
         owner = ctx.owner
+        owner._engine.set_upstream_grad(g)
+        if owner._dp is not None:
+            owner._dp.allreduce_kl(owner._engine)           # VAE: the clamp's gate sees the global KL
         owner._engine.backward()
         owner._after_backward(g)
         return torch.zeros_like(owner._anchor), None
@@ -93,6 +100,9 @@ class HipModelBase(nn.Module):
                           update_codebook_every_step=update_codebook_every_step, n_mel=n_mel)
         self.window_batch_size = hps.n_win_batch
         self._engine: Optional[TrainEngine] = None
+        self._engines: Dict[int, TrainEngine] = {}      # engines by batch size (train B, sampling B = 1, ...)
+        self._opt_carry = None                           # (step, exp_avg flat, exp_avg_sq flat) while no engine holds them
+        self._weights_epoch = 0                          # bumped whenever parameter values change behind torch's back
         self._device = torch.device("cpu")
         self._pending_state: Optional[Dict[str, torch.Tensor]] = None
         self._ema_allreduce = None
@@ -204,6 +214,7 @@ class HipModelBase(nn.Module):
                 else:
                     unexpected.append(k)
         self._push_buffers_to_engine()
+        self._weights_epoch += 1
         if strict and (missing or [u for u in unexpected if "_lead" not in u and "eye" not in u
                                    and "residual_offsets" not in u]):
             raise RuntimeError(f"state_dict mismatch: missing {missing}, unexpected {unexpected}")
@@ -212,20 +223,44 @@ class HipModelBase(nn.Module):
     # ---- device placement / engine ---------------------------------------------------------
     def _apply(self, fn, recurse=True):
         # .to(device) / .float() ...: let nn.Module move the parameter tensors (views into the
-        # engine's flat buffer are copied out by this), then drop the engine; it is rebuilt
-        # lazily on the next run() and the values are copied back in.
+        # engine's flat buffer are copied out by this), then drop the engines; one is rebuilt
+        # lazily on the next run() and the values (and the Adam moments) are copied back in.
         if self._engine is not None:
             self._sync_buffers_from_engine()
+            self._save_opt_carry()
         out = super()._apply(fn, recurse)
         self._engine = None
+        self._engines = {}
         self._device = next(iter(self._parameters.values())).device
+        if self._opt_carry is not None:
+            st, m, v = self._opt_carry
+            self._opt_carry = (st, m.to(self._device), v.to(self._device))
         self._anchor = torch.zeros((), requires_grad=True, device=self._device)
         return out
 
     def _drop_engine(self):
         if self._engine is not None:
             self._pull_params_to_cpu()
+            self._save_opt_carry()
         self._engine = None
+        self._engines = {}
+
+    def _save_opt_carry(self):
+        """Adam moments / step count live in the engine's flat buffers; keep them when the engine goes away
+        (model.to(), override(), a different batch size, sample()), so optimizer state survives exactly like
+        torch.optim.Adam's per-parameter state does in the reference's save / restore flow (checkpoint.py:82-102)."""
+        eng = self._engine
+        if eng is not None and (eng.step_count > 0 or self._opt_carry is None):
+            n = eng.ps.numel
+            self._opt_carry = (eng.step_count, eng.adam_m[:n].detach().clone(), eng.adam_v[:n].detach().clone())
+
+    def _opt_state_flat(self):
+        """(step, exp_avg flat, exp_avg_sq flat) from the live engine, else from the carry, else None."""
+        eng = self._engine
+        if eng is not None:
+            n = eng.ps.numel
+            return eng.step_count, eng.adam_m[:n], eng.adam_v[:n]
+        return self._opt_carry
 
     def _pull_params_to_cpu(self):
         eng = self._engine
@@ -259,8 +294,16 @@ class HipModelBase(nn.Module):
                              "move it to a cuda device first (no CPU execution path exists)")
         L.load()
         if eng is not None:
+            # another batch size (e.g. sample() uses B = 1 between training steps): parameters, EMA buffers and
+            # Adam moments move to the other engine; engines are kept per batch size so that switching back does
+            # not rebuild plans and graphs
             self._pull_params_to_cpu()
-        eng = TrainEngine(self.hps, B, self._device, n_win=self.window_batch_size, **self._opts)
+            self._save_opt_carry()
+        new = self._engines.get(B)
+        if new is None:
+            new = TrainEngine(self.hps, B, self._device, n_win=self.window_batch_size, **self._opts)
+            self._engines[B] = new
+        eng = new
         # re-home the parameters into the flat buffer (values preserved)
         with torch.no_grad():
             for name, pname in self._pnames:
@@ -270,7 +313,16 @@ class HipModelBase(nn.Module):
                 p.data = view
                 p.grad = eng.ps.view(name, grad=True)
         self._engine = eng
+        self._weights_epoch += 1
         self._push_buffers_to_engine()
+        if self._opt_carry is not None:
+            st, m, v = self._opt_carry
+            n = eng.ps.numel
+            eng.adam_m[:n].copy_(m)
+            eng.adam_v[:n].copy_(v)
+            eng.step_count = int(st)
+        if self._dp is not None:
+            self._dp.prepare_vae(eng)
         if eng.bn_type == "vae":
             eng.set_anneal_weight(float(self.objective.anneal_weight))
         return eng
@@ -316,8 +368,10 @@ class HipModelBase(nn.Module):
             eng = self._ensure_engine(1)
             eng.set_inputs(wav, mel, voice, jitter)
             cond, bias = eng.conditioning()
-            stamp = (id(eng), eng.ps.params._version)
-            if self._sampler is None or self._sampler[0] != stamp:       # weights are re-packed when they changed
+            # the sampler keeps its own packed copy of the weights: re-pack whenever they may have changed.  FusedAdam
+            # updates parameters by raw pointer (no tensor _version bump), hence the explicit counters
+            stamp = (eng.serial, eng.ps.params._version, eng.weights_version, self._weights_epoch)
+            if self._sampler is None or self._sampler[0] != stamp:
                 self._sampler = (stamp, S.from_engine(eng))
             smp = self._sampler[1]
             g = eng.geom
@@ -363,7 +417,7 @@ class HipModelBase(nn.Module):
             if eng.bn_type == "vqvae-ema":
                 m["hst_ent"], m["nunq"] = dg[4], dg[5]              # vqema_bn.py:258-260
             else:
-                m["nunq"] = eng.ind[:eng.Q].unique().numel
+                m["nunq"] = eng.ind[:eng.Q].unique().numel()
         elif eng.bn_type == "vae":
             m["kl_div_loss"], m["log_pred_loss"] = eng.loss_buf[2], m["rec"]
         elif eng.bn_type == "ae":

@@ -202,6 +202,8 @@ typedef struct {                 /* d(ze) = d(zq) + gscale*gamma * d(min_dist)/d
     float demb_coef;             /* upstream loss gradient (weight of the l2 term, vq_bn.py:78) */
     float* dze;                  /* [Q][d_pitch]                                              */
     float* demb;                 /* optional [K][d], pre-zeroed: d/d(emb) of sum (sg(ze)-emb)^2 */
+    const float* gmul;           /* optional device scalar: upstream d(L)/d(loss) of THIS backward call; multiplies
+                                    coef and demb_coef at run time (a captured graph stays valid for any value)  */
 } aew_vq_bwd_t;
 
 typedef struct {                 /* jitter gather (wavenet.py:330-336) fp32 -> bf16           */
@@ -266,8 +268,9 @@ typedef struct {                 /* fused log-softmax + NLL (+ gradient)  wavene
     float* nll;                  /* fwd: [B][w] per-position nll (0 at u=w-1)                 */
     float* ptgt;                 /* fwd: [B][w] probability of the target (chassis.py:266-270)*/
     uint16_t* dlogits; int64_t dl_bs; int32_t dl_pitch;     /* bwd: bf16 [B][w][Q_pad]        */
-    float scale;                 /* bwd: d(loss)/d(nll term) incl. upstream gradient          */
+    float scale;                 /* bwd: d(loss)/d(nll term)                                  */
     int32_t backward;
+    const float* gmul;           /* optional device scalar: upstream d(L)/d(loss), multiplies scale at run time */
 } aew_softmax_nll_t;
 
 typedef struct {                 /* MFCC + delta + delta-delta front-end on the device (mfcc.py:39-76: librosa.feature.mfcc
@@ -342,6 +345,7 @@ typedef struct {                 /* VAE reparameterisation (vae_bn.py:44-53) and
     float* dlin;                            /* bwd: [Q][2d pitch]                            */
     int32_t backward;
     const float* kl_coef_dev;               /* if non-NULL, kl_coef is read from device memory at run time  */
+    const float* gmul;                      /* optional device scalar: upstream d(L)/d(loss), multiplies kl_coef */
 } aew_vae_t;
 
 typedef struct {                 /* AE norm term (ae_bn.py:36-38): | ||ze|| - 1 | per row      */
@@ -349,6 +353,7 @@ typedef struct {                 /* AE norm term (ae_bn.py:36-38): | ||ze|| - 1 
     float* term;                 /* fwd: [Q]                                                  */
     const float* dze_in; float coef; float* dze;  /* bwd: dze = dze_in + coef*sign*ze/||ze||   */
     int32_t backward;
+    const float* gmul;           /* optional device scalar: upstream d(L)/d(loss), multiplies coef              */
 } aew_ae_norm_t;
 
 typedef struct {                 /* time-jitter indices on the device (jitter.py:13-33).  out[b][t] = t - 1 + X[b][t],

@@ -690,8 +690,23 @@ def gen_sampler():
     save("mi_tiny_sampler.npz", **res)
 
 
+def gen_par():
+    """The key / value sets of the reference's par/arch.*.json and par/train.*.json (north_star: "par/*.json config
+    schema"), as data, so that config.from_par is tested against every file the reference ships."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob(os.path.join(REF, "par", "*.json"))):
+        with open(path) as fh:
+            out[os.path.basename(path)] = json.load(fh)
+    with open(os.path.join(HERE, "par_values.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("par_values.json:", sorted(out))
+
+
 def main():
-    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt", "jitter", "sampler"]
+    which = sys.argv[1:] or ["geometry", "mi", "ae", "full", "ckpt", "jitter", "sampler", "par"]
+    if "par" in which:
+        gen_par()
     if "sampler" in which:
         gen_sampler()
     if "jitter" in which:

@@ -222,6 +222,10 @@ class Emu:
             new = torch.where(de[:, None] > 0, nu.view(p.K, p.d) / de[:, None].clamp_min(1e-30), old)
             self.wr(p.emb, kd, new.reshape(-1))
 
+    def _gmul(self, p) -> float:
+        """optional device scalar: upstream d(L)/d(loss) of the backward call (aewavenet.h, `gmul`)"""
+        return float(self.rd(p.gmul, torch.arange(1))[0]) if p.gmul else 1.0
+
     def op_7(self, p):   # VQ_BWD
         idx = torch.arange(p.Q)[:, None] * p.d_pitch + torch.arange(p.d)[None, :]
         z = self.rd(p.ze, idx)
@@ -236,17 +240,19 @@ class Emu:
             dj = t / (u * v) - u * z / (v * v * zn)
         else:
             dj = 2 * t
+        gm = self._gmul(p)
         out = torch.zeros(p.Q, p.d_pitch)
-        out[:, :p.d] = dzq + p.coef * dj
+        out[:, :p.d] = dzq + p.coef * gm * dj
         self.wr(p.dze, torch.arange(p.Q * p.d_pitch), out.reshape(-1))
         if p.demb:
             ft, off = self.flat(p.demb)
             K = int(ind.max()) + 1
-            acc = torch.zeros(K, p.d).index_add_(0, ind, -2.0 * t * p.demb_coef)
+            acc = torch.zeros(K, p.d).index_add_(0, ind, -2.0 * t * p.demb_coef * gm)
             ft[off: off + K * p.d] += acc.reshape(-1)
 
     def _gather_index(self, p, B, N, C_):
         j = self.rd(p.jitter, torch.arange(B)[:, None] * p.jit_pitch + torch.arange(N)[None, :])   # B,N
+        j = j.clamp(0, N - 1)                    # the kernels clamp (the reference's Jitter can emit N at position N-1)
         b = torch.arange(B)[:, None, None].expand(B, N, C_)
         c = torch.arange(C_)[None, None, :].expand(B, N, C_)
         jj = j[:, :, None].expand(B, N, C_)
@@ -359,7 +365,7 @@ class Emu:
             if p.ptgt:
                 self.wr(p.ptgt, torch.arange(p.B * p.w), (lp.exp() * live).reshape(-1))
         else:
-            g = (lsm.exp() - torch.nn.functional.one_hot(tgt, p.Q).float()) * p.scale * live[:, :, None]
+            g = (lsm.exp() - torch.nn.functional.one_hot(tgt, p.Q).float()) * (p.scale * self._gmul(p)) * live[:, :, None]
             out = torch.zeros(p.B, p.w, p.Q_pad)
             out[:, :, :p.Q] = g
             idx = (torch.arange(p.B)[:, None, None] * p.dl_bs + torch.arange(p.w)[None, :, None] * p.dl_pitch
@@ -414,6 +420,7 @@ class Emu:
             self.wr(p.kl_terms, torch.arange(p.Q), (1 + torch.log(s2) - mu * mu - s2).sum(1))
         else:
             klc = float(self.rd(p.kl_coef_dev, torch.arange(1))[0]) if p.kl_coef_dev else p.kl_coef
+            klc *= self._gmul(p)
             if p.kl_value:
                 klc = klc if float(self.rd(p.kl_value, torch.arange(1))[0]) >= p.free_nats else 0.0
             ds = self.rd(p.dsample, q * p.d_pitch + j)
@@ -428,7 +435,7 @@ class Emu:
         if not p.backward:
             self.wr(p.term, torch.arange(p.Q), (nrm - 1).abs())
         else:
-            g = self.rd(p.dze_in, q * p.d_pitch + j) + p.coef * torch.sign(nrm - 1)[:, None] * z / nrm[:, None]
+            g = self.rd(p.dze_in, q * p.d_pitch + j) + p.coef * self._gmul(p) * torch.sign(nrm - 1)[:, None] * z / nrm[:, None]
             out = torch.zeros(p.Q, p.d_pitch)
             out[:, :p.d] = g
             self.wr(p.dze, torch.arange(p.Q * p.d_pitch), out.reshape(-1))
