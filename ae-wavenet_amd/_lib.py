@@ -41,7 +41,8 @@ class GemmNT(C.Structure):
                 ("batch", i32), ("n_segs", i32), ("K_total", i32), ("seg", Seg * MAX_SEGS),
                 ("W", vp), ("epi", i32), ("flags", u32), ("out0", View), ("out1", View),
                 ("out2", View), ("aux0", View), ("aux1", View), ("bias", vp), ("bias_bs", i64),
-                ("n_split", i32), ("reserved", i32), ("counter", vp)]
+                ("n_split", i32), ("reserved", i32), ("counter", vp),
+                ("W2", vp), ("N2", i32), ("N2_pad", i32), ("out3", View)]
 
 
 class GemmTN(C.Structure):
@@ -260,7 +261,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 11:
+    if lib.aew_abi_version() != 12:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -284,4 +285,4 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
            "aew_set_lanes", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_rows192",
-           "aew_sampler_run")
+           "aew_sampler_run", "aew_set_fn")

@@ -1653,8 +1653,56 @@ static int check_seg(const aew_seg_t& s, int esize, int ktile) {
     return 0;
 }
 
+// full-N kernels (aew_fn.hip, same translation unit)
+static bool fn_supported(const aew_gemm_nt_t& g);
+static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st);
+extern int g_fn_enable_flag();
+
 static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.M <= 0 || g.batch <= 0 || !g.W) return AEW_E_ARG;
+    if (g.W2) {
+        // fused gated layer: z tile -> residual 1x1 (see aewavenet.h)
+        if (g.epi != AEW_EPI_GATED || g.dtype != AEW_BF16 || g.N2 <= 0 || g.N2 > g.N2_pad || (g.N2 & 7) || g.N2_pad % 128 ||
+            !g.out3.ptr || !g.out0.ptr || g.out0.dtype != AEW_BF16 || ((uintptr_t)g.W2 & 15))
+            return AEW_E_ARG;
+        {   // the residual GEMM consumes z for every row m in [0, M): out0 must hold them all
+            const int64_t r0 = g.out0.row_off, r1 = (int64_t)(g.M - 1) * g.out0.row_step + g.out0.row_off;
+            if (r0 < g.out0.row_lo || r0 >= g.out0.row_hi || r1 < g.out0.row_lo || r1 >= g.out0.row_hi) return AEW_E_ARG;
+        }
+        if (!(g.impl == 2 && g_fn_enable_flag() && fn_supported(g))) {
+            // unfused execution with the same result: GATED, then a STORE | ADD_AUX0 GEMM over the z it wrote
+            aew_gemm_nt_t a = g;
+            a.W2 = nullptr;
+            int rc = launch_gemm_nt(a, st);
+            if (rc) return rc;
+            aew_gemm_nt_t b2 = {};
+            b2.dtype = AEW_BF16; b2.impl = g.impl == 2 ? 0 : g.impl;
+            b2.M = g.M; b2.N = g.N2; b2.N_pad = g.N2_pad; b2.batch = g.batch;
+            b2.n_segs = 1; b2.K_total = g.N_pad / 2;
+            b2.seg[0].ptr = g.out0.ptr; b2.seg[0].batch_stride = g.out0.batch_stride; b2.seg[0].row_pitch = g.out0.row_pitch;
+            b2.seg[0].row_step = g.out0.row_step; b2.seg[0].row_off = g.out0.row_off;
+            b2.seg[0].row_lo = g.out0.row_lo; b2.seg[0].row_hi = g.out0.row_hi; b2.seg[0].k_len = g.N_pad / 2;
+            b2.W = g.W2; b2.epi = AEW_EPI_STORE; b2.flags = g.aux0.ptr ? AEW_EF_ADD_AUX0 : 0;
+            b2.out0 = g.out3; b2.aux0 = g.aux0;
+            return launch_gemm_nt(b2, st);
+        }
+    }
+    if (g.impl == 2 && g.dtype == AEW_BF16) {
+        if (g_fn_enable_flag() && fn_supported(g)) {
+            const int es2 = 2;
+            int ks = 0;
+            for (int s = 0; s < g.n_segs; ++s) {
+                const int rc = check_seg(g.seg[s], es2, 64);
+                if (rc) return rc;
+                ks += g.seg[s].k_len;
+            }
+            if (ks != g.K_total || g.N > g.N_pad || (g.N & 7)) return AEW_E_ARG;
+            return launch_fn(g, st);
+        }
+        aew_gemm_nt_t a = g;                                  // not covered: the tiled kernel (same results)
+        a.impl = 0;
+        return launch_gemm_nt(a, st);
+    }
     const int es = g.dtype == AEW_BF16 ? 2 : 4;
     const int kt = g.dtype == AEW_BF16 ? 64 : NF_BK;        // ABI contract: bf16 segments are 64-aligned
     const int ntile = g.dtype == AEW_BF16 ? NT_BN : NF_BN;

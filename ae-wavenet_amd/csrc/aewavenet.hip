@@ -2,6 +2,7 @@
 // declared in include/aewavenet.h.   Build: see __graft_entry__.build()
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC aewavenet.hip -o libaewavenet_hip.so
 #include "aew_gemm.hip"
+#include "aew_fn.hip"
 #include "aew_ops.hip"
 #include "aew_sampler.hip"
 

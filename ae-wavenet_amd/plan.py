@@ -203,7 +203,8 @@ def make_nt(dtype: int, M: int, N: int, N_pad: int, batch: int, segs: Sequence[L
             epi: int = L.EPI_STORE, flags: int = 0, out0: Optional[L.View] = None,
             out1: Optional[L.View] = None, out2: Optional[L.View] = None,
             aux0: Optional[L.View] = None, aux1: Optional[L.View] = None, bias_ptr: int = 0,
-            bias_bs: int = 0, n_split: int = 0, counter_ptr: int = 0, impl: int = 0) -> L.GemmNT:
+            bias_bs: int = 0, n_split: int = 0, counter_ptr: int = 0, impl: int = 0,
+            W2_ptr: int = 0, N2: int = 0, N2_pad: int = 0, out3: Optional[L.View] = None) -> L.GemmNT:
     g = L.GemmNT()
     g.dtype, g.impl, g.M, g.N, g.N_pad, g.batch = dtype, impl, M, N, N_pad, batch
     if not 1 <= len(segs) <= L.MAX_SEGS:
@@ -219,6 +220,9 @@ def make_nt(dtype: int, M: int, N: int, N_pad: int, batch: int, segs: Sequence[L
             setattr(g, nm, v)
     g.bias, g.bias_bs, g.n_split = bias_ptr or None, bias_bs, n_split
     g.counter = counter_ptr or None
+    if W2_ptr:                       # fused gated layer: residual 1x1 over the z tile (aewavenet.h)
+        g.W2, g.N2, g.N2_pad = W2_ptr, N2, N2_pad
+        g.out3 = out3
     return g
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 11
+#define AEW_ABI_VERSION 12
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -103,7 +103,9 @@ typedef struct {
 
 typedef struct {
     int32_t dtype;               /* operand type AEW_BF16 | AEW_F32 */
-    int32_t impl;                /* 0 = MFMA kernel, 1 = scalar check kernel (same math)      */
+    int32_t impl;                /* 0 = tiled MFMA kernel, 1 = scalar check kernel, 2 = full-N MFMA kernel with
+                                    loader / consumer waves (aew_fn.hip; falls back to 0 when the shape is not
+                                    covered).  Same results bit for bit                            */
     int32_t M;                   /* output rows per batch                                     */
     int32_t N;                   /* output columns to store: multiple of 8 (bf16) / 4 (f32)   */
     int32_t N_pad;               /* rows of W (multiple of 128 for bf16, 64 for f32)          */
@@ -121,6 +123,14 @@ typedef struct {
     int32_t n_split;             /* RES_SKIP column boundary (multiple of the N tile)         */
     int32_t reserved;
     unsigned long long* counter; /* AEW_EF_COUNT_ZERO target                                  */
+    /* Fused gated layer (AEW_EPI_GATED only; wavenet.py:100-109).  With W2 != NULL the op also computes the
+     * residual 1x1 of the layer from the z tile it has just produced:
+     *     out3[b][m][n2] = sum_k z[b][m][k] * W2[n2][k] + aux0[b][m][n2]        n2 < N2, k < N_pad / 2
+     * (z = the bf16 values written to out0, so the result equals GATED followed by a STORE | ADD_AUX0 GEMM over
+     * out0; impl 0 / 1 execute it exactly that way, impl 2 keeps the z tile in LDS).                        */
+    const void* W2;              /* packed [N2_pad][N_pad / 2] bf16                                          */
+    int32_t N2, N2_pad;          /* N2 multiple of 8, N2_pad multiple of 128                                 */
+    aew_view_t out3;
 } aew_gemm_nt_t;
 
 typedef struct {
@@ -435,6 +445,9 @@ int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
 int aew_set_nt_wave_rows(int rows);
 /* Shapes 128 / 256 only: 1 (default) the register-double-buffered loop, 2 K tiles of 64, 0 the plain loop. */
 int aew_set_nt_pipe(int on);
+/* impl = 2 descriptors (full-N kernels, aew_fn.hip): 1 (default) use them where the shape is covered, 0 run every
+ * impl = 2 descriptor on the tiled kernels instead (A/B and bisecting aid; same results). */
+int aew_set_fn(int on);
 /* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
 int aew_set_nt_small_tiles(int n);
 /* default NT shape only: 192 x 128 tiles (8 waves of 48x64) instead of 256 x 128 — 0 never, 1 (default) where the

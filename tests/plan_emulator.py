@@ -94,6 +94,18 @@ class Emu:
                 self.vstore(g.out0, b, m, 0, a * s)
                 self.vstore(g.out1, b, m, 0, s * (1 - a * a))
                 self.vstore(g.out2, b, m, 0, a * s * (1 - s))
+                if g.W2:
+                    # fused gated layer (aewavenet.h): residual 1x1 over the z just STORED (its storage rounding
+                    # included: the kernel's LDS z tile holds the same bf16 values) + the aux0 addend -> out3
+                    K2 = g.N_pad // 2
+                    W2t, w2off = self.flat(g.W2)
+                    W2 = W2t[w2off:w2off + g.N2_pad * K2].float().view(g.N2_pad, K2)
+                    zs = torch.zeros(g.M, K2)
+                    zs[:, :g.N] = self.vload(g.out0, b, m, 0, g.N)
+                    res = zs @ W2.t()[:, :g.N2]
+                    if g.aux0.ptr:
+                        res = res + self.vload(g.aux0, b, m, 0, g.N2)
+                    self.vstore(g.out3, b, m, 0, res)
             elif g.epi == L.EPI_RES_SKIP:
                 ns = g.n_split
                 if ns > 0:

@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _tiny(bn="vqvae-ema", **kw):
+def _tiny(bn="vqvae-ema", every_step=True, **kw):
     from ae_wavenet_amd import autoencoder_model as ae
     args = dict(n_res=64, n_dil=32, n_skp=32, n_post=32, n_lc_out=16, enc_n_out=64, bn_n_out=72 if bn != "vqvae-ema" else 8,
                 bn_vq_n_embed=64, n_win_batch=96, n_blocks=2, n_block_layers=3, n_global_embed=4, n_speakers=5)
     args.update(kw)
     hps = config.make_hps(bn, **args)
     torch.manual_seed(11)
-    m = ae.AutoEncoder(hps, n_mel=39).to(DEV)
+    m = ae.AutoEncoder(hps, n_mel=39, update_codebook_every_step=every_step).to(DEV)
     return hps, m
 
 
@@ -68,7 +68,7 @@ def test_unclipped_jitter_is_clamped():
 @pytest.mark.parametrize("bn", ["vqvae-ema", "vae", "ae", "vqvae"])
 def test_upstream_gradient_reaches_every_grad(bn):
     d = 16 if bn == "vae" else 8                               # != embed_len (8): eps layout is unambiguous
-    hps, m = _tiny(bn, bn_n_out=d)
+    hps, m = _tiny(bn, every_step=False, bn_n_out=d)          # frozen codebook: the three runs see the same forward
     if bn == "vae":
         m.objective.update_anneal_weight(0.3)
     batch = _batch(m, 2)
@@ -123,10 +123,11 @@ def test_adam_state_survives_engine_rebuilds():
     same(opt.state_dict()["state"])
     # a different training batch size
     b3 = _batch(m, 3, seed=2)
-    _, _, loss = m.run(*b3)
+    m._ensure_engine(3)
     same(opt.state_dict()["state"])
     for k, v in m.state_dict().items():
         assert torch.equal(v.detach().cpu(), w_ref[k]), k       # weights and codebook buffers travelled too
+    _, _, loss = m.run(*b3)
     loss.backward()
     opt.step()
     st = opt.state_dict()["state"]
@@ -153,7 +154,7 @@ def test_encode_and_conditioning_leave_the_histogram_alone():
     def source():
         while True:
             yield batch
-    m.init_codebook(source(), 3 * eng.Q // 2)
+    m.init_codebook(source(), 5 * eng.Q)                        # 80 samples >= K = 64 codes
     torch.cuda.synchronize()
     assert torch.equal(m._engine.ind_hist, hist)
     assert m.init_codebook_iters >= 1
