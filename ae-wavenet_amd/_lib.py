@@ -219,7 +219,8 @@ class Sampler(C.Structure):
                 ("wav_out", vp), ("seed", C.c_uint64), ("nap_eighths", i32), ("pad", i32), ("prof", vp)]
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaewavenet_hip.so")
+LIB_PATH = os.environ.get("AEW_LIB_PATH") or \
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaewavenet_hip.so")   # (AEW_LIB_PATH: tools-only builds)
 _lib = None
 
 

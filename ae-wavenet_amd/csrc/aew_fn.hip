@@ -24,6 +24,10 @@
 // Results are bit-identical to k_gemm_nt_bf16 (same MFMA, K ascending, same epilogue arithmetic).
 #include "aew_common.h"
 
+#ifndef AEW_FN_ABLATE
+#define AEW_FN_ABLATE 0           /* 1: tools/fused_ablate.py, tools/gemm_sweep.py switches in aew_gemm_nt_t.reserved */
+#endif
+#define FN_ABL(g, bit) (AEW_FN_ABLATE && ((g).reserved & (bit)))
 #define FN_NCONS 8
 #define FN_NLOAD 4
 #define FN_THREADS ((FN_NCONS + FN_NLOAD) * 64)
@@ -91,7 +95,9 @@ __device__ __forceinline__ void fn_dma_v(const void* gsrc, uint32_t lds_off) {
 }
 // ... and scalar base + per-lane 32-bit offset (W pieces: no per-piece vector address arithmetic at all)
 __device__ __forceinline__ void fn_dma_s(uint64_t sbase, uint32_t voff, uint32_t lds_off) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(lds_off) : "memory", "m0");
+    // s_nop 4: the scalar base may come straight from a v_readlane (SGPR spill reload = VALU write of an SGPR), which
+    // needs 5 wait states before a VMEM instruction reads it as its address; hipcc pads nothing inside asm
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(lds_off) : "memory", "m0");
 }
 
 __device__ __forceinline__ void fn_barrier() {
@@ -134,6 +140,11 @@ struct FnLoader {
     // issue K tile `kt` of `tile` into the stage at byte offset `stage`
     template <int EPI>
     __device__ __forceinline__ void issue(const aew_gemm_nt_t& g, uint32_t stage) {
+        if (FN_ABL(g, 2)) {                                    // (ablation: no operand traffic)
+            ++kt; kin += 64;
+            if (kin >= g.seg[seg].k_len && seg + 1 < g.n_segs) { ++seg; kin = 0; }
+            return;
+        }
 #pragma unroll
         for (int jj = 0; jj < Cfg::XPL; ++jj) {
             const int q = ld + FN_NLOAD * jj;
@@ -202,6 +213,27 @@ __device__ __forceinline__ void fn_sched_groups() {
 
 template <int NTW, int MT>
 __device__ __forceinline__ void fn_compute(const char* xs, const char* ws, int xo, f32x4_t (&acc)[NTW][MT]) {
+    if constexpr (NTW * MT >= 24) {
+        // Full accumulator budget (24 tiles = 96 VGPRs of the 168): K step by K step in source order.  Any forced
+        // read-ahead here (fragments of both K steps live, sched_group_barrier pipelining) makes the register
+        // allocator spill INSIDE the loop (62 scratch accesses per K tile, 3x slower tiles); the compiler's own
+        // order keeps one X fragment in flight and the partner wave on the SIMD covers the LDS latency.
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int o = xo ^ (ks << 6);
+            bf16x8_t wf[NTW], xf[MT];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(ws + o + i * 2048);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(xs + o + j * 2048);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        return;
+    }
     bf16x8_t wf[2][NTW], xf[2][MT];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -220,9 +252,9 @@ __device__ __forceinline__ void fn_compute(const char* xs, const char* ws, int x
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
     // Shape of the step (one basic block): the fragment reads run AHEAD of the MFMA groups that consume them - W
     // fragments and two X fragments first, then after every group of NTW MFMAs (one X fragment against all W
-    // fragments) the next read(s), so that a wave never sits on an lgkmcnt(0) between groups.  Without this the
-    // compiler, held to 168 VGPRs, emits read -> wait -> 4 MFMAs serially with ONE X fragment register.
-    constexpr int total_reads = 2 * (NTW + MT), pre = (NTW + 2 < total_reads) ? NTW + 2 : total_reads;
+    // fragments) the next read(s), so that a wave never sits on an lgkmcnt(0) between groups.
+    constexpr int total_reads = 2 * (NTW + MT);
+    constexpr int pre = NTW + 2 < total_reads ? NTW + 2 : total_reads;
     __builtin_amdgcn_sched_group_barrier(0x100, pre, 0);
     fn_sched_groups<NTW, MT, 0, total_reads - pre>();
 }
@@ -312,7 +344,7 @@ __device__ __forceinline__ void fn_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
         char* o1 = (EPI == AEW_EPI_STORE && !SECOND) ? epi_view_row(c1, j) : nullptr;
         const char* a0 = epi_view_row(ca0, j);
         const char* a1 = SECOND ? nullptr : epi_view_row(ca1, j);
-        if (!row_ok) continue;
+        if (!row_ok || FN_ABL(g, 16)) continue;
 #pragma unroll
         for (int u = 0; u < (NTW + 1) / 2; ++u) {
             if (2 * u + 1 < NTW) {                             // a tile pair: 8 consecutive channels
@@ -370,28 +402,43 @@ __device__ __forceinline__ void fn_epilogue_gated(const aew_gemm_nt_t& g, f32x4_
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const bool row_ok = mbase + j * 16 < g.M;
-        float z[W], pf[W], pg[W];
+        // two channels at a time, packed to bf16 at once: 3 * W / 2 live result registers instead of 3 * W floats
+        // (at 168 VGPRs with 96 accumulators the wide form spilled into the K loop)
+        uint32_t zp[W / 2], fp[W / 2], gp[W / 2];
 #pragma unroll
-        for (int e = 0; e < W; ++e) {
-            const float f = acc[e >> 2][j][e & 3], q = acc[NTW / 2 + (e >> 2)][j][e & 3];
-            const float a = tanh_f(f + fb[e]);
-            const float s = sigmoid_f(q + gb[e]);
-            z[e] = a * s;
-            pf[e] = s * (1.0f - a * a);
-            pg[e] = z[e] * (1.0f - s);
+        for (int h = 0; h < W / 2; ++h) {
+            float zz[2], ff[2], gg[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int e = 2 * h + r;
+                const float f = acc[e >> 2][j][e & 3], q = acc[NTW / 2 + (e >> 2)][j][e & 3];
+                const float a = tanh_f(f + fb[e]);
+                const float s = sigmoid_f(q + gb[e]);
+                zz[r] = a * s;
+                ff[r] = s * (1.0f - a * a);
+                gg[r] = zz[r] * (1.0f - s);
+            }
+            zp[h] = pack2_bf16(zz[0], zz[1]); fp[h] = pack2_bf16(ff[0], ff[1]); gp[h] = pack2_bf16(gg[0], gg[1]);
         }
         if (ZLDS) {
-            if (W == 8)
-                *reinterpret_cast<uint4*>(zrow + j * 2048) =
-                    ch_ok ? make_uint4(pack2_bf16(z[0], z[1]), pack2_bf16(z[2], z[3]), pack2_bf16(z[W - 4], z[W - 3]), pack2_bf16(z[W - 2], z[W - 1]))
-                          : make_uint4(0, 0, 0, 0);
+            if constexpr (W == 8)
+                *reinterpret_cast<uint4*>(zrow + j * 2048) = ch_ok ? make_uint4(zp[0], zp[1], zp[W / 2 - 2], zp[W / 2 - 1]) : make_uint4(0, 0, 0, 0);
             else
-                *reinterpret_cast<uint2*>(zrow + j * 2048) = ch_ok ? make_uint2(pack2_bf16(z[0], z[1]), pack2_bf16(z[2], z[3])) : make_uint2(0, 0);
+                *reinterpret_cast<uint2*>(zrow + j * 2048) = ch_ok ? make_uint2(zp[0], zp[1]) : make_uint2(0, 0);
         }
-        if (row_ok && ch_ok) {
-            row_store<W>(epi_view_row(c0, j), AEW_BF16, ch, z);
-            row_store<W>(epi_view_row(c1, j), AEW_BF16, ch, pf);
-            row_store<W>(epi_view_row(c2, j), AEW_BF16, ch, pg);
+        if (row_ok && ch_ok && !FN_ABL(g, 16)) {               // (ablation: math but no global stores)
+            char* o0 = epi_view_row(c0, j);
+            char* o1 = epi_view_row(c1, j);
+            char* o2 = epi_view_row(c2, j);
+            if constexpr (W == 8) {
+                if (o0) *reinterpret_cast<uint4*>(o0 + ch * 2) = make_uint4(zp[0], zp[1], zp[W / 2 - 2], zp[W / 2 - 1]);
+                if (o1) *reinterpret_cast<uint4*>(o1 + ch * 2) = make_uint4(fp[0], fp[1], fp[W / 2 - 2], fp[W / 2 - 1]);
+                if (o2) *reinterpret_cast<uint4*>(o2 + ch * 2) = make_uint4(gp[0], gp[1], gp[W / 2 - 2], gp[W / 2 - 1]);
+            } else {
+                if (o0) *reinterpret_cast<uint2*>(o0 + ch * 2) = make_uint2(zp[0], zp[1]);
+                if (o1) *reinterpret_cast<uint2*>(o1 + ch * 2) = make_uint2(fp[0], fp[1]);
+                if (o2) *reinterpret_cast<uint2*>(o2 + ch * 2) = make_uint2(gp[0], gp[1]);
+            }
         }
     }
 }
@@ -433,16 +480,18 @@ __device__ __forceinline__ void fn_consumer_tile(const aew_gemm_nt_t& g, char* s
     for (int k = 0; k < nkt; ++k) {
         fn_barrier();                                          // A_k: tile k landed; my reads of tile k-1 are consumed
         const char* st = smem + ((ktg + k) & 1) * Cfg::STAGE;
-        fn_compute<NTW, MT>(st + Cfg::XOFF, st + Cfg::WOFF + wn * NTW * 2048, xo, acc);
+        if (!FN_ABL(g, 1))                                     // (ablation: barriers only)
+            fn_compute<NTW, MT>(st + Cfg::XOFF, st + Cfg::WOFF + wn * NTW * 2048, xo, acc);
     }
     ktg += nkt;
     if constexpr (NTW2 == 0) {
+        if (FN_ABL(g, 4)) return;                              // (ablation: no epilogue)
         if constexpr (EPI == AEW_EPI_GATED) fn_epilogue_gated<NTW, MT, false>(g, acc, t, wn, lane, nullptr, 0);
         else fn_epilogue<NTW, MT, EPI, false>(g, acc, t, wn, lane);
     } else {
         typedef FnFuse<NTW, NTW2> F;
         fn_barrier();                                          // G: every wave is done with the last operand stage
-        fn_epilogue_gated<NTW, MT, true>(g, acc, t, wn, lane, smem + F::ZOFF, F::ZKT);
+        if (!FN_ABL(g, 4)) fn_epilogue_gated<NTW, MT, true>(g, acc, t, wn, lane, smem + F::ZOFF, F::ZKT);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my z rows are in LDS
         fn_barrier();                                          // Z: z image complete, W2 K tiles 0 (and 1) landed
         f32x4_t acc2[NTW2][MT];
@@ -453,11 +502,11 @@ __device__ __forceinline__ void fn_consumer_tile(const aew_gemm_nt_t& g, char* s
 #pragma unroll 1
         for (int u = 0; u < F::K2T; ++u) {
             const char* ws = smem + ((u & 1) ? F::WB : F::WA) + wn * NTW2 * 2048;
-            fn_compute<NTW2, MT>(smem + F::ZOFF + u * F::ZKT, ws, xo, acc2);
+            if (!FN_ABL(g, 8)) fn_compute<NTW2, MT>(smem + F::ZOFF + u * F::ZKT, ws, xo, acc2);
             if (u + 1 < F::K2T) fn_barrier();                  // H: W2 stage u & 1 is free, K tile u + 1 landed
         }
         fn_barrier();                                          // F: LDS is free for the next tile's operands
-        fn_epilogue<NTW2, MT, AEW_EPI_STORE, true>(g, acc2, t, wn, lane);
+        if (!FN_ABL(g, 4)) fn_epilogue<NTW2, MT, AEW_EPI_STORE, true>(g, acc2, t, wn, lane);
     }
 }
 

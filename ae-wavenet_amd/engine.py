@@ -187,6 +187,15 @@ class DecoderPlan:
     n_side_lanes = 4          # weight gradients / column sums rotate over this many side lanes (1..4): they are
                               # mutually independent, so they need no ordering among themselves.  Measured
                               # ms/step: 1 lane 8.44, 2: 8.54, 3: 8.59, 4: 8.19 (one lane per op kind: 8.93)
+    # Ops that run on the full-N loader / consumer kernels (csrc/aew_fn.hip, impl 2; bit-identical results):
+    #   "layer"  the gated pair of a layer as ONE fused op (gated GEMM -> z tile in LDS -> residual 1x1 + add)
+    #   "G1"     gated GEMM alone on the full-N kernel (when "layer" is off or for the last layer)
+    #   "dx" "dz" "skip" "dcond" "post"   the other large NT GEMMs of the stack
+    # Default: the two long-K multi-segment GEMMs (K = 20 x 256: skip sum, cond gradient), where the loader / consumer
+    # pipeline wins (0.170 vs 0.187 ms, 0.224 vs 0.248 ms).  The fused layer and the other ops are measured SLOWER than
+    # the tiled kernels on this workload (fused layer 100-121 us vs 77-104 us for the pair; profiles/r02_notes.md:
+    # with one block per CU nothing runs under the epilogue's 220 KB of stores per tile) and stay opt-in (AEW_FN_OPS).
+    fn_ops = frozenset(("skip", "dcond"))
     split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
                               # measured slower (8.86 vs 8.62 ms/step): half-batch launches lose more than the
                               # overlap of their tails returns
@@ -196,6 +205,9 @@ class DecoderPlan:
                  jitter: torch.Tensor, take_compat: bool, packer: Packer, impl: int = 0):
         self.ws, self.ps, self.hps, self.g, self.B, self.pre = ws, ps, hps, geom, B, pre
         self.impl = impl
+        import os as _os
+        if _os.environ.get("AEW_FN_OPS") is not None:          # A/B aid: comma list, "" = none
+            self.fn_ops = frozenset(v for v in _os.environ["AEW_FN_OPS"].split(",") if v)
         self.gmul_ptr = ws.bufs["loss.gmul"].data_ptr() if "loss.gmul" in ws.bufs else 0
         self.n_lc_in = n_lc_in
         self.lc_src, self.wav, self.voice, self.jitter = lc_src, wav, voice, jitter
@@ -267,6 +279,11 @@ class DecoderPlan:
             t = ws.alloc(p + "off_" + k, self.NL, torch.int64)
             t[:self.NL].copy_(torch.tensor(v, dtype=torch.int64))
             self.off_tbl[k] = t
+
+    def _impl(self, kind: str) -> int:
+        """impl of an NT op of the given kind: the full-N kernels (2) where selected, unless the engine was built on
+        the scalar check kernels (impl 1)."""
+        return 2 if (self.impl == 0 and kind in self.fn_ops) else self.impl
 
     def _wmat(self, name, rows, cols, dt=BF) -> Mat:
         return Mat.new(self.ws, self.pre + "wp." + name, 1, rows, cols, dt)
@@ -463,18 +480,27 @@ class DecoderPlan:
                 plan.lane = 1 if c == 1 else 0
                 segs = [x.seg(Rp, b0=b0), x.seg(Rp, row_off=lg.dil, b0=b0),
                         self.cond.seg(Cp, row_off=lg.cond_lead, b0=b0)]
+                sfx = f".c{c}" if n_chains > 1 else ""
+                gkw = dict(epi=L.EPI_GATED, out0=self.z[l].view(b0=b0), out1=self.pf[l].view(b0=b0),
+                           out2=self.pg[l].view(b0=b0),
+                           bias_ptr=self.bias_bl.data_ptr() + 4 * (l * 2 * Dp + b0 * NL * 2 * Dp), bias_bs=NL * 2 * Dp)
+                if not last and self._impl("layer") == 2:
+                    # the gated pair as ONE op (wavenet.py:100-109): z never leaves the CU between the two GEMMs
+                    plan.add(L.OP_GEMM_NT, make_nt(
+                        BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, impl=2, W2_ptr=self.Wrs[l].ptr, N2=Rp, N2_pad=Rp,
+                        out3=self.x[l + 1].view(b0=b0), aux0=x.view(row_off=lg.dil, b0=b0), **gkw),
+                        f"G1.{l}" + sfx, TAG_G1, join=(l == 0 and c == 0))
+                    continue
                 plan.add(L.OP_GEMM_NT, make_nt(
-                    BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, epi=L.EPI_GATED,
-                    out0=self.z[l].view(b0=b0), out1=self.pf[l].view(b0=b0), out2=self.pg[l].view(b0=b0),
-                    bias_ptr=self.bias_bl.data_ptr() + 4 * (l * 2 * Dp + b0 * NL * 2 * Dp), bias_bs=NL * 2 * Dp,
-                    impl=impl), f"G1.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_G1,
+                    BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, impl=self._impl("G1"), **gkw),
+                    f"G1.{l}" + sfx, TAG_G1,
                     join=(l == 0 and c == 0))                 # x[0] and the gated biases come from the side lane
                 if not last:
                     # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
                     plan.add(L.OP_GEMM_NT, make_nt(
                         BF, P_l, Rp, Rp, nb, [self.z[l].seg(Dp, b0=b0)], self.Wrs[l].ptr, flags=L.EF_ADD_AUX0,
                         out0=self.x[l + 1].view(b0=b0), aux0=x.view(row_off=lg.dil, b0=b0), impl=impl),
-                        f"G2.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_G2)
+                        f"G2.{l}" + sfx, TAG_G2)
             if self.n_lo < NL and l == self.n_lo - 1:
                 # early half of the skip sum (layers 0 .. n_lo-1): all its inputs exist now
                 plan.lane = 0
@@ -493,15 +519,15 @@ class DecoderPlan:
             segs = [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(lo, NL)]
             plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp_hi.ptr,
                                            flags=L.EF_ADD_AUX0 | L.EF_RELU_POST, out0=self.h0.view(),
-                                           aux0=self.skp_part.view(), impl=impl), "skip_all", TAG_G2, join=True)
+                                           aux0=self.skp_part.view(), impl=self._impl("skip")), "skip_all", TAG_G2, join=True)
         else:
             segs = [self.z[l].seg(Dp, row_off=lg.skip_lead) for l, lg in enumerate(g.layers)]
             plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Sp, Sp, B, segs, self.Wskp_lo.ptr, flags=L.EF_RELU,
-                                           out0=self.h0.view(), impl=impl), "skip_all", TAG_G2, join=True)
+                                           out0=self.h0.view(), impl=self._impl("skip")), "skip_all", TAG_G2, join=True)
         # 7. post network (wavenet.py:359-360)
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Pp, Pp, B, [self.h0.seg(Sp)], self.Wp1.ptr,
                                        flags=L.EF_BIAS | L.EF_RELU, out0=self.h1.view(),
-                                       bias_ptr=self.bias_vec["post1"], impl=impl), "post1", TAG_POST)
+                                       bias_ptr=self.bias_vec["post1"], impl=self._impl("post")), "post1", TAG_POST)
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Qp, Qp, B, [self.h1.seg(Pp)], self.Wp2.ptr,
                                        flags=L.EF_BIAS, out0=self.logits.view(),
                                        bias_ptr=self.bias_vec["post2"], impl=impl), "post2", TAG_POST)
@@ -603,7 +629,7 @@ class DecoderPlan:
             segs.append(self.dskp.seg(Sp, row_off=-lg.skip_lead))
             plan.add(L.OP_GEMM_NT, make_nt(BF, P_l, Dp, Dp, B, segs, self.WrsT[l].ptr, epi=L.EPI_DFG,
                                            aux0=self.pf[l].view(), aux1=self.pg[l].view(),
-                                           out0=self.dfg[l].view(), impl=impl), f"dz.{l}", TAG_DZ)
+                                           out0=self.dfg[l].view(), impl=self._impl("dz")), f"dz.{l}", TAG_DZ)
             if self.n_lo < NL and l == self.n_lo:
                 hsegs = [self.dfg[k].seg(2 * Dp, row_off=-g.layers[k].cond_lead) for k in range(self.n_lo, NL)]
                 with plan.side(self.EARLY_LANE):               # upper half of the cond gradient: inputs complete
@@ -639,7 +665,7 @@ class DecoderPlan:
                 BF, lg.in_len, Rp, Rp, B, segs, self.WfgT[l].ptr,
                 flags=0 if last else L.EF_ADD_AUX0,
                 out0=dx.view(hi=lg.in_len),
-                aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=impl), f"dx.{l}", TAG_DX)
+                aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=self._impl("dx")), f"dx.{l}", TAG_DX)
             dx_next = dx
             if early_tbl is not None and l == NL // 2:
                 with plan.side(1):                                 # after the wgrads issued so far, on any lane
@@ -672,7 +698,7 @@ class DecoderPlan:
         else:
             segs = [self.dfg[l].seg(2 * Dp, row_off=-lg.cond_lead) for l, lg in enumerate(g.layers)]
             plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT_lo.ptr, out0=self.dcond.view(),
-                                           impl=impl), "dcond", TAG_DCOND)
+                                           impl=self._impl("dcond")), "dcond", TAG_DCOND)
         # ---- speaker / gated-bias gradients
         sbw = L.SpkBwd()
         self._fill_spk(sbw)

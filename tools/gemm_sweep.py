@@ -15,9 +15,13 @@ lib = L.load()
 dev = "cuda:0"
 VARIANTS = [("thin 256x128 (default)", 64, 1), ("fat pipe 256x128", 128, 1), ("wide pipe 256x256 K32", 256, 1),
             ("p64 256x256 K64", 256, 2), ("p64 128x128 K64", 0, 1), ("p64 256x128 K64", 1, 1)]
-if hasattr(lib, "aew_set_nt_v2"):
-    VARIANTS.append(("v2", -1, 0))
-SHAPES = [("square 8192x4096x4096", 1, 8192, 4096, 4096), ("square 4096^3", 1, 4096, 4096, 4096),
+VARIANTS.append(("full-N loader/consumer (impl 2)", -1, 0))
+VARIANTS.append(("  impl 2, consumers idle (DMA only)", -2, 1))
+VARIANTS.append(("  impl 2, loaders idle (LDS+MFMA only)", -2, 2))
+VARIANTS.append(("  impl 2, barriers only", -2, 3))
+SHAPES = [("square 8192x4096x4096", 1, 8192, 4096, 4096),
+          ("long-K 8x8192 N512 K4096", 8, 8192, 512, 4096), ("long-K 8x8192 N384 K4096", 8, 8192, 384, 4096),
+          ("long-K 8x8192 N256 K4096", 8, 8192, 256, 4096), ("long-K 8x8192 N128 K4096", 8, 8192, 128, 4096),
           ("G1-like 8x6000 N512 K896", 8, 6000, 512, 896), ("dx-like 8x6200 N384 K1024", 8, 6200, 384, 1024),
           ("dz-like 8x6000 N256 K640", 8, 6000, 256, 640), ("G2-like 8x6000 N384 K256", 8, 6000, 384, 256)]
 
@@ -36,15 +40,15 @@ def main():
         ref = None
         for vname, rows, pipe in VARIANTS:
             if rows >= 0:
-                if hasattr(lib, "aew_set_nt_v2"):
-                    lib.aew_set_nt_v2(0)
                 lib.aew_set_nt_wave_rows(rows)
                 lib.aew_set_nt_pipe(pipe)
-            else:
-                lib.aew_set_nt_v2(1)
+            elif Np > 512:
+                continue
             if rows == 256 and Np % 256:
                 continue
-            g = make_nt(L.BF16, M, N, Np, B, [x.seg(K)], W.ptr, out0=y.view())
+            g = make_nt(L.BF16, M, N, Np, B, [x.seg(K)], W.ptr, out0=y.view(), impl=2 if rows < 0 else 0)
+            if rows == -2:
+                g.reserved = pipe
             p = Plan("sweep")
             for _ in range(10):
                 p.add(L.OP_GEMM_NT, g, "g", 1)
@@ -54,6 +58,8 @@ def main():
             out = y.tensor().float().clone()
             if ref is None:
                 ref = out
+            if rows == -2:
+                out = ref
             err = float((out - ref).abs().max())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             best = 1e9
