@@ -18,6 +18,7 @@ EPI_STORE, EPI_GATED, EPI_RES_SKIP, EPI_DFG = 0, 1, 2, 3
 EF_BIAS, EF_RELU, EF_OUT1_PRE, EF_ADD_AUX0 = 1 << 0, 1 << 1, 1 << 2, 1 << 3
 EF_MUL_POS1, EF_OUT1_POS1, EF_ACCUM, EF_OUT2_RELU, EF_COUNT_ZERO = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 EF_RELU_POST = 1 << 9
+EF_OUT2_COPY = 1 << 10
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,

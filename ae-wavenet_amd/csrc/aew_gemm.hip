@@ -84,6 +84,7 @@ __device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiUni& 
         for (int r = 0; r < W; ++r) zero_count += (n + r < U.N && v[r] == 0.f) ? 1u : 0u;
     }
     row_store<W>(R.o0, U.dt_o0, n, v);
+    if (fl & AEW_EF_OUT2_COPY) row_store<W>(R.o2, U.dt_o2, n, v);
 }
 
 // filt / gate values of the same W channels ch..ch+W-1; np_f = packed column of filt channel ch
@@ -1718,6 +1719,8 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     if (g.dtype == AEW_BF16 && g.impl != 1 && (g.epi == AEW_EPI_STORE || g.epi == AEW_EPI_DFG) &&
         ((g.aux0.ptr && g.aux0.dtype != AEW_BF16) || (g.aux1.ptr && g.aux1.dtype != AEW_BF16)))
         return AEW_E_UNSUP;                                  // the MFMA epilogues prefetch aux rows as bf16
+    if (g.dtype == AEW_BF16 && g.impl != 1 && g.epi == AEW_EPI_STORE && (g.flags & AEW_EF_OUT2_COPY))
+        return AEW_E_UNSUP;                                  // the copy output exists in the fp32 / check epilogues only
     if (g.impl == 1) {
         const int nq = (g.epi == AEW_EPI_GATED) ? g.N_pad / 8 : g.N_pad / 4;
         dim3 grid((nq + 63) / 64, g.M, g.batch);

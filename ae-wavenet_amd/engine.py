@@ -749,46 +749,60 @@ class DecoderPlan:
 # encoder + bottleneck (fp32 exact chain)
 # ------------------------------------------------------------------------------------------
 class EncoderPlan:
+    """Encoder (wave_encoder.py:34-103).  Forward: fp32, exact k-ascending chains (bit-exact code indices against
+    oracle/exact_chain.c).  Backward: bf16 operands, fp32 accumulation on the bf16 MFMA kernels - the forward's
+    exactness contract does not extend to gradients, and the fp32 kernels spent 0.48 ms per step here (9.5 % of the
+    step for 0.3 % of its FLOPs: one serial chain per output, every 16-row tile re-streaming the weight matrix).  The
+    forward's epilogue writes what the backward reads as bf16: the activations (wgrad operand), the pre-activation
+    (relu mask)."""
+
     def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, n_mel: int,
-                 mel_cl: Mat, packer: Packer, impl: int = 0):
+                 mel_cl: Mat, packer: Packer, impl: int = 0, in_tbl: Optional[CopyTableBuilder] = None,
+                 in_mel: Optional[torch.Tensor] = None):
         self.ws, self.ps, self.hps, self.g, self.B, self.impl = ws, ps, hps, geom, B, impl
         self.pk = packer
-        self.n_mel, self.Mp = n_mel, ru(n_mel, 64)
-        self.E, self.Ep = hps.enc_n_out, ru(hps.enc_n_out, 64)
+        self.n_mel, self.Mp, self.Mb = n_mel, ru(n_mel, 64), ru(n_mel, 128)
+        self.E, self.Ep, self.Eb = hps.enc_n_out, ru(hps.enc_n_out, 64), ru(hps.enc_n_out, 128)
         self.lens = geom.enc_lens                      # 10 entries
-        self.y: List[Mat] = [mel_cl]
-        self.r: List[Optional[Mat]] = [None]
+        E, Ep, Eb = self.E, self.Ep, self.Eb
+        self.y: List[Mat] = [mel_cl]                   # fp32 activations (forward chain)
+        self.yb: List[Mat] = [Mat.new(ws, "enc.yb0", B, self.lens[0], self.Mb, BF)]    # bf16 copies (wgrad operand)
+        if in_tbl is not None and in_mel is not None:
+            in_tbl.add(in_mel.data_ptr(), self.yb[0].ptr, [B, geom.mel_len, n_mel], [n_mel * geom.mel_len, 1, geom.mel_len],
+                       [self.yb[0].bs, self.Mb, 1], F3, BF)
+        self.r: List[Optional[Mat]] = [None]           # bf16 pre-activations (relu mask of the backward)
         for i in range(9):
-            self.y.append(Mat.new(ws, f"enc.y{i + 1}", B, self.lens[i + 1], self.Ep, F3))
-            self.r.append(Mat.new(ws, f"enc.r{i + 1}", B, self.lens[i + 1], self.Ep, F3))
-        self.dy = [Mat.new(ws, f"enc.dy{i}", B, self.lens[i], self.Mp if i == 0 else self.Ep, F3) for i in range(10)]
-        self.dpre = [None] + [Mat.new(ws, f"enc.dpre{i}", B, self.lens[i], self.Ep, F3) for i in range(1, 10)]
+            self.y.append(Mat.new(ws, f"enc.y{i + 1}", B, self.lens[i + 1], Ep, F3))
+            self.yb.append(Mat.new(ws, f"enc.yb{i + 1}", B, self.lens[i + 1], Eb, BF))
+            self.r.append(Mat.new(ws, f"enc.r{i + 1}", B, self.lens[i + 1], Eb, BF))
+        self.dy = [Mat.new(ws, f"enc.dy{i}", B, self.lens[i], self.Mb if i == 0 else Eb, BF) for i in range(10)]
+        self.dpre = [None] + [Mat.new(ws, f"enc.dpre{i}", B, self.lens[i], Eb, BF) for i in range(1, 10)]
         self.zero_cnt = ws.alloc("enc.zero_cnt", 9, torch.int64)
         self.W, self.WT, self.bias = [], [], []
-        cin, cinp = n_mel, self.Mp
-        E, Ep = self.E, self.Ep
+        cin, cinp, cinb = n_mel, self.Mp, self.Mb
         for i, (f, s) in enumerate(zip(G.ENCODER_FILTERS, G.ENCODER_STRIDES)):
             nm = f"encoder.net.{i}.conv."
             Wm = Mat.new(ws, f"enc.wp.{i}", 1, Ep, f * cinp, F3)
             packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], Wm, 0, [f * cinp, 1, cinp])
             self.W.append(Wm)
+            # dgrad layouts, bf16: [ci][k*Eb + co] <- W[co][ci][k]  (per output phase for strided layers)
             if s == 1:
-                WT = Mat.new(ws, f"enc.wpT.{i}", 1, cinp, f * Ep, F3)
-                packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], WT, 0, [1, f * Ep, Ep], late=True)
+                WT = Mat.new(ws, f"enc.wpT.{i}", 1, cinb, f * Eb, BF)
+                packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], WT, 0, [1, f * Eb, Eb], late=True)
                 self.WT.append([WT])
             else:
                 phs = []
                 for ph in range(s):
-                    WT = Mat.new(ws, f"enc.wpT.{i}.{ph}", 1, cinp, (f // s) * Ep, F3)
-                    # [ci][j*Ep + co] <- W[co][ci][ph + s*j]
-                    packer.rec(nm + "weight", ph, [cin * f, f, s], [E, cin, f // s], WT, 0, [1, (f // s) * Ep, Ep],
+                    WT = Mat.new(ws, f"enc.wpT.{i}.{ph}", 1, cinb, (f // s) * Eb, BF)
+                    # [ci][j*Eb + co] <- W[co][ci][ph + s*j]
+                    packer.rec(nm + "weight", ph, [cin * f, f, s], [E, cin, f // s], WT, 0, [1, (f // s) * Eb, Eb],
                                late=True)
                     phs.append(WT)
                 self.WT.append(phs)
             bt = ws.alloc(f"enc.wp.bias{i}", Ep, torch.float32)
             packer.pack_tbl.add(ps.ptr(nm + "bias"), bt.data_ptr(), [E], [1], [1], F3, F3)
             self.bias.append(bt)
-            cin, cinp = E, Ep
+            cin, cinp, cinb = E, Ep, Eb
         self.gbuf = {}
 
     def build_forward(self, plan: Plan):
@@ -798,37 +812,38 @@ class EncoderPlan:
         for i, (f, s, res) in enumerate(zip(G.ENCODER_FILTERS, G.ENCODER_STRIDES, G.ENCODER_RESIDUAL)):
             X, Y, Rm = self.y[i], self.y[i + 1], self.r[i + 1]
             segs = [X.seg(cinp, row_step=s, row_off=k) for k in range(f)]
-            flags = L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE | L.EF_COUNT_ZERO | (L.EF_ADD_AUX0 if res else 0)
+            flags = L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE | L.EF_COUNT_ZERO | L.EF_OUT2_COPY | (L.EF_ADD_AUX0 if res else 0)
             plan.add(L.OP_GEMM_NT, make_nt(
                 F3, Y.rows, self.E, Ep, B, segs, self.W[i].ptr, flags=flags, out0=Y.view(), out1=Rm.view(),
+                out2=self.yb[i + 1].view(),
                 aux0=X.view(row_off=(f - 1) // 2) if res else null_view(), bias_ptr=self.bias[i].data_ptr(),
                 counter_ptr=self.zero_cnt.data_ptr() + 8 * i, impl=impl), f"enc.{i}", TAG_ENC)
             cinp = Ep
 
     def build_backward(self, plan: Plan, need_input_grad: bool = True):
         """Expects dy[9] and dpre[9] already written (by the bottleneck backward)."""
-        B, impl, E, Ep, ps, pk = self.B, self.impl, self.E, self.Ep, self.ps, self.pk
+        B, impl, E, Eb, ps, pk = self.B, self.impl, self.E, self.Eb, self.ps, self.pk
         for i in range(8, -1, -1):
             f, s, res = G.ENCODER_FILTERS[i], G.ENCODER_STRIDES[i], G.ENCODER_RESIDUAL[i]
-            X = self.y[i]
-            cin, cinp = (self.n_mel, self.Mp) if i == 0 else (E, Ep)
+            X = self.yb[i]
+            cin, cinb = (self.n_mel, self.Mb) if i == 0 else (E, Eb)
             dpre, dyo = self.dpre[i + 1], self.dy[i + 1]
             Lo = dpre.rows
             cs = L.Colsum()
-            cs.x = dpre.seg(64)
-            cs.dtype, cs.M, cs.N, cs.batch = F3, Lo, E, B
+            cs.x = dpre.seg(128)
+            cs.dtype, cs.M, cs.N, cs.batch = BF, Lo, E, B
             cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 1
             with plan.side(1 + (2 * i) % DecoderPlan.n_side_lanes):
                 plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
-            t = make_tn(F3, Lo, B, E, Ep, dpre.seg(64), [X.seg(cinp, row_step=s, row_off=k) for k in range(f)],
+            t = make_tn(BF, Lo, B, E, Eb, dpre.seg(Eb), [X.seg(cinb, row_step=s, row_off=k) for k in range(f)],
                         impl=impl)
             slabs = L.tn_slabs(t)
-            gt = self.ws.alloc(f"enc.wg.{i}", slabs * Ep * t.K_total, torch.float32)
-            t.out, t.out_batch_stride = gt.data_ptr(), Ep * t.K_total
+            gt = self.ws.alloc(f"enc.wg.{i}", slabs * Eb * t.K_total, torch.float32)
+            t.out, t.out_batch_stride = gt.data_ptr(), Eb * t.K_total
             with plan.side(1 + (2 * i + 1) % DecoderPlan.n_side_lanes):
                 plan.add(L.OP_GEMM_TN, t, f"wgrad.enc{i}", TAG_ENC)
             pk.rec(f"encoder.net.{i}.conv.weight", 0, [cin * f, f, 1], [E, cin, f], None, 0,
-                   [f * cinp, 1, cinp], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=Ep * t.K_total)
+                   [f * cinb, 1, cinb], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=Eb * t.K_total)
             if i == 0 and not need_input_grad:
                 continue
             dX = self.dy[i]
@@ -838,11 +853,11 @@ class EncoderPlan:
                 Mq = (Li - ph + s - 1) // s
                 if Mq <= 0:
                     continue
-                segs = [dpre.seg(Ep, row_off=-j) for j in range(f // s)] if s > 1 else \
-                       [dpre.seg(Ep, row_off=-k) for k in range(f)]
+                segs = [dpre.seg(Eb, row_off=-j) for j in range(f // s)] if s > 1 else \
+                       [dpre.seg(Eb, row_off=-k) for k in range(f)]
                 flags = (L.EF_ADD_AUX0 if res else 0) | (L.EF_OUT1_POS1 if i > 0 else 0)
                 plan.add(L.OP_GEMM_NT, make_nt(
-                    F3, Mq, ru(cin, 4), cinp, B, segs, self.WT[i][ph].ptr, flags=flags,
+                    BF, Mq, ru(cin, 8), cinb, B, segs, self.WT[i][ph].ptr, flags=flags,
                     out0=dX.view(row_step=s, row_off=ph),
                     out1=self.dpre[i].view(row_step=s, row_off=ph) if i > 0 else null_view(),
                     aux0=dyo.view(row_step=s, row_off=ph - lw) if res else null_view(),

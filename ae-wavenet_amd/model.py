@@ -94,7 +94,8 @@ class TrainEngine:
         # ---- sub-plans
         self.enc: Optional[EncoderPlan] = None
         if with_enc:
-            self.enc = EncoderPlan(ws, ps, hps, g, B, self.n_mel, self.mel_cl, self.pk, impl)
+            self.enc = EncoderPlan(ws, ps, hps, g, B, self.n_mel, self.mel_cl, self.pk, impl, in_tbl=self.in_tbl,
+                                   in_mel=self.in_mel)
             self._alloc_bottleneck()
             lc_src = self.code
         else:

@@ -395,7 +395,7 @@ class HipModelBase(nn.Module):
             self._dp.allreduce_grads(eng)
         m = self.objective.metrics
         if self.kind == "autoencoder":
-            mg = eng.enc.dy[0].tensor()[:, :, :eng.n_mel]
+            mg = eng.enc.dy[0].tensor()[:, :, :eng.n_mel].float()
             m["mel_grad_sd"] = mg.std()
             m["bn_grad_sd"] = eng.dec.dlc_src.tensor()[:, :, :self.hps.bn_n_out].std()
         else:

@@ -98,6 +98,8 @@ typedef struct {
 #define AEW_EF_ACCUM       (1u << 6)  /* RES_SKIP: out1 += acc instead of =                    */
 #define AEW_EF_OUT2_RELU   (1u << 7)  /* RES_SKIP: out2 = relu(new out1) as bf16              */
 #define AEW_EF_RELU_POST   (1u << 9)  /* val = max(val,0) AFTER the aux0 add (sum of partial GEMMs, then relu) */
+#define AEW_EF_OUT2_COPY   (1u << 10) /* out2 = the value stored to out0, in out2's dtype (bf16 copy of an fp32
+                                         activation for the bf16 backward GEMMs)                */
 #define AEW_EF_COUNT_ZERO  (1u << 8)  /* atomically add #(out0==0) into counter (enc_az metric,
                                          wave_encoder.py:46)                                   */
 

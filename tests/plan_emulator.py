@@ -150,6 +150,8 @@ class Emu:
             t, off = self.flat(g.counter)
             t[off] += int((v[ok] == 0).sum())
         self.vstore(g.out0, b, m, 0, v)
+        if fl & L.EF_OUT2_COPY:
+            self.vstore(g.out2, b, m, 0, v)
 
     def op_2(self, t):   # GEMM_TN
         slabs = L.tn_slabs(t)

@@ -207,3 +207,41 @@ def test_interpreter_fused_equals_two_ops(case):
     Emu(ws_b).run(q)
     for n in case.outputs():
         assert torch.equal(ws_a.get(n).float(), ws_b.get(n).float()), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bn", ["vqvae-ema"])
+def test_engine_with_all_fn_ops_matches_tiled_engine(bn, monkeypatch):
+    """A whole training step with every covered op on the full-N kernels (fused gated layers included) against the
+    same step on the tiled kernels: forward bit-identical, gradients equal up to the atomically accumulated bias sums."""
+    from ae_wavenet_amd import config, engine as E, model as M
+    hps = config.make_hps(bn, n_res=192, n_dil=128, n_skp=128, n_post=128, n_lc_out=128, enc_n_out=64, bn_n_out=16,
+                          bn_vq_n_embed=64, n_win_batch=700, n_blocks=2, n_block_layers=4, n_global_embed=4, n_speakers=5)
+    res = {}
+    for tag, ops in (("tiled", frozenset()), ("fn", frozenset(("layer", "G1", "dx", "dz", "skip", "dcond", "post")))):
+        monkeypatch.setattr(E.DecoderPlan, "fn_ops", ops)
+        eng = M.TrainEngine(hps, B=3, device=DEV, n_mel=39, update_codebook_every_step=False)
+        labels = eng.fwd_b.labels
+        assert ("G2.0" in labels) == (tag == "tiled")             # fused: no separate residual GEMMs
+        gen = torch.Generator().manual_seed(9)
+        for k in eng.ps.names():
+            shp = eng.ps.shape[k]
+            t = torch.empty(shp)
+            torch.nn.init.xavier_uniform_(t, generator=gen) if len(shp) >= 2 else t.uniform_(-0.1, 0.1, generator=gen)
+            eng.ps.view(k).copy_(t)
+        eng.emb.copy_(torch.randn(64, 16, generator=gen))
+        eng.init_ema_from_emb()
+        g = eng.geom
+        wav = torch.randint(0, 256, (3, g.enc_in_len), generator=gen).float()
+        mel = torch.randn(3, 39, g.mel_len, generator=gen)
+        voice = torch.randint(0, 5, (3,), generator=gen)
+        jitter = torch.arange(g.embed_len).repeat(3, 1)
+        eng.set_inputs(wav.to(DEV), mel.to(DEV), voice.to(DEV), jitter.to(DEV))
+        loss = float(eng.forward())
+        eng.backward()
+        torch.cuda.synchronize()
+        res[tag] = (loss, eng.logits().clone(), eng.ps.grads[:eng.ps.numel].clone())
+    assert res["tiled"][0] == res["fn"][0]
+    assert torch.equal(res["tiled"][1], res["fn"][1])
+    ga, gb = res["tiled"][2], res["fn"][2]
+    assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-6 * float(ga.abs().max()))

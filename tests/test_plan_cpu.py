@@ -122,7 +122,7 @@ def test_autoencoder_vqema_plan(golden_dir, mode, jk, loss_mode, gtag, ltag):
     np.testing.assert_allclose(pred, z["pred"], rtol=tol(mode, 1e-4, 5e-2), atol=tol(mode, 2e-5, 3e-2))
     assert abs(float(eng.loss_buf[0]) / float(z[ltag]) - 1) < tol(mode, 1e-5, 5e-3)
     check_grads(eng, z, gtag, mode)
-    mg = eng.enc.dy[0].tensor()[:, :, :9].permute(0, 2, 1).numpy()
+    mg = eng.enc.dy[0].tensor()[:, :, :9].permute(0, 2, 1).float().numpy()
     close_dir(mode, mg, z[gtag + ".@mel"])
     bg = eng.dec.dlc_src.tensor()[:, :, :eng.d].permute(0, 2, 1).numpy()
     ref = z[gtag + ".@encoding_bn"]
