@@ -2,113 +2,36 @@
 """bench.py — 16 kHz audio samples / second / training step of the VQ-VAE-EMA WaveNet
 autoencoder (par/arch.vqvae-ema.json shape) on N MI355X, data-parallel.
 
-A step = forward + backward + gradient all-reduce (N>1) + fused Adam + EMA codebook update
-over one batch of 8 windows x 5000 output samples per GPU (BASELINE.json configs[1]; weak
-scaling), synthetic inputs resident in HBM before the timed region, random-init weights.
+A step (chassis.py:131-171) = a fresh batch from pinned host memory through the device prefetcher ->
+`model.run(wav, mel, voice, jitter)` -> `loss.backward()` -> `FusedAdam.step()` (gradient / EMA-statistic collectives
+inside for N > 1), on the drop-in module surface (autoencoder_model.AutoEncoder), over one batch of 8 windows x 5000
+output samples per GPU (BASELINE.json configs[1]; weak scaling), synthetic data, random-init weights.  The headline
+`value` is that step.  `engine_only` repeats the measurement below the module surface (TrainEngine forward / backward /
+adam on one resident batch: round 1's number).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          # spawns N ranks itself (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints one JSON line.  `roofline` is for the dominant kernel (the bf16 NT GEMM that
-carries forward + dgrad of the gated stack): algorithmic FLOPs / HIP-event time measured on
-the plan's stream.  `cpu_baseline` times the oracle (torch fp32 CPU port of the reference) on
-one window of the same workload.
+Rank 0 prints one JSON line.  `roofline` is for the dominant kernel (the bf16 NT GEMM that carries forward + dgrad of
+the gated stack): algorithmic FLOPs / HIP-event time measured on the plan's stream.  `cpu_baseline` times the oracle
+(torch fp32 CPU port of the reference) on a bounded sample of the same workload, Adam included, with and without the
+reference's diagnostic second backward.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
 
-
-def build_engine(args, device):
-    from ae_wavenet_amd import config, model as M
-    hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch)
-    eng = M.TrainEngine(hps, B=args.batch, device=device, n_mel=39)
-    gen = torch.Generator().manual_seed(2507)                     # hparams.py:92 random_seed
-    for k in eng.ps.names():
-        shp = eng.ps.shape[k]
-        t = torch.empty(shp)
-        if len(shp) >= 2:
-            torch.nn.init.xavier_uniform_(t, generator=gen)      # netmisc.py:10-14
-        else:
-            t.zero_()
-        eng.ps.view(k).copy_(t)
-    emb = torch.empty(hps.bn_vq_n_embed, hps.bn_n_out)
-    torch.nn.init.xavier_uniform_(emb, gain=10, generator=gen)    # vqema_bn.py:97
-    eng.emb.copy_(emb)
-    eng.init_ema_from_emb()
-    return hps, eng
-
-
-def synth_batch(eng, rank, device):
-    g = eng.geom
-    gen = torch.Generator().manual_seed(1000 + rank)
-    B = eng.B
-    wav = torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float()
-    mel = torch.randn(B, 39, g.mel_len, generator=gen)
-    voice = torch.randint(0, 40, (B,), generator=gen)
-    jitter = torch.arange(g.embed_len).repeat(B, 1)
-    return [t.to(device) for t in (wav, mel, voice, jitter)]
-
-
-def cpu_baseline(hps, eng, seconds_budget=40.0):
-    """Oracle (torch fp32 CPU restatement of the reference) forward+backward on ONE window of
-    the same workload (B=1, same n_win), all host cores."""
-    from oracle import ref_model as R
-    from ae_wavenet_amd import geometry
-    g = eng.geom
-    sd = {k: eng.ps.view(k).detach().cpu().clone().requires_grad_(True) for k in eng.ps.names()}
-    emb = eng.emb.detach().cpu().clone()
-    gen = torch.Generator().manual_seed(5)
-    wav = torch.randint(0, 256, (1, g.enc_in_len), generator=gen).float()
-    mel = torch.randn(1, 39, g.mel_len, generator=gen)
-    voice = torch.randint(0, 40, (1,), generator=gen)
-    jitter = torch.arange(g.embed_len).repeat(1, 1)
-    cores = torch.get_num_threads()
-    times = []
-    t_start = time.time()
-    for it in range(3):
-        t0 = time.time()
-        out = R.ae_run(sd, {"emb": emb}, hps, g, wav, mel, voice, jitter, loss_mode="intended", take_compat=False)
-        out["loss"].backward()
-        times.append(time.time() - t0)
-        for v in sd.values():
-            v.grad = None
-        if time.time() - t_start > seconds_budget:
-            break
-    best = min(times)
-    return {"value": g.n_win / best, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+bwd, 1 window of {g.n_win} samples (B=1), best of {len(times)} "
-                      f"({best:.2f} s/step)"}
-
-
-def pmc_traffic():
-    """HBM bytes per launch (a number, as the bench contract asks) of the dominant kernel from the committed PMC passes
-    (profiles/r01_pmc_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, FETCH doubled per MI355X_MICROARCH.md).  bench.py cannot collect PMCs itself."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
-    try:
-        import csv
-        n = tot = 0.0
-        for r in csv.DictReader(open(path)):
-            if "k_gemm_nt_bf16" in r["kernel"]:
-                k = float(r["launches"])
-                n += k
-                tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
-        return round(tot / n) if n else None
-    except Exception:
-        return None
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -117,6 +40,7 @@ def main():
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--jitter-prob", dest="jitter_prob", type=float, default=0.12, help="par/train.basic.json")
     ap.add_argument("--lanes", type=int, default=1, help="0: serial plan order (no side-lane overlap)")
     ap.add_argument("--nt-wave-rows", dest="nt_wave_rows", type=int, default=64, help="bf16 NT shape (64|128|256)")
     ap.add_argument("--nt-pipe", dest="nt_pipe", type=int, default=1, help="0 plain loop, 1 pipelined, 2 pipelined K=64 tiles")
@@ -127,12 +51,134 @@ def main():
     ap.add_argument("--nt-small", dest="nt_small", type=int, default=-1, help="tile-count threshold for 64-row NT tiles")
     ap.add_argument("--side-lanes", dest="side_lanes", type=int, default=0, help="side lanes the wgrads rotate over (1..4)")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
-    args = ap.parse_args()
+    ap.add_argument("--engine-only", action="store_true", help="headline = the engine-level step (no module surface / loader)")
+    return ap.parse_args()
 
+
+def spawn(args):
+    """`python bench.py --gpus N` without a launcher: one process per GPU through torch.distributed.run on
+    127.0.0.1 (train.py:58-60 semantics: one process per device).  Fails loudly if the node has fewer devices."""
+    import torch
+    share = os.environ.get("AEW_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if not share and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU number "
+                         "(AEW_BENCH_SHARE_GPU=1 AEW_BENCH_BACKEND=gloo runs all ranks on cuda:0 as a functional check)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def make_model(args, device):
+    import torch
+    from ae_wavenet_amd import autoencoder_model as ae, config, optim
+    hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=args.jitter_prob)
+    torch.manual_seed(2507)                                       # hparams.py:92 random_seed
+    model = ae.AutoEncoder(hps, n_mel=39).to(device)              # Xavier weights, zero biases, codebook gain 10
+    opt = optim.FusedAdam(model, lr=args.lr)
+    return hps, model, opt
+
+
+def host_batches(model, B, rank, n_pool=8):
+    """A pool of distinct host batches (pinned by the prefetcher): what the reference's DataLoader workers hand to the
+    training loop (data.py:218-240: wav, mel, voice, jitter; the jitter indices are generated on the device here)."""
+    import torch
+    g = model.geom
+    gen = torch.Generator().manual_seed(1000 + rank)
+    pool = []
+    for _ in range(n_pool):
+        wav = torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float()
+        mel = torch.randn(B, 39, g.mel_len, generator=gen)
+        voice = torch.randint(0, 40, (B,), generator=gen)
+        pool.append((wav, mel, voice, None))
+
+    def it():
+        i = 0
+        while True:
+            yield pool[i % n_pool]
+            i += 1
+    return it()
+
+
+def cpu_baseline(hps, eng, seconds_budget=30.0):
+    """The oracle (torch fp32 CPU restatement of the reference) on a bounded sample of the same workload: 2 of the 8
+    windows of a batch, one full training step each way - forward, [the reference's diagnostic autograd.grad over
+    (mel, encoding), autoencoder_model.py:252-257], backward, Adam over all parameters - on all host cores."""
+    import torch
+    from oracle import ref_model as R
+    g = eng.geom
+    nb = 2
+    sd = {k: eng.ps.view(k).detach().cpu().clone().requires_grad_(True) for k in eng.ps.names()}
+    emb = eng.emb.detach().cpu().clone()
+    gen = torch.Generator().manual_seed(5)
+    wav = torch.randint(0, 256, (nb, g.enc_in_len), generator=gen).float()
+    mel = torch.randn(nb, 39, g.mel_len, generator=gen)
+    voice = torch.randint(0, 40, (nb,), generator=gen)
+    jitter = torch.arange(g.embed_len).repeat(nb, 1)
+    cores = torch.get_num_threads()
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+    res = {}
+    t_start = time.time()
+    for diag in (False, True):
+        best = None
+        for it in range(2):
+            t0 = time.time()
+            opt.zero_grad()
+            m = mel.clone().requires_grad_(True)
+            out = R.ae_run(sd, {"emb": emb}, hps, g, wav, m, voice, jitter, loss_mode="intended", take_compat=False)
+            if diag:
+                torch.autograd.grad(out["loss"], (m, out["encoding_bn"]), retain_graph=True, allow_unused=True)
+            out["loss"].backward()
+            opt.step()
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+            if time.time() - t_start > seconds_budget * (2 if diag else 1) / 2:
+                break
+        res[diag] = best
+    return {"value": nb * g.n_win / res[True], "unit": "samples/s", "cores": cores, "kind": "port",
+            "value_without_diagnostic_backward": nb * g.n_win / res[False],
+            "sample": f"oracle forward + backward + Adam on {nb} of the batch's 8 windows ({nb} x {g.n_win} samples): "
+                      f"{res[True]:.2f} s with the reference's diagnostic second backward (what its run() does), "
+                      f"{res[False]:.2f} s without; time per window is independent of the batch size on the CPU"}
+
+
+def pmc_traffic():
+    """HBM bytes per launch (a number, as the bench contract asks) of the dominant kernel from the committed PMC passes
+    (profiles/r02_pmc_hbm_traffic.csv, else round 1's: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, FETCH doubled per MI355X_MICROARCH.md).  bench.py cannot collect PMCs itself."""
+    for name in ("r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            import csv
+            n = tot = 0.0
+            for r in csv.DictReader(open(path)):
+                if "k_gemm_nt_bf16" in r["kernel"]:
+                    k = float(r["launches"])
+                    n += k
+                    tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
+            if n:
+                return round(tot / n), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn(args)
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # AEW_BENCH_SHARE_GPU=1 + AEW_BENCH_BACKEND=gloo: all ranks on cuda:0 over gloo - a functional check of the
     # multi-process path on a one-GPU box (tools/measure_round.sh), not a measurement
@@ -140,6 +186,8 @@ def main():
     backend = os.environ.get("AEW_BENCH_BACKEND", "nccl")
     if share:
         local = 0
+    if not share and torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: no cuda:{local} on this node ({torch.cuda.device_count()} devices)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dp = None
@@ -149,6 +197,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
         from ae_wavenet_amd.dp import DataParallel
         dp = DataParallel()
 
@@ -172,22 +222,16 @@ def main():
         _E.DecoderPlan.n_side_lanes = args.side_lanes
     if os.environ.get("AEW_SPLIT_MULTISEG"):
         _E.DecoderPlan.split_multiseg = os.environ["AEW_SPLIT_MULTISEG"] == "1"
-    hps, eng = build_engine(args, device)
-    if dp is not None:
-        dp.broadcast_params(eng)
-    batch = synth_batch(eng, rank, device)
-    eng.set_inputs(*batch)
-    ema_ar = dp.allreduce_ema if dp is not None else None
-    # sum-type loss (VQEMA 'intended'): summed gradients across ranks == single-process global batch
-    gscale = 1.0
 
-    def step():
-        if dp is not None:
-            dp.train_step(eng, args.lr, gscale)     # collectives overlapped (EMA stats, decoder / encoder grads)
-        else:
-            eng.forward()
-            eng.backward()
-            eng.adam_step(args.lr, gscale)
+    from ae_wavenet_amd.jitter import DeviceJitter
+    from ae_wavenet_amd.loader import DevicePrefetcher
+    hps, model, opt = make_model(args, device)
+    eng = model._ensure_engine(args.batch)
+    if dp is not None:
+        dp.attach(model)                       # gradient / EMA-statistic collectives inside backward() / step()
+        dp.broadcast_params(eng)
+    loader = DevicePrefetcher(host_batches(model, args.batch, rank), device, depth=2,
+                              jitter=DeviceJitter(args.jitter_prob, seed=2507 + rank))
 
     def fence():
         torch.cuda.synchronize()
@@ -195,19 +239,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- the step through the boundary ----------------------------------------------------------------------
+    def step():
+        wav, mel, voice, jitter = next(loader)
+        opt.zero_grad()
+        pred, target, loss = model.run(wav, mel, voice, jitter)
+        loss.backward()
+        opt.step()
+
+    def engine_step():
+        if dp is not None:
+            dp.train_step(eng, args.lr, 1.0)
+        else:
+            eng.forward()
+            eng.backward()
+            eng.adam_step(args.lr, 1.0)
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    head_fn, other_fn = (engine_step, step) if args.engine_only else (step, engine_step)
+    dt = timed(head_fn)
     loss_val = float(eng.loss_buf[0])
+    dt_other = timed(other_fn)
 
     # ---- per-kernel timing for the roofline (outside the timed region) ----------------------
     roof = None
@@ -219,7 +285,7 @@ def main():
         for _ in range(n_t):
             eng.forward(None, timing=True)
             eng.backward(timing=True)
-            eng.adam_step(args.lr, gscale)
+            eng.adam_step(args.lr, 1.0)
         cap = 1 << 16
         ms = (C.c_float * cap)()
         tags = (C.c_int32 * cap)()
@@ -244,13 +310,14 @@ def main():
                 for lab, v in sorted(per.items(), key=lambda kv: -kv[1]):
                     fh.write(f"{v:9.4f}  {lab}\n")
         fl = eng.flops_per_step()
-        # forward + dgrad of the gated stack / post network run on the bf16 NT kernel,
-        # wgrad on the bf16 TN kernel  (90.4 MFLOP per output sample per step)
+        # forward + dgrad of the gated stack / post network run on the bf16 NT kernels (k_gemm_nt_bf16 and, for the
+        # long-K multi-segment GEMMs, k_fn), wgrad on the bf16 TN kernel  (90.4 MFLOP per output sample per step)
         nt_flops, nt_ms = fl["step"] * 2.0 / 3.0, cls_ms.get(1, 0.0)
         n_launch = max(cls_n.get(1, 0) // n_t, 1)
         achieved = nt_flops / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
+        traffic, src = pmc_traffic()
         roof = {"bound": "mfma", "kernel": "k_gemm_nt_bf16", "achieved": round(achieved, 2), "peak": 2500.0,
-                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": pmc_traffic(),
+                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": traffic,
                 "launches_per_step": n_launch, "avg_launch_ms": round(nt_ms / n_launch, 5),
                 "alg_flops_per_launch": nt_flops / n_launch,
                 "tn_bf16": {"achieved": round((fl["step"] / 3.0) / (cls_ms.get(2, 1e9) * 1e-3) / 1e12, 2),
@@ -259,7 +326,7 @@ def main():
         # the same launches against the HBM roofline: measured bytes per launch (PMC) / measured time per launch.  At
         # K = 256..1024 with 3-4 activation tensors in and out the stack's intensity (~240 FLOP/B) is below the ridge
         # (2500 / 8 = 312), see profiles/r01_op_roofline.txt
-        roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2)"
+        roof["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2)" if src else None
         if roof["traffic"]:
             tbps = roof["traffic"] / (nt_ms / n_launch * 1e-3) / 1e12
             roof["hbm_view"] = {"achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
@@ -267,7 +334,7 @@ def main():
     cpu = None
     if world > 1:
         cpu = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
-               "sample": "measured at --gpus 1 only (rank 0 would hold the other ranks for ~20 s)"}
+               "sample": "measured at --gpus 1 only (rank 0 would hold the other ranks for ~30 s)"}
     elif rank == 0 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(hps, eng)
@@ -276,17 +343,24 @@ def main():
                    "sample": f"failed: {type(e).__name__}: {e}"}
 
     if rank == 0:
-        samples = world * args.batch * args.n_win * args.steps
+        n_ranks = dist.get_world_size() if world > 1 else 1
+        samples = n_ranks * args.batch * args.n_win * args.steps
+        names = ("engine", "boundary") if args.engine_only else ("boundary", "engine")
         out = {
             "metric": "16kHz audio samples/sec/step (VQ-VAE-EMA train)",
-            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": samples / dt, "unit": "samples/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "VQ-VAE-EMA (arch.vqvae-ema shape: 2x10 gated layers, 368 res / 256 dil "
                                    "/ 256 skip, K=4096 d=32) fwd+bwd+Adam",
-                       "global_batch": world * args.batch, "n_win_batch": args.n_win,
-                       "parallelism": f"dp{world}", "loss": float(loss_val),
-                       "decoder": "bf16 MFMA, fp32 accumulate", "encoder_vq": "fp32 MFMA exact chain"},
+                       "timed_region": {"boundary": "pinned host batch -> DevicePrefetcher (H2D copy stream, jitter on the device) "
+                                                    "-> AutoEncoder.run -> loss.backward() -> FusedAdam.step()",
+                                        "engine": "TrainEngine.forward / backward / adam_step on one resident batch"}[names[0]],
+                       "global_batch": n_ranks * args.batch, "n_win_batch": args.n_win, "jitter_prob": args.jitter_prob,
+                       "parallelism": f"dp{n_ranks}", "loss": float(loss_val),
+                       "decoder": "bf16 MFMA, fp32 accumulate", "encoder_vq": "fp32 MFMA exact chain (forward), bf16 MFMA (backward)"},
+            names[1] + "_only" if names[1] == "engine" else "through_boundary":
+                {"ms_per_step": 1e3 * dt_other / args.steps, "value": samples / dt_other, "unit": "samples/s"},
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_ms_by_tag": {str(k): round(v, 4) for k, v in sorted(kern.items())},
         }
