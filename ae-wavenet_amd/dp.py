@@ -3,10 +3,20 @@
 The reference only distributes on TPU (xmp.spawn + xm.optimizer_step, train.py:58-60,
 chassis.py:168-169).  Here every rank holds a full replica and an independent shard of audio
 windows (sampler rule data.py:100-106); per step the ranks exchange
-  * the flat gradient buffer (one bucketed all-reduce, SUM; the optimizer applies 1/world for
-    mean-type losses — SURVEY §8e), and
+  * the gradients (SUM; the optimizer applies 1/world for mean-type losses — SURVEY §8e), and
   * the VQ-EMA statistics z_sum / n_sum (SUM) before the EMA update, so that all replicas keep
     an identical codebook (north-star requirement; the reference lets replicas drift).
+
+Two schedules for the gradient exchange (same result up to fp32 summation order):
+  train_step          all-reduce of the decoder tail under the encoder backward, all-reduce of the head under the
+                      decoder's Adam range (round 1);
+  train_step_sharded  reduce-scatter + SHARDED Adam + all-gather (what xm.optimizer_step amounts to on a ring):
+                      every rank receives and updates only its 1/world shard of each region (a ring reduce-scatter moves
+                      half the bytes of an all-reduce before the optimizer can start, and the Adam pass shrinks by
+                      world), then the updated shards are all-gathered; the decoder region's exchange runs under the
+                      encoder backward and the head's reduce-scatter, its all-gather under the head's Adam.  Optional
+                      bf16 gradient transport (half the xGMI bytes of the reduce-scatter; fp32 master parameters and
+                      moments unchanged).
 """
 from __future__ import annotations
 
@@ -33,6 +43,8 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.sharded, self.bf16_grads = False, False
+        self._pending, self._st = [], None
 
     def grad_scale(self, mean_loss: bool) -> float:
         """Factor the optimizer applies to the summed gradient: 1/world reproduces the
@@ -116,6 +128,119 @@ class DataParallel:
             work["enc"].wait()
             eng.adam_step(lr, grad_scale, lo=0, hi=lo, count=False, **adam_kw)
 
+    # ---- reduce-scatter + sharded Adam + all-gather ------------------------------------------------------------
+    def _split(self, a: int, b: int):
+        """Region [a, b) of the flat buffer -> (shard elements s, remainder start): world * s elements are reduce-
+        scattered (rank r owns [a + r*s, a + (r+1)*s)), the < 4*world elements from the remainder start are all-reduced
+        and updated by every rank.  s is a multiple of 4 (the Adam kernel works on float4)."""
+        s = ((b - a) // (4 * self.world)) * 4
+        return s, a + self.world * s
+
+    def _reduce_region(self, flat: torch.Tensor, a: int, b: int, bf16: bool):
+        """Issue the reduction of gradient region [a, b): returns a list of async work handles and a `finish`
+        callable to run after they completed (bf16 transport: copy the reduced shard back as fp32)."""
+        s, rem = self._split(a, b)
+        work, fin = [], []
+        if s > 0:
+            main = flat[a:a + self.world * s]
+            mine = flat[a + self.rank * s: a + (self.rank + 1) * s]
+            if bf16:
+                half = main.to(torch.bfloat16)
+                out = torch.empty(s, dtype=torch.bfloat16, device=flat.device)
+                work.append(dist.reduce_scatter_tensor(out, half, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                fin.append(lambda: mine.copy_(out))
+                self._keep = (half, out)
+            else:
+                out = torch.empty(s, dtype=flat.dtype, device=flat.device)     # out of place: valid on every backend
+                work.append(dist.reduce_scatter_tensor(out, main, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                fin.append(lambda: mine.copy_(out))
+                self._keep = (out,)
+        if rem < b:
+            work.append(dist.all_reduce(flat[rem:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return work, fin
+
+    def _update_region(self, eng, a: int, b: int, lr, grad_scale, count, adam_kw):
+        """Adam on this rank's shard of region [a, b) (+ the replicated remainder), then the all-gather of the updated
+        parameter shards (async; returned)."""
+        s, rem = self._split(a, b)
+        work = []
+        if s > 0:
+            lo = a + self.rank * s
+            eng.adam_step(lr, grad_scale, lo=lo, hi=lo + s, count=count, **adam_kw)
+            count = False
+            main = eng.ps.params[a:a + self.world * s]
+            work.append(dist.all_gather_into_tensor(main, eng.ps.params[lo:lo + s].clone(), group=self.group, async_op=True))
+        if rem < b:
+            eng.adam_step(lr, grad_scale, lo=rem, hi=b, count=count, **adam_kw)
+        return work
+
+    def finish(self):
+        """Wait for the parameter all-gathers of the previous sharded step (called before the next forward)."""
+        for w in getattr(self, "_pending", []):
+            w.wait()
+        self._pending = []
+
+    def backward_exchange(self, eng, bf16_grads: bool = False):
+        """Backward with the sharded gradient exchange issued as the regions become final: decoder tail (reduce-scatter
+        under the bottleneck / encoder backward), then the head.  optimizer_step() completes it."""
+        n, lo = eng.ps.numel, eng.dec_grad_offset
+        flat = eng.ps.grads
+        st = {}
+
+        def after_decoder():
+            st["dec"] = self._reduce_region(flat, lo, n, bf16_grads)
+
+        self.allreduce_kl(eng)
+        eng.backward(after_decoder=after_decoder)
+        if "dec" not in st:
+            after_decoder()
+        st["head"] = self._reduce_region(flat, 0, lo, bf16_grads) if lo > 0 else ([], [])
+        self._st = st
+
+    def optimizer_step(self, eng, lr: float, grad_scale: float = 1.0, **adam_kw):
+        """Sharded Adam + all-gather of the updated parameters (left in flight: finish() before the next forward)."""
+        n, lo = eng.ps.numel, eng.dec_grad_offset
+        st, self._st = self._st, None
+        for w in st["dec"][0]:
+            w.wait()
+        for f in st["dec"][1]:
+            f()
+        pend = self._update_region(eng, lo, n, lr, grad_scale, True, adam_kw)      # decoder shards; all-gather in flight
+        for w in st["head"][0]:
+            w.wait()
+        for f in st["head"][1]:
+            f()
+        if lo > 0:
+            pend += self._update_region(eng, 0, lo, lr, grad_scale, False, adam_kw)
+        self._pending = pend
+
+    def train_step_sharded(self, eng, lr: float, grad_scale: float = 1.0, bf16_grads: bool = False, **adam_kw):
+        """forward + backward + sharded optimizer step (see the module docstring).  Every rank ends with the same
+        parameters as train_step() gives (fp32 transport: up to summation order; bf16 transport: the summed gradient
+        is rounded to bf16 once per hop).  The Adam MOMENTS of a rank are valid for its own shards only (ZeRO-1): use
+        gather_moments() before reading them (checkpoints)."""
+        if self.world == 1:
+            eng.forward()
+            eng.backward()
+            eng.adam_step(lr, grad_scale, **adam_kw)
+            return
+        self.finish()
+        eng.forward(self.allreduce_ema_async)
+        self.backward_exchange(eng, bf16_grads)
+        self.optimizer_step(eng, lr, grad_scale, **adam_kw)
+
+    def gather_moments(self, eng):
+        """All-gather the Adam moments (each rank holds valid moments for its own shards only under the sharded step)."""
+        if self.world == 1:
+            return
+        n, lo = eng.ps.numel, eng.dec_grad_offset
+        for a, b in ((lo, n), (0, lo)):
+            s, rem = self._split(a, b)
+            if s > 0:
+                for buf in (eng.adam_m, eng.adam_v):
+                    dist.all_gather_into_tensor(buf[a:a + self.world * s], buf[a + self.rank * s: a + (self.rank + 1) * s].clone(),
+                                                group=self.group)
+
     def allreduce_ema_async(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
         """Like allreduce_ema but returns the work handle (the engine then defers the EMA accumulation)."""
         if self.world == 1:
@@ -151,8 +276,13 @@ class DataParallel:
             for t in (eng.emb, eng.ema_numer, eng.ema_denom):
                 dist.broadcast(t, src, group=self.group)
 
-    def attach(self, model):
+    def attach(self, model, sharded: bool = False, bf16_grads: bool = False):
+        """Hook the collectives into the module surface.  sharded=False: loss.backward() leaves the fully reduced
+        gradients in every .grad (any optimizer).  sharded=True: backward issues the reduce-scatter, FusedAdam.step()
+        updates this rank's shards and all-gathers the parameters (model.run waits for them); .grad then holds the
+        reduced values for this rank's shards only, so only FusedAdam may be used."""
         model._dp = self
-        model._ema_allreduce = self.allreduce_ema
+        self.sharded, self.bf16_grads = bool(sharded), bool(bf16_grads)
+        model._ema_allreduce = self.allreduce_ema_async if sharded else self.allreduce_ema
         if getattr(model, "_engine", None) is not None:
             self.prepare_vae(model._engine)

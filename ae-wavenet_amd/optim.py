@@ -28,7 +28,12 @@ class FusedAdam(torch.optim.Optimizer):
         if eng is None:
             raise RuntimeError("FusedAdam.step() before the first model.run()")
         g = self.param_groups[0]
-        eng.adam_step(g["lr"], self.grad_scale, g["betas"], g["eps"])
+        dp = getattr(self.model, "_dp", None)
+        if dp is not None and dp.sharded and dp.world > 1:
+            # data parallel, sharded: Adam on this rank's shards of the reduce-scattered gradient, then all-gather
+            dp.optimizer_step(eng, g["lr"], self.grad_scale, betas=g["betas"], eps=g["eps"])
+        else:
+            eng.adam_step(g["lr"], self.grad_scale, g["betas"], g["eps"])
 
     # ---- torch.optim.Adam-compatible state -------------------------------------------------
     def _layout(self):

@@ -42,9 +42,13 @@ class _StepFn(torch.autograd.Function):
         # step, chassis.py:157-160); accumulation over several backward() calls is not supported.
         owner = ctx.owner
         owner._engine.set_upstream_grad(g)
-        if owner._dp is not None:
-            owner._dp.allreduce_kl(owner._engine)           # VAE: the clamp's gate sees the global KL
-        owner._engine.backward()
+        dp = owner._dp
+        if dp is not None and dp.sharded and dp.world > 1:
+            dp.backward_exchange(owner._engine, dp.bf16_grads)   # reduce-scatter issued under the encoder backward
+        else:
+            if dp is not None:
+                dp.allreduce_kl(owner._engine)               # VAE: the clamp's gate sees the global KL
+            owner._engine.backward()
         owner._after_backward(g)
         return torch.zeros_like(owner._anchor), None
 
@@ -258,6 +262,8 @@ class HipModelBase(nn.Module):
         """(step, exp_avg flat, exp_avg_sq flat) from the live engine, else from the carry, else None."""
         eng = self._engine
         if eng is not None:
+            if self._dp is not None and self._dp.sharded:
+                self._dp.gather_moments(eng)              # collective: every rank reads its optimizer state together
             n = eng.ps.numel
             return eng.step_count, eng.adam_m[:n], eng.adam_v[:n]
         return self._opt_carry
@@ -336,6 +342,8 @@ class HipModelBase(nn.Module):
         (B, w-1), loss scalar with a grad_fn whose backward fills every parameter's .grad."""
         B = wav.shape[0]
         eng = self._ensure_engine(B)
+        if self._dp is not None:
+            self._dp.finish()                                # parameter all-gathers of the previous sharded step
         eng.set_inputs(wav, mel, voice, jitter, eps=eps)
         loss = _StepFn.apply(self._anchor, self)
         w, g = eng.n_win, eng.geom
@@ -391,7 +399,7 @@ class HipModelBase(nn.Module):
         # re-attach .grad views (optim.zero_grad(set_to_none=True) detaches them)
         for name, pname in self._pnames:
             self._parameters[pname].grad = eng.ps.view(name, grad=True)
-        if self._dp is not None:
+        if self._dp is not None and not self._dp.sharded:
             self._dp.allreduce_grads(eng)
         m = self.objective.metrics
         if self.kind == "autoencoder":

@@ -227,8 +227,10 @@ def main():
     from ae_wavenet_amd.loader import DevicePrefetcher
     hps, model, opt = make_model(args, device)
     eng = model._ensure_engine(args.batch)
+    sharded = os.environ.get("AEW_DP_SHARDED", "1") == "1"       # reduce-scatter + sharded Adam + all-gather (dp.py)
+    bf16_grads = os.environ.get("AEW_DP_BF16_GRADS", "0") == "1"
     if dp is not None:
-        dp.attach(model)                       # gradient / EMA-statistic collectives inside backward() / step()
+        dp.attach(model, sharded=sharded, bf16_grads=bf16_grads)  # collectives inside run() / backward() / step()
         dp.broadcast_params(eng)
     loader = DevicePrefetcher(host_batches(model, args.batch, rank), device, depth=2,
                               jitter=DeviceJitter(args.jitter_prob, seed=2507 + rank))
@@ -357,7 +359,9 @@ def main():
                                                     "-> AutoEncoder.run -> loss.backward() -> FusedAdam.step()",
                                         "engine": "TrainEngine.forward / backward / adam_step on one resident batch"}[names[0]],
                        "global_batch": n_ranks * args.batch, "n_win_batch": args.n_win, "jitter_prob": args.jitter_prob,
-                       "parallelism": f"dp{n_ranks}", "loss": float(loss_val),
+                       "parallelism": f"dp{n_ranks}" + ("" if n_ranks == 1 else (" reduce-scatter + sharded Adam + all-gather" if sharded else " all-reduce")
+                                                        + (" (bf16 gradient transport)" if bf16_grads else "")),
+                       "loss": float(loss_val),
                        "decoder": "bf16 MFMA, fp32 accumulate", "encoder_vq": "fp32 MFMA exact chain (forward), bf16 MFMA (backward)"},
             names[1] + "_only" if names[1] == "engine" else "through_boundary":
                 {"ms_per_step": 1e3 * dt_other / args.steps, "value": samples / dt_other, "unit": "samples/s"},

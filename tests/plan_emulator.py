@@ -482,3 +482,16 @@ class Emu:
             pk, am = torch.log_softmax(self.rd(p.logits, idx).double(), -1).max(-1)
             o[6], o[7], o[8] = pk.mean(), pk.std(), am.unique().numel()
         self.wr(p.out, torch.arange(9), o)
+
+
+def emulate(eng):
+    """Make a TrainEngine built on 'cpu' executable: every plan it would send to aew_run_plan goes through the
+    interpreter instead (test infrastructure for the GPU-less container: data-parallel schedules, optimizer flows)."""
+    emu = Emu(eng.ws)
+    eng._stream = lambda: 0
+    eng._run = lambda plan, timing=False: emu.run(plan)
+    for name in ("opt", "cb"):
+        pl = getattr(eng, name, None)
+        if pl is not None:
+            pl.run = (lambda p: (lambda stream=0: emu.run(p)))(pl)
+    return eng

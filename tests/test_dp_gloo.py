@@ -127,3 +127,111 @@ def test_shard_indices_match_reference_rule():
         assert idx == [vals[i] for i in perm]
         seen += idx
     assert sorted(seen) == list(range(n))                 # the shards partition the dataset
+
+
+# ----------------------------------------------------------------------------------------------
+# real training steps on two ranks (plans executed by the CPU interpreter) vs ONE process on the global batch
+# ----------------------------------------------------------------------------------------------
+def _tiny(bn):
+    return config.make_hps(bn, n_res=8, n_dil=8, n_skp=8, n_post=8, n_lc_out=8, n_global_embed=2, n_speakers=3,
+                           n_blocks=1, n_block_layers=2, enc_n_out=8, bn_n_out=4, bn_vq_n_embed=16, n_win_batch=6)
+
+
+def _seed_engine(eng, seed=7):
+    gen = torch.Generator().manual_seed(seed)
+    n = eng.ps.numel
+    eng.ps.params[:n].copy_(torch.randn(n, generator=gen) * 0.3)
+    if eng.bn_type == "vqvae-ema":
+        eng.emb.copy_(torch.randn(eng.emb.shape, generator=gen))
+        eng.init_ema_from_emb()
+    eng.adam_m.zero_(); eng.adam_v.zero_(); eng.step_count = 0
+
+
+def _global_batch(eng_geom, n_mel, world, seed=3):
+    gen = torch.Generator().manual_seed(seed)
+    g = eng_geom
+    wav = torch.randint(0, 256, (world, g.enc_in_len), generator=gen).float()
+    mel = torch.randn(world, n_mel, g.mel_len, generator=gen)
+    voice = torch.randint(0, 3, (world,), generator=gen)
+    jitter = torch.arange(g.embed_len).repeat(world, 1)
+    return wav, mel, voice, jitter
+
+
+def _real_worker(rank, world, port, bn, q):
+    from tests.plan_emulator import emulate
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hps = _tiny(bn)
+        eng = emulate(M.TrainEngine(hps, B=1, device="cpu", n_mel=5))
+        d = dp.DataParallel()
+        d.prepare_vae(eng)
+        batch = _global_batch(eng.geom, 5, world)
+        mine = [t[rank:rank + 1] for t in batch]
+        gs = d.grad_scale(M.MEAN_LOSS[eng.bn_type])
+        out = {}
+        n = eng.ps.numel
+        for name in ("allreduce", "sharded", "sharded_bf16"):
+            _seed_engine(eng)
+            eng.set_inputs(*mine)
+            for it in range(2):                                   # two steps: the second sees the exchanged state
+                if name == "allreduce":
+                    d.train_step(eng, 1e-2, gs)
+                else:
+                    d.train_step_sharded(eng, 1e-2, gs, bf16_grads=name.endswith("bf16"))
+            d.finish()
+            if name != "allreduce":
+                d.gather_moments(eng)
+            out[name] = (eng.ps.params[:n].numpy().copy(), eng.adam_m[:n].numpy().copy(),
+                         eng.emb.numpy().copy() if eng.bn_type == "vqvae-ema" else None)    # numpy: pickled by value
+        ref = None
+        if rank == 0:                                             # the same two steps in ONE process, global batch
+            one = emulate(M.TrainEngine(hps, B=world, device="cpu", n_mel=5))
+            _seed_engine(one)
+            one.set_inputs(*batch)
+            for it in range(2):
+                one.forward(); one.backward(); one.adam_step(1e-2, 1.0)
+            ref = (one.ps.params[:n].numpy().copy(), one.adam_m[:n].numpy().copy(),
+                   one.emb.numpy().copy() if one.bn_type == "vqvae-ema" else None)
+        q.put((rank, out, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bn", ["vqvae-ema", "ae"])
+def test_dp_real_steps_match_single_process_global_batch(bn):
+    """Sum-type loss (VQ-VAE-EMA: summed gradients, one codebook from summed EMA statistics) and mean-type loss (AE:
+    the optimizer scales the summed gradient by 1 / world): two ranks with one window each == one process with both."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, bn, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, o0, ref), (_, o1, _) = res
+    T = lambda a: None if a is None else torch.from_numpy(a)
+    o0 = {k: tuple(T(a) for a in v) for k, v in o0.items()}
+    o1 = {k: tuple(T(a) for a in v) for k, v in o1.items()}
+    p_ref, m_ref, e_ref = (T(a) for a in ref)
+    scale = float(p_ref.abs().max())
+    for name, tol in (("allreduce", 2e-5), ("sharded", 2e-5), ("sharded_bf16", 2e-2)):
+        pa, ma, ea = o0[name]
+        pb, mb, eb = o1[name]
+        assert torch.equal(pa, pb), name                                   # the replicas stay identical
+        assert torch.equal(ma, mb), name                                   # gathered moments too
+        assert float((pa - p_ref).abs().max()) <= tol * scale, (name, float((pa - p_ref).abs().max()), scale)
+        # (bf16 transport rounds every summed gradient to 8 bits of mantissa; Adam's normalised update then moves
+        # near-zero-gradient parameters differently in step 1, which step 2's moments see: looser bound)
+        mtol = 0.1 if name.endswith("bf16") else tol
+        assert float((ma - m_ref).abs().max()) <= mtol * max(float(m_ref.abs().max()), 1e-12), name
+        if e_ref is not None:
+            assert torch.equal(ea, eb)
+            assert float((ea - e_ref).abs().max()) <= (1e-3 if name.endswith("bf16") else 1e-5) * float(e_ref.abs().max()), name
+    assert torch.equal(o0["allreduce"][0], o0["sharded"][0]) or \
+        float((o0["allreduce"][0] - o0["sharded"][0]).abs().max()) <= 1e-6 * scale
