@@ -260,8 +260,9 @@ def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.", "scratch.")):
     """First buffers (in allocation order) whose GPU content deviates from the interpreter."""
     bad = []
     for n, tc in ec.ws.bufs.items():
-        if n.startswith(skip_prefix) or ".wg." in n or n.startswith("enc.wg") or n.startswith("bn.wg"):
-            continue                     # wgrad slabs: split layout is implementation detail
+        if n.startswith(skip_prefix) or ".wg." in n or n.startswith("enc.wg") or n.startswith("bn.wg") or "tbl." in n \
+                or n == "bn.vq_part":
+            continue                     # wgrad slabs / search scratch: implementation detail; tables hold pointers
         tg = eg.ws.get(n).cpu()
         if tc.dtype in (torch.int64, torch.int32):
             if not torch.equal(tc, tg):
@@ -430,6 +431,112 @@ def test_full_width_step_vs_oracle():
         worst = max(worst, (e, k))
         assert e < 0.15 and cos > 0.99, (k, e, cos)
     print("worst gradient max-normalised error:", worst)
+
+
+def test_full_width_step_vs_interpreter_buffer_by_buffer():
+    """The tight full-width check: the same plans executed by the CPU interpreter with the REAL storage types (bf16
+    decoder buffers) on the full-width model (768-wide encoder, K = 4096 codes, 20 x 368/256 decoder; B = 2, w = 100).
+
+    Forward: every workspace buffer GPU vs interpreter at the toy-width limits (3e-2 of the buffer's maximum for bf16,
+    2e-2 for fp32).  Backward: TEACHER-FORCED - the interpreter starts from the GPU's own forward state.  Free-running,
+    the two forwards differ by bf16 rounding noise (~0.8 % relative L2 in h0 / h1 after 20 layers), which flips the
+    ReLU mask of the ~0.3 % of units whose pre-activation lies inside it; every flip swaps a whole gradient
+    contribution, so ANY two correct implementations differ by sqrt(2 * 0.003) ~ 8 % relative L2 in every gradient
+    (measured: 7.8 % in dh1, 10 % downstream) - the same effect that sets the 15 % bound against the fp32 oracle.  With
+    the masks pinned, every backward buffer and every parameter gradient has to agree to bf16 rounding: an indexing
+    error that moves one column of one tensor shows up here."""
+    hps, eg, wts, emb, inp = seeded_full_engine(B=2, w=100)
+    ec = M.TrainEngine(hps, B=2, device="cpu", n_mel=39, update_codebook_every_step=False)
+    for k, v in wts.items():
+        ec.ps.view(k).copy_(torch.from_numpy(v))
+    ec.emb.copy_(torch.from_numpy(emb))
+    ec.init_ema_from_emb()
+    ec.set_inputs(*inp)
+    eg.set_inputs(*[t.to(DEV) for t in inp])
+    emu = Emu(ec.ws)
+    for name in ("fwd_a", "fwd_b"):
+        emu.run(getattr(ec, name))
+    eg.forward()
+    torch.cuda.synchronize()
+    assert torch.equal(ec.ind[:ec.Q], eg.ind[:eg.Q].cpu())
+    bad = diff_workspaces(ec, eg)
+    assert not bad, ("forward", bad[:12])
+    worst_fwd = 0.0
+    for n in ("decoder.h0", "decoder.h1", "decoder.logits", "decoder.cond", "decoder.x19", "decoder.z10", "bn.zq"):
+        a, b = ec.ws.get(n).float(), eg.ws.get(n).cpu().float()
+        worst_fwd = max(worst_fwd, float((a - b).norm() / a.norm()))
+    print(f"forward, free-running: worst relative L2 of the sampled activation buffers {worst_fwd:.3e}")
+    assert worst_fwd < 2e-2
+    # ---- backward from the GPU's forward state
+    for n, t in ec.ws.bufs.items():
+        if "tbl." not in n:                                   # (the copy tables hold each workspace's own pointers)
+            t.copy_(eg.ws.get(n).cpu())
+    emu.run(ec.bwd)
+    eg.backward()
+    torch.cuda.synchronize()
+    bad = diff_workspaces(ec, eg)
+    assert not bad, ("backward", bad[:12])
+    rows = []
+    for k in eg.ps.names():
+        a, b = ec.ps.view(k, grad=True).float(), eg.ps.view(k, grad=True).cpu().float()
+        na = float(a.norm())
+        if na == 0:
+            assert float(b.abs().max()) == 0, k
+            continue
+        rows.append((float((a - b).norm()) / na, float((a - b).abs().max()) / float(a.abs().max()), k))
+    rows.sort(reverse=True)
+    print("relative-L2 / max-normalised error of the parameter gradients, GPU vs interpreter (worst 8 of %d):" % len(rows))
+    for r in rows[:8]:
+        print("   %.3e  %.3e  %s" % r)
+    print("   median relative L2 %.3e" % sorted(r[0] for r in rows)[len(rows) // 2])
+    assert rows[0][0] < 2e-2, rows[0]
+    assert max(r[1] for r in rows) < 3e-2, max(rows, key=lambda r: r[1])
+
+
+def test_deep_decoder_step_vs_oracle():
+    """BASELINE configs[4] architecture (30 dilation layers x 512 residual channels), short window: one training step
+    against the fp32 oracle - code indices exact, logits / loss / gradients within the stated bf16 tolerances."""
+    from oracle import ref_model as R
+    hps = config.make_hps("deep", n_win_batch=64, bn_vq_n_embed=512)
+    B = 1
+    eng = M.TrainEngine(hps, B=B, device=DEV, n_mel=39, update_codebook_every_step=False)
+    assert len(eng.geom.layers) == 30 and hps.n_res == 512
+    shapes = {k: eng.ps.shape[k] for k in eng.ps.names()}
+    wts = np_weights(shapes, 21)
+    for k, v in wts.items():
+        eng.ps.view(k).copy_(torch.from_numpy(v))
+    rs = np.random.RandomState(22)
+    emb = (rs.standard_normal((512, hps.bn_n_out)) * 0.7).astype(np.float32)
+    eng.emb.copy_(torch.from_numpy(emb))
+    eng.init_ema_from_emb()
+    g = eng.geom
+    inp = (torch.from_numpy(rs.randint(0, 256, (B, g.enc_in_len)).astype(np.float32)),
+           torch.from_numpy(rs.standard_normal((B, 39, g.mel_len)).astype(np.float32)),
+           torch.from_numpy(rs.randint(0, 40, (B,)).astype(np.int64)), torch.arange(g.embed_len).repeat(B, 1))
+    eng.set_inputs(*[t.to(DEV) for t in inp])
+    loss = eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in wts.items()}
+    out = R.ae_run(sd, {"emb": torch.from_numpy(emb)}, hps, g, *inp, loss_mode="intended", take_compat=False)
+    out["loss"].backward()
+    assert np.array_equal(eng.ind[:eng.Q].cpu().numpy(), out["min_ind"].reshape(-1).numpy())
+    lg = eng.logits().permute(0, 2, 1).cpu()
+    err = (lg - out["quant"].detach()).abs().max().item()
+    print(f"DEEP: logit max abs err {err:.4f} (scale {out['quant'].abs().max().item():.2f})")
+    assert err <= 0.08
+    assert abs(float(loss) / float(out["loss"].detach()) - 1) < 1e-2
+    worst = (0.0, "")
+    for k in eng.ps.names():
+        ref = sd[k].grad
+        if ref is None or ref.abs().max().item() == 0:
+            continue
+        got = eng.ps.view(k, grad=True).cpu()
+        e = (got - ref).abs().max().item() / ref.abs().max().item()
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        worst = max(worst, (e, k))
+        assert e < 0.2 and cos > 0.985, (k, e, cos)
+    print("DEEP: worst gradient max-normalised error:", worst)
 
 
 def test_full_window_forward_vs_oracle():
