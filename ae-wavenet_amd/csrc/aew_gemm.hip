@@ -1491,6 +1491,169 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
 }
 
 // =============================================================================================
+// TN kernel, bf16, big tiles ("tnb"): out tile 256 (k) x 256 (n) = 2 x 2 HALVES of 128 columns, 8 waves as
+// 2 (k half) x 4 (64 n columns), each wave 128 (k) x 64 (n) = 8 x 4 MFMA tiles.  The small-tile kernel above stages
+// (128 + 128) columns per 64 MFMAs = 256 B per MFMA and is bound by the LDS-DMA path (measured 18-30 B/clk/CU,
+// profiles/r02_notes.md); this one stages (256 + 256) columns per 256 MFMAs = 128 B per MFMA.  A k half is a
+// 128-column tile of ONE A segment (tn_locate), so tiles never straddle segments although segments are only
+// 128-aligned; a half that does not exist (K_total or N_pad not a multiple of 256) is skipped by the waves that own it.
+// LDS: 4-stage ring of 32-row stages, stage = [G half 0 | G half 1 | A half 0 | A half 1] x 32 rows x 256 B = 32 KiB;
+// wave w stages region w >> 1 (pieces (w & 1) * 4 .. + 3): one source matrix / segment per wave.
+// Slab layout and split-K are those of the small-tile kernel (the unpack table is unchanged).
+// =============================================================================================
+#define TNB_STAGES 4
+#define TNB_STAGE_BYTES (4 * TN_RC * 256)            // 32 KiB
+#define TNB_LDS_BYTES (TNB_STAGES * TNB_STAGE_BYTES)  // 128 KiB: one block per CU
+#define TNB_THREADS 512
+
+struct TnbSrc {                                      // what one wave stages: 4 pieces (4 rows each) of one region
+    const char* p[4];
+    int row[4], m[4];
+    int64_t inc;
+    int step, lo, hi;
+    bool valid, fast;
+};
+
+__device__ __forceinline__ void tnb_setup(const aew_seg_t s, int col, int b, int r_lo, int wave, int lane, TnbSrc& S,
+                                          int nst, int r_end) {
+    const int lr = lane >> 4, pc = lane & 15;
+    S.step = TN_RC * s.row_step;
+    S.inc = (int64_t)S.step * s.row_pitch * 2;
+    S.lo = (int)s.row_lo; S.hi = (int)s.row_hi;
+    bool ok = nst > 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ((wave & 1) * 4 + j) * 4 + lr;
+        const int c = tn_swz_bf16(r, pc);
+        const int m = r_lo + r;
+        S.m[j] = m;
+        S.row[j] = m * s.row_step + s.row_off;
+        S.p[j] = reinterpret_cast<const char*>(s.ptr) +
+                 ((int64_t)b * s.batch_stride + (int64_t)S.row[j] * s.row_pitch + col + c * 8) * 2;
+        const int last = nst - 1, r0 = S.row[j], r1 = r0 + last * S.step;
+        ok = ok && (m + last * TN_RC < r_end) && min(r0, r1) >= S.lo && max(r0, r1) < S.hi;
+    }
+    S.fast = __all(ok);
+}
+
+__device__ __forceinline__ void tnb_issue(uint32_t lds_region, int r_end, int wave, TnbSrc& S) {
+    const char* zp = reinterpret_cast<const char*>(aew_zero_page);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t dst = lds_region + ((wave & 1) * 4 + j) * 1024;
+        if (S.fast) {
+            glds16_raw(S.p[j], dst);
+        } else {
+            const bool ok = S.m[j] < r_end && S.row[j] >= S.lo && S.row[j] < S.hi;
+            glds16_raw(ok ? S.p[j] : zp, dst);
+            S.row[j] += S.step; S.m[j] += TN_RC;
+        }
+        S.p[j] += S.inc;
+    }
+}
+
+__global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big(const aew_gemm_tn_t g, int splits, int rows_per_split,
+                                                                     int fold_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;                  // k half, 64-column n slab (n half = wn >> 1)
+    const int nk128 = g.K_total / 128, nn128 = g.N_pad / 128;
+    const int nkt = (nk128 + 1) / 2, nnt = (nn128 + 1) / 2;
+    const int n_tiles = nkt * nnt;
+    const int n_chunks = splits * (fold_batch ? 1 : g.batch);
+    // XCD-aware order (see k_gemm_tn_bf16): the tiles that contract over one (batch, row chunk) sit on one XCD
+    const int L = blockIdx.x, seq = L >> 3;
+    const int chunk = (seq / n_tiles) * 8 + (L & 7);
+    if (chunk >= n_chunks) return;
+    const int tile = seq % n_tiles;
+    const int kt = tile % nkt, nt = tile / nkt;
+    const int sp = chunk % splits, bz = chunk / splits;
+    const int b_lo = fold_batch ? 0 : bz, b_hi = fold_batch ? g.batch : bz + 1;
+    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
+    const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
+    const int total = nst * (b_hi - b_lo);
+    // ---- what this wave stages: region = wave >> 1: 0,1 = G halves, 2,3 = A halves
+    const int region = wave >> 1, rhalf = region & 1;
+    const bool stage_g = region < 2;
+    const int my128 = stage_g ? 2 * nt + rhalf : 2 * kt + rhalf;          // 128-column tile index of the staged half
+    const bool stage_valid = stage_g ? my128 < nn128 : my128 < nk128;
+    TnTile st_tt = {0, 0, 0};
+    if (!stage_g && stage_valid) st_tt = tn_locate(g, my128, 128);
+    // ---- what this wave computes
+    const int k128 = 2 * kt + wk, n128 = 2 * nt + (wn >> 1);
+    const bool comp_valid = k128 < nk128 && n128 < nn128;
+    TnTile ctt = {0, 0, 0};
+    if (k128 < nk128) ctt = tn_locate(g, k128, 128);
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    TnbSrc S;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem);
+    int st_in_b = 0, bcur = b_lo, issued = 0, slot = 0;
+    auto setup = [&]() {
+        if (stage_g) tnb_setup(g.g, my128 * 128, bcur, r_lo, wave, lane, S, nst, r_hi);
+        else tnb_setup(g.seg[st_tt.seg], st_tt.kin, bcur, r_lo, wave, lane, S, nst, r_hi);
+    };
+    auto issue_next = [&]() {
+        if (stage_valid) {
+            if (issued == 0) setup();
+            else if (st_in_b == 0) setup();
+            tnb_issue(lds0 + slot * TNB_STAGE_BYTES + region * (TN_RC * 256), r_hi, wave, S);
+        }
+        if (++st_in_b == nst) { st_in_b = 0; ++bcur; }
+        slot = (slot + 1 == TNB_STAGES) ? 0 : slot + 1;
+        ++issued;
+    };
+    // waves of an invalid region issue nothing: their vmcnt is 0, the counted waits below pass at once
+#pragma unroll
+    for (int q = 0; q < TNB_STAGES - 1; ++q)
+        if (q < total) issue_next();
+    int stage = 0;
+    for (int t = 0; t < total; ++t) {
+        // stage t has landed once at most the stages issued after it are outstanding (4 pieces per wave and stage)
+        const int ahead = min(total - 1 - t, TNB_STAGES - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + TNB_STAGES - 1 < total) issue_next();          // into the stage computed at step t - 1
+        const char* sb = smem + stage * TNB_STAGE_BYTES;
+        stage = (stage + 1 == TNB_STAGES) ? 0 : stage + 1;
+        if (comp_valid) {
+            const char* gs = sb + (wn >> 1) * (TN_RC * 256);
+            const char* as = sb + (2 + wk) * (TN_RC * 256);
+            bf16x8_t af[8], gf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16<0>(gs, 0, (wn & 1) * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = tn_frag_bf16<0>(as, 0, i * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (!comp_valid) return;
+    const int slab = fold_batch ? sp : (bz * splits + sp);
+    float* out = g.out + (int64_t)slab * g.out_batch_stride;
+    const int q = lane & 15, gq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n128 * 128 + (wn & 1) * 64 + j * 16 + q;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = ctt.koff + i * 16 + 4 * gq;
+            *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// =============================================================================================
 // TN kernel, fp32: out tile 64 (k) x 64 (n), contraction staged 32 rows at a time, operands by
 // ds_read_b32 (v_mfma_f32_16x16x4_f32 takes one row of the contraction per 16-lane group).
 // =============================================================================================
@@ -1639,6 +1802,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
 #undef AEW_SET_NT
     AEW_SET_LDS(k_gemm_nt_f32, NF_STAGES * NF_STAGE_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16_big, TNB_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
 #undef AEW_SET_LDS
@@ -1794,12 +1958,33 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+static int g_tn_big = 0;                              // 1: 256 x 256 tiles (k_gemm_tn_bf16_big) for large bf16 outputs.  Off: measured equal CU time
+                                                     // to the 128 x 128 kernel on this workload and it writes more slabs (profiles/r02_notes.md)
+static int g_tn_big_target = 256;                    // ... split-K until about this many blocks (one block per CU)
 static int g_tn_fold_rows = 4096;                    // contractions up to this many rows fold the batch
 static int g_tn_target_blocks = 512;                 // split-K until a TN launch has about this many blocks
 static int g_tn_small_tiles = 8, g_tn_small_target = 128;   // outputs of <= small_tiles tiles split to small_target blocks
 
+// does this op run on the big-tile kernel?  (bf16, MFMA path, at least one full 256 x 256 tile's worth of output)
+static bool tn_use_big(const aew_gemm_tn_t& g) {
+    return g_tn_big && !g_tn_safe && g.dtype == AEW_BF16 && g.impl != 1 && g.N_pad >= 256 && g.K_total >= 256 &&
+           (int64_t)g.Mc * g.batch > g_tn_fold_rows;
+}
+
 // split heuristic: aim for >= ~2 blocks per CU
 static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* rps, int* fold) {
+    if (tn_use_big(g)) {
+        const int tiles = ((g.N_pad / 128 + 1) / 2) * ((g.K_total / 128 + 1) / 2);
+        int want = (g_tn_big_target + tiles * g.batch - 1) / (tiles * g.batch);
+        int max_sp = (g.Mc + 8 * rc - 1) / (8 * rc);       // keep >= 8 stages per block
+        if (max_sp < 1) max_sp = 1;
+        int sp = want < 1 ? 1 : (want > max_sp ? max_sp : want);
+        int r = (g.Mc + sp - 1) / sp;
+        r = ((r + rc - 1) / rc) * rc;
+        sp = (g.Mc + r - 1) / r;
+        *splits = sp; *rps = r; *fold = 0;
+        return;
+    }
     const int tiles = (g.N_pad / tile) * (g.K_total / tile);
     int f = ((int64_t)g.Mc * g.batch <= g_tn_fold_rows) ? 1 : 0;   // short contractions: fold the batch loop
     int slabs_b = f ? 1 : g.batch;
@@ -1860,9 +2045,15 @@ static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_tn_check<float>, grid, dim3(64), 0, st, g, sp, rps, fold);
     } else if (g.dtype == AEW_BF16) {
         const int n_chunks = sp * (fold ? 1 : g.batch);
-        dim3 grid(((n_chunks + 7) / 8) * 8 * (g.N_pad / TN_BT) * (g.K_total / TN_BT));
         const int rc = ensure_big_lds();
         if (rc) return rc;
+        if (tn_use_big(g)) {
+            const int tiles = ((g.N_pad / 128 + 1) / 2) * ((g.K_total / 128 + 1) / 2);
+            dim3 gridb(((n_chunks + 7) / 8) * 8 * tiles);
+            hipLaunchKernelGGL(k_gemm_tn_bf16_big, gridb, dim3(TNB_THREADS), TNB_LDS_BYTES, st, g, sp, rps, fold);
+            return (int)hipGetLastError();
+        }
+        dim3 grid(((n_chunks + 7) / 8) * 8 * (g.N_pad / TN_BT) * (g.K_total / TN_BT));
         if (g_tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
         else hipLaunchKernelGGL(k_gemm_tn_bf16<0>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
     } else {

@@ -226,6 +226,11 @@ extern "C" int aew_timing_read(float* ms, int32_t* tags, int capacity, int* coun
 }
 
 extern "C" int aew_set_tn_safe(int on) { g_tn_safe = on ? 1 : 0; return 0; }
+extern "C" int aew_set_tn_big(int on, int target_blocks) {
+    g_tn_big = on ? 1 : 0;
+    if (target_blocks > 0) g_tn_big_target = target_blocks;
+    return 0;
+}
 extern "C" int aew_set_tn_small(int max_tiles, int target_blocks) {
     if (max_tiles < 0 || target_blocks < 1) return AEW_E_ARG;
     g_tn_small_tiles = max_tiles;

@@ -685,6 +685,10 @@ class DecoderPlan:
         # ---- base layer (wavenet.py:351)
         if ps.has(p + "base_layer.bias"):
             self._colsum(plan, dx0, T, R, ps.ptr(p + "base_layer.bias", True), label="db.base")
+        # (as a TN GEMM over a materialised one-hot matrix: 0.044 ms + 29 MB written by base_gather.  The scatter-add form
+        # - rows of dx0 added into LDS images per 64 channels, AEW-internal experiment of round 2 - took 0.58 ms: the
+        # rows have to be fetched one dependent (wav[t] -> dx0[t]) load pair at a time and the partial images merged
+        # with ~10 M global atomics; the GEMM streams the same bytes at full rate)
         gp, gs, gn = self._wgrad(plan, "base", BF, T, R, Rp, dx0.seg(Rp), [self.onehot.seg(Qp)], TAG_MISC)
         pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], None, 0, [Qp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
         # ---- conditioning gradient over all layers' dfg (wavenet.py:100-101 cond terms).  With split_multiseg the

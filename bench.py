@@ -213,6 +213,9 @@ def main():
         lib.aew_set_nt_small_tiles(args.nt_small)
     if args.tn_blocks:
         lib.aew_set_tn_target_blocks(args.tn_blocks)
+    if os.environ.get("AEW_TNB") is not None:                    # A/B aid: big-tile wgrad kernel off (0) / split-K block target
+        v = int(os.environ["AEW_TNB"])
+        lib.aew_set_tn_big(1 if v > 0 else 0, v)
     if args.tn_small:
         a, b = (int(v) for v in args.tn_small.split(","))
         lib.aew_set_tn_small(a, b)

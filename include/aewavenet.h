@@ -472,6 +472,9 @@ int aew_set_tn_target_blocks(int n);
 int aew_set_tn_small(int max_tiles, int target_blocks);
 /* 1: read TN fragments with a scalar LDS gather instead of ds_read_b64_tr_b16 (debug aid). */
 int aew_set_tn_safe(int on);
+/* 256 x 256 output tiles for large bf16 wgrads (k_gemm_tn_bf16_big): on = 0 / 1, target_blocks > 0 sets the split-K
+ * block target.  Changes the slab count: call before plans are built (aew_tn_slabs follows it). */
+int aew_set_tn_big(int on, int target_blocks);
 
 /* =======================================================================================
  * Autoregressive sampler — replaces WaveNet.forward_test (wavenet.py:367-531: the per-sample Python

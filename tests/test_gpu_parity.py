@@ -219,6 +219,49 @@ def test_gemm_tn(dtype, safe, Mc):
         assert err <= (2e-3 if dtype == BF else 2e-5) * scale, ("impl", impl, "safe", safe, err, scale)
 
 
+@pytest.mark.parametrize("Np,ks", [(256, (128, 128, 256)), (384, (128, 256)), (128 * 5, (384, 384, 128)), (512, (384, 384, 128))])
+def test_gemm_tn_big_tiles(Np, ks):
+    """256 x 256-tile wgrad kernel (k_gemm_tn_bf16_big) against the 128 x 128 kernel and the scalar check kernel: halves of
+    128 columns, so K_total / N_pad that are odd multiples of 128 and tiles that straddle two segments are covered."""
+    lib = L.load()
+    gen = torch.Generator().manual_seed(5)
+    B, Mc = 3, 2500
+    R0 = Mc + 43
+    ws_c = Workspace("cpu")
+    ws_c.alloc("G", B * R0 * Np, torch.bfloat16)
+    ws_c.alloc("A1", B * R0 * 384, torch.bfloat16); ws_c.alloc("A2", B * R0 * 384, torch.bfloat16)
+    for n in ("G", "A1", "A2"):
+        _fill(ws_c, n, gen)
+
+    def build(ws, impl):
+        Gm = Mat(ws, "G", B, R0, Np, BF)
+        A1 = Mat(ws, "A1", B, R0, 384, BF)
+        A2 = Mat(ws, "A2", B, R0, 384, BF)
+        segs = [(A1 if i % 2 == 0 else A2).seg(k, row_off=(0, 16, -4)[i % 3], hi=R0 - 5 if i == 1 else None) for i, k in enumerate(ks)]
+        t = make_tn(BF, Mc, B, Np - 8, Np, Gm.seg(Np, row_off=3, hi=Mc - 77), segs, impl=impl)
+        slabs = L.tn_slabs(t)
+        ws.alloc("out", slabs * Np * t.K_total, torch.float32)
+        t.out, t.out_batch_stride = ws.get("out").data_ptr(), Np * t.K_total
+        return t, slabs
+
+    res = {}
+    try:
+        for tag, big, impl in (("big", 1, 0), ("small", 0, 0), ("check", 0, 1)):
+            lib.aew_set_tn_big(big, 0)
+            ws_g = _mirror(ws_c, DEV)
+            t, slabs = build(ws_g, impl)
+            p = Plan("tn"); p.add(L.OP_GEMM_TN, t, "tn"); p.run(stream())
+            torch.cuda.synchronize()
+            res[tag] = ws_g.get("out")[:slabs * Np * t.K_total].view(slabs, Np, t.K_total).sum(0).cpu()
+    finally:
+        lib.aew_set_tn_big(0, 0)                              # the library default
+    scale = res["check"].abs().max().item()
+    assert scale > 0
+    for tag in ("big", "small"):
+        err = (res[tag] - res["check"]).abs().max().item()
+        assert err <= 2e-3 * scale, (tag, err, scale)
+
+
 # ----------------------------------------------------------------------------------------------
 # whole training steps on the reduced-width golden models: GPU vs interpreter vs golden
 # ----------------------------------------------------------------------------------------------
