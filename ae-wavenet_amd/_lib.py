@@ -22,7 +22,7 @@ EF_OUT2_COPY = 1 << 10
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
- OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC) = range(1, 23)
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC, OP_MOMENTS) = range(1, 24)
 
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -176,12 +176,17 @@ class Mfcc(C.Structure):
                 ("scratch", vp), ("out", vp), ("out_bs", i64), ("out_pitch", i32)]
 
 
+class Moments(C.Structure):
+    _fields_ = [("x", View), ("rows", i32), ("cols", i32), ("batch", i32), ("out", vp)]
+
+
 class _OpU(C.Union):
     _fields_ = [("nt", GemmNT), ("tn", GemmTN), ("copy", CopyTable), ("vqn", VqNearest),
                 ("vqs", VqStats), ("vqe", VqEma), ("vqb", VqBwd), ("lcg", LcGather),
                 ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
                 ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
-                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag), ("mfcc", Mfcc)]
+                ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag), ("mfcc", Mfcc),
+                ("mom", Moments)]
 
 
 class Op(C.Structure):
@@ -193,7 +198,7 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
             OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit",
-            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc"}
+            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc", OP_MOMENTS: "mom"}
 
 # ---- autoregressive sampler (aew_actor_t / aew_sampler_t) ----
 ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMPLE = -1, 0, 1, 2, 3, 4, 5, 6
@@ -263,7 +268,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 12:
+    if lib.aew_abi_version() != 13:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

@@ -572,6 +572,46 @@ __global__ __launch_bounds__(1024) void k_reduce(const aew_reduce_t p) {
 }
 
 // =============================================================================================
+// mean / unbiased std of a channels-last view (gradient statistics of run(), autoencoder_model.py:252-257)
+// =============================================================================================
+__global__ __launch_bounds__(1024) void k_moments(const aew_moments_t p) {
+    // one block; thread e takes elements e, e+1024, ... of the (batch, row, col) index space; fp64 partial sums
+    // combined by a fixed tree -> deterministic and free of the cancellation of sum(x^2) - n mean^2 in fp32
+    __shared__ double sh[2][1024];
+    const int64_t per_b = (int64_t)p.rows * p.cols, n = per_b * p.batch;
+    double s = 0.0, q = 0.0;
+    for (int64_t e = threadIdx.x; e < n; e += 1024) {
+        const int b = (int)(e / per_b);
+        const int r = (int)((e - b * per_b) / p.cols), c = (int)(e - b * per_b - (int64_t)r * p.cols);
+        const int row = r * p.x.row_step + p.x.row_off;
+        if (row < p.x.row_lo || row >= p.x.row_hi) continue;                    // rows outside the view read as zero
+        const int64_t off = b * p.x.batch_stride + (int64_t)row * p.x.row_pitch + c;
+        const float v = p.x.dtype == AEW_BF16 ? bf2f(static_cast<const uint16_t*>(p.x.ptr)[off])
+                                              : static_cast<const float*>(p.x.ptr)[off];
+        s += (double)v;
+        q += (double)v * (double)v;
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double S = sh[0][0], Q = sh[1][0], mean = n > 0 ? S / (double)n : 0.0;
+        const double var = n > 1 ? fmax(Q - S * mean, 0.0) / (double)(n - 1) : 0.0;
+        p.out[0] = (float)mean;
+        p.out[1] = (float)sqrt(var);
+        p.out[2] = (float)S;
+        p.out[3] = (float)Q;
+    }
+}
+
+// =============================================================================================
 // Adam (torch.optim.Adam defaults; checkpoint.py:49-50), flat buffer, float4 vectorised
 // =============================================================================================
 __global__ void k_adam(const aew_adam_t a) {
@@ -1053,6 +1093,12 @@ static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
 static int launch_reduce(const aew_reduce_t& p, hipStream_t st) {
     if (p.n_terms < 1 || p.n_terms > 4) return AEW_E_ARG;
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, p);
+    return (int)hipGetLastError();
+}
+static int launch_moments(const aew_moments_t& p, hipStream_t st) {
+    if (!p.x.ptr || !p.out || p.rows < 0 || p.cols < 0 || p.batch < 0 || p.cols > p.x.row_pitch) return AEW_E_ARG;
+    if (p.x.dtype != AEW_BF16 && p.x.dtype != AEW_F32) return AEW_E_UNSUP;
+    hipLaunchKernelGGL(k_moments, dim3(1), dim3(1024), 0, st, p);
     return (int)hipGetLastError();
 }
 static int launch_adam(const aew_adam_t& p, hipStream_t st) {

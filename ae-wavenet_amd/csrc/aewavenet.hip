@@ -49,6 +49,7 @@ static int dispatch(const aew_op_t& op, hipStream_t st) {
         case AEW_OP_JITTER: return launch_jitter(op.u.jit, st);
         case AEW_OP_VQ_DIAG: return launch_vq_diag(op.u.diag, st);
         case AEW_OP_MFCC: return launch_mfcc(op.u.mfcc, st);
+        case AEW_OP_MOMENTS: return launch_moments(op.u.mom, st);
         default: return AEW_E_UNSUP;
     }
 }

@@ -246,6 +246,19 @@ class TrainEngine:
             self._red_index = len(fb.ops)
         red.out = self.loss_buf.data_ptr()
         fb.add(L.OP_REDUCE, red, "loss", TAG_LOSS)
+        # what run() reports next to the loss every step (chassis.py:266-270 tprb_m, the loss modules' `rec` / `com`):
+        # one more reduction op on a side lane instead of a handful of framework kernels behind the step
+        self.met_buf = ws.alloc("diag.metrics", 8, torch.float32)        # [1] rec, [2] tprb_m, [3] com
+        met = L.Reduce()
+        mterms = [(nll_ptr, B * w, 1.0 / n_pos), (self.dec.ptgt.data_ptr(), B * w, 1.0 / n_pos)]
+        if bn in ("vqvae-ema", "vqvae"):
+            mterms.append((self.min_dist.data_ptr(), self.Q, float(hps.bn_vq_gamma) / self.Q))
+        met.n_terms = len(mterms)
+        for i, (p_, n_, s_) in enumerate(mterms):
+            met.x[i], met.n[i], met.scale[i], met.post_scale[i] = p_, n_, s_, 1.0
+        met.out = self.met_buf.data_ptr()
+        with fb.side(1):
+            fb.add(L.OP_REDUCE, met, "metrics", TAG_LOSS)
         # per-step diagnostics the reference's loss modules report (vqema_bn.py:251-264): one fused reduction op,
         # off the critical chain
         self.diag = ws.alloc("diag.out", 16, torch.float32)
@@ -312,6 +325,17 @@ class TrainEngine:
                                          out1=self.enc.dpre[9].view(), aux1=self.enc.r[9].view(), impl=impl),
                    "d.bn.linear", TAG_VQ)
             self.enc.build_backward(bw, need_input_grad=True)
+        # gradient statistics of run() (autoencoder_model.py:252-257 mel_grad_sd / bn_grad_sd; mfcc_inverter.py:100-106
+        # mel_grad_sd / mel_grad_mean): by-products of this backward, reduced on a side lane
+        self.gstat = ws.alloc("diag.gstat", 8, torch.float32)            # [0:4] mel (mean, std, sum, sumsq), [4:8] bn
+        stats = [(self.enc.dy[0], self.n_mel, 0, "mel"), (self.dec.dlc_src, hps.bn_n_out, 4, "bn")] \
+            if self.enc is not None else [(self.dec.dlc_src, self.n_mel, 0, "mel")]
+        with bw.side(1):
+            for mat, cols, slot, nm in stats:
+                mo = L.Moments()
+                mo.x, mo.rows, mo.cols, mo.batch = mat.view(), mat.rows, cols, B
+                mo.out = self.gstat.data_ptr() + 4 * slot
+                bw.add(L.OP_MOMENTS, mo, f"grad stats ({nm})", TAG_LOSS)
         self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads the side-lane encoder wgrad slabs
         # Deferred EMA (data parallel): the EMA accumulators are not read again before the codebook
         # refresh, so the cross-rank sum of z_sum | n_sum can run asynchronously under the whole

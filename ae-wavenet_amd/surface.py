@@ -401,26 +401,32 @@ class HipModelBase(nn.Module):
             self._parameters[pname].grad = eng.ps.view(name, grad=True)
         if self._dp is not None and not self._dp.sharded:
             self._dp.allreduce_grads(eng)
+        # gradient statistics: AEW_OP_MOMENTS ops on a side lane of the backward plan (views, no kernels here)
         m = self.objective.metrics
+        gs = eng.gstat
         if self.kind == "autoencoder":
-            mg = eng.enc.dy[0].tensor()[:, :, :eng.n_mel].float()
-            m["mel_grad_sd"] = mg.std()
-            m["bn_grad_sd"] = eng.dec.dlc_src.tensor()[:, :, :self.hps.bn_n_out].std()
+            m["mel_grad_sd"], m["bn_grad_sd"] = gs[1], gs[5]
         else:
-            mg = eng.dec.dlc_src.tensor()[:, :, :eng.n_mel]
-            m["mel_grad_sd"], m["mel_grad_mean"] = mg.std(), mg.mean()
+            m["mel_grad_sd"], m["mel_grad_mean"] = gs[1], gs[0]
+
+    def _az_numel(self, eng):
+        key = (eng.serial,)
+        if getattr(self, "_az_cache", (None,))[0] != key:
+            n = [eng.B * eng.geom.enc_lens[i + 1] * self.hps.enc_n_out for i in range(9)]
+            self._az_cache = (key, torch.tensor(n, dtype=torch.float64, device=eng.enc.zero_cnt.device))
+        return self._az_cache[1]
 
     def _fill_forward_metrics(self, eng):
         w, B = eng.n_win, eng.B
         n_pos = B * (w - 1)
         m = self.objective.metrics
-        m["rec"] = eng.dec.nll[:B * w].sum() / n_pos
-        self.tprb_m = eng.dec.ptgt[:B * w].sum() / n_pos            # chassis.py:266-270
+        mb = eng.met_buf                                           # the "metrics" reduction op of the forward plan
+        m["rec"] = mb[1]
+        self.tprb_m = mb[2]                                        # chassis.py:266-270
         dg = eng.diag                                              # AEW_OP_VQ_DIAG: one fused reduction op per step
         m["pk_m"], m["pk_sd"], m["pk_nuq"] = dg[6], dg[7], dg[8]    # vqema_bn.py:261-263
         if eng.bn_type in ("vqvae-ema", "vqvae"):
-            md = eng.min_dist[:eng.Q]
-            m["com"] = (md * self.hps.bn_vq_gamma).mean()
+            m["com"] = mb[3]
             m["min_ze"], m["max_ze"], m["min_emb"], m["max_emb"] = dg[0], dg[1], dg[2], dg[3]   # vqema_bn.py:254-257
             if eng.bn_type == "vqvae-ema":
                 m["hst_ent"], m["nunq"] = dg[4], dg[5]              # vqema_bn.py:258-260
@@ -431,7 +437,6 @@ class HipModelBase(nn.Module):
         elif eng.bn_type == "ae":
             m["norm"] = eng.loss_buf[2]
         if eng.enc is not None and hasattr(self, "encoder"):
-            cnt = eng.enc.zero_cnt[:9].double()
+            az = eng.enc.zero_cnt[:9].double() / self._az_numel(eng)   # one division; the entries are views
             for i in range(9):
-                numel = B * eng.geom.enc_lens[i + 1] * self.hps.enc_n_out
-                self.encoder.metrics[f"enc_az_{i}"] = cnt[i] / numel
+                self.encoder.metrics[f"enc_az_{i}"] = az[i]

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 12
+#define AEW_ABI_VERSION 13
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -318,6 +318,15 @@ typedef struct {                 /* per-step diagnostics of the reference's loss
     float* out;                  /* [12]                                                       */
 } aew_vq_diag_t;
 
+typedef struct {                 /* first two moments of a channels-last view: the gradient statistics run() reports
+                                    every step (autoencoder_model.py:252-257 mel_grad_sd / bn_grad_sd,
+                                    mfcc_inverter.py:100-106 mel_grad_sd / mel_grad_mean), over x[b][m][0:cols],
+                                    b < batch, m < rows.  out[0] mean, out[1] unbiased std (torch.std), out[2] sum,
+                                    out[3] sum of squares.  One block, fp64 accumulation in a fixed order.       */
+    aew_view_t x; int32_t rows, cols, batch;
+    float* out;                  /* [4] */
+} aew_moments_t;
+
 typedef struct {                 /* column sums over rows: out[b][n] (+)= sum_m x[b][m][n]     */
     aew_seg_t x; int32_t dtype; int32_t M, N, batch;
     float* out; int64_t out_bs; int32_t accumulate;
@@ -390,7 +399,8 @@ enum {
     AEW_OP_GEMM_NT = 1, AEW_OP_GEMM_TN, AEW_OP_COPY_TABLE, AEW_OP_VQ_NEAREST, AEW_OP_VQ_STATS,
     AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
     AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
-    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG, AEW_OP_MFCC
+    AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG, AEW_OP_MFCC,
+    AEW_OP_MOMENTS
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
@@ -415,6 +425,7 @@ typedef struct {
         aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
         aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
         aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit; aew_vq_diag_t diag; aew_mfcc_t mfcc;
+        aew_moments_t mom;
     } u;
 } aew_op_t;
 

@@ -483,6 +483,13 @@ class Emu:
             o[6], o[7], o[8] = pk.mean(), pk.std(), am.unique().numel()
         self.wr(p.out, torch.arange(9), o)
 
+    def op_23(self, p):  # MOMENTS (gradient statistics of run(): autoencoder_model.py:252-257, mfcc_inverter.py:100-106)
+        m = torch.arange(p.rows)
+        x = torch.stack([self.vload(p.x, b, m, 0, p.cols) for b in range(p.batch)]).double()
+        n = x.numel()
+        o = torch.tensor([x.mean(), x.std() if n > 1 else 0.0, x.sum(), (x * x).sum()]) if n else torch.zeros(4)
+        self.wr(p.out, torch.arange(4), o.float())
+
 
 def emulate(eng):
     """Make a TrainEngine built on 'cpu' executable: every plan it would send to aew_run_plan goes through the

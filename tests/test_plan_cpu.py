@@ -99,6 +99,12 @@ def test_mfcc_inverter_plan(golden_dir, mode, tag):
     # d(loss)/d(mel) comes out of the jitter scatter (channels-last)
     mg = eng.dec.dlc_src.tensor()[:, :, :7].permute(0, 2, 1).numpy()
     close_dir(mode, mg, z["mel_grad"])
+    # the per-step statistics run() reports are plan ops too (AEW_OP_MOMENTS / the "metrics" reduction)
+    if "mel_grad_sd" in z:
+        assert abs(float(eng.gstat[1]) - float(z["mel_grad_sd"])) < tol(mode, 1e-6, 2e-2) * max(1.0, float(z["mel_grad_sd"]))
+    assert abs(float(eng.gstat[0]) - float(mg.mean())) < 1e-6 and abs(float(eng.gstat[1]) - float(mg.std(ddof=1))) < 1e-6
+    n_pos = eng.B * (eng.n_win - 1)
+    assert abs(float(eng.met_buf[1]) - float(eng.dec.nll.sum()) / n_pos) < 1e-5
 
 
 @pytest.mark.parametrize("jk,loss_mode,gtag,ltag", [("random", "intended", "gint", "loss_intended"),

@@ -90,6 +90,52 @@ def test_upstream_gradient_reaches_every_grad(bn):
     assert torch.allclose(m._engine.ps.grads[:n], g1, rtol=2e-4, atol=1e-7 * float(g1.abs().max()))
 
 
+@pytest.mark.parametrize("kind", ["vqvae-ema", "vae", "mfcc"])
+def test_step_metrics_come_from_the_plan(kind):
+    """rec / tprb_m / com / mel_grad_sd / bn_grad_sd / mel_grad_mean / enc_az are reduced by ops of the step's own
+    plans (side lanes); here they are held to the same reductions done with torch on the buffers they summarise."""
+    if kind == "mfcc":
+        from ae_wavenet_amd import mfcc_inverter as mi
+        hps = config.make_hps("mi", n_res=64, n_dil=32, n_skp=32, n_post=32, n_lc_out=16, n_win_batch=96, n_blocks=2,
+                              n_block_layers=3, n_global_embed=4, n_speakers=5)
+        torch.manual_seed(3)
+        m = mi.MfccInverter(hps).to(DEV)
+        g = m.geom
+        gen = torch.Generator().manual_seed(2)
+        n_mel = hps.n_lc_in
+        batch = (torch.randint(0, 256, (2, g.enc_in_len), generator=gen).float().to(DEV),
+                 torch.randn(2, n_mel, g.mel_len, generator=gen).to(DEV),
+                 torch.randint(0, 5, (2,), generator=gen).to(DEV), torch.arange(g.embed_len).repeat(2, 1).to(DEV))
+    else:
+        hps, m = _tiny(kind, bn_n_out=16 if kind == "vae" else 8)
+        batch = _batch(m, 2)
+    _, _, loss = m.run(*batch)
+    loss.backward()
+    torch.cuda.synchronize()
+    eng, mt = m._engine, m.objective.metrics
+    B, w = eng.B, eng.n_win
+    n_pos = B * (w - 1)
+
+    def close(a, b, tol=2e-5):
+        a, b = float(a), float(b)
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (a, b)
+    close(mt["rec"], eng.dec.nll[:B * w].double().sum() / n_pos)
+    close(m.tprb_m, eng.dec.ptgt[:B * w].double().sum() / n_pos)
+    if kind == "vqvae-ema":
+        close(mt["com"], (eng.min_dist[:eng.Q].double() * hps.bn_vq_gamma).mean())
+    if kind == "mfcc":
+        mg = eng.dec.dlc_src.tensor()[:, :, :eng.n_mel].double()
+        close(mt["mel_grad_sd"], mg.std())
+        close(mt["mel_grad_mean"], mg.mean(), 1e-6)
+    else:
+        close(mt["mel_grad_sd"], eng.enc.dy[0].tensor()[:, :, :eng.n_mel].double().std())
+        close(mt["bn_grad_sd"], eng.dec.dlc_src.tensor()[:, :, :hps.bn_n_out].double().std())
+        for i in range(9):
+            numel = B * eng.geom.enc_lens[i + 1] * hps.enc_n_out
+            close(m.encoder.metrics[f"enc_az_{i}"], float(eng.enc.zero_cnt[i]) / numel, 1e-9)
+    assert float(mt["mel_grad_sd"]) > 0
+
+
 def test_adam_state_survives_engine_rebuilds():
     from ae_wavenet_amd import optim
     hps, m = _tiny()
