@@ -259,6 +259,7 @@ def load():
     lib.aew_selftest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.aew_tn_slabs.argtypes = [C.c_void_p]
     lib.aew_tn_fold.argtypes = [C.c_void_p]
+    lib.aew_nt_kernel.argtypes = [C.c_void_p]
     lib.aew_graph_capture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.aew_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.aew_graph_destroy.argtypes = [C.c_void_p]
@@ -291,5 +292,5 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe",
            "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
            "aew_set_lanes", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
-           "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_rows192",
-           "aew_sampler_run", "aew_set_fn", "aew_set_tn_big")
+           "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nf_deep", "aew_set_nt_rows192",
+           "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big")

@@ -656,3 +656,20 @@ static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st) {
             return fn_launch<4, AEW_EPI_STORE, 0>(g, st);
     }
 }
+
+// Which kernel launch_gemm_nt runs for this descriptor under the current settings (bench.py / tools: per-kernel
+// rooflines are grouped by the kernel that ran, like a rocprofv3 kernel trace groups them by name).
+//   0 k_gemm_nt_bf16 (256- or 192-row tiles)   1 k_gemm_nt_bf16_p64 (64-row tiles: launches of few tiles)
+//   2 k_fn (full-N loader / consumer)          3 k_gemm_nt_f32        4 k_gemm_nt_check      5 an A/B shape
+extern "C" int aew_nt_kernel(const aew_gemm_nt_t* gp) {
+    if (!gp) return AEW_E_ARG;
+    const aew_gemm_nt_t& g = *gp;
+    if (g.impl == 1) return 4;
+    if (g.dtype != AEW_BF16) return 3;
+    if (g.impl == 2 && g_fn_enable_flag() && fn_supported(g)) return 2;
+    if (g_nt_wave_rows != 64) return 5;
+    bool zspan = true;
+    for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
+    const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
+    return (g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan) ? 1 : 0;
+}

@@ -940,9 +940,16 @@ __device__ __forceinline__ void p64_frags_ready(bf16x8_t (&wf)[4], bf16x8_t (&xf
 //                4 x 4 x 2 = 256 x 128 tile, 8 waves of 64 x 64, one block per CU (96 KiB)
 //                4 x 1 x 2 =  64 x 128 tile, 2 waves, three blocks per CU: launches with few rows (the
 //                            upsampler dgrads have 56 tiles of 256 rows for 256 CUs)
-template <int EPI, int MT, int WM, int WN>
+//   S = ring depth.  2: tile T+2 is issued one tile time ahead (the long-K shapes are MFMA-bound anyway).  The 64-row
+//   shape runs launches of a few dozen blocks whose K loop is pure DMA latency at depth 2 (36 tiles x ~1 us for the
+//   encoder dgrads against 0.2 us of MFMAs per tile); S = 5 keeps four tiles in flight (counted vmcnt).
+template <int N>
+__device__ __forceinline__ void p64_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, int MT, int WM, int WN, int S = 2>
 __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf16_p64(const aew_gemm_nt_t g) {
     typedef P64Cfg<MT, WM, WN> Cfg;
+    static_assert(S >= 2 && (S - 1) * Cfg::PIECES <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wm = wave / WN;
@@ -1009,9 +1016,9 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
             }
         }
     };
-    // prologue: tiles 0 and 1 in flight
+    // prologue: tiles 0 .. S-1 in flight
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < S; ++q) {
 #pragma unroll
         for (int j = 0; j < Cfg::PIECES; ++j) issue_piece(smem + q * Cfg::STAGE_BYTES, j);
         advance();
@@ -1029,10 +1036,7 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
         else P64_READ4(WF, XF, WA_, XA_);              \
     } while (0)
 
-    if (Cfg::PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tile 0 (mine) landed
-    else if (Cfg::PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (Cfg::PIECES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p64_wait_vm<(S - 1) * Cfg::PIECES>();                      // tile 0 (mine) landed
     __builtin_amdgcn_s_barrier();
     P64_READ(wA, xA, wlane, xlane);
     uint32_t cur = 0;                                          // byte offset of the stage holding tile T
@@ -1047,12 +1051,13 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) AEW_MFMA_BF16(acc[i][j], wA[i], xA[j]);
-        // ---- sub-step b: tile T+1 has landed, tile T is entirely in registers -> its stage is free
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- sub-step b: tile T+1 has landed (T+2 .. T+S-1 may be in flight), tile T is entirely in registers ->
+        // its stage is free
+        p64_wait_vm<(S - 2) * Cfg::PIECES>();
         p64_frags_ready<MT>(wB, xB);
         __builtin_amdgcn_s_barrier();
         char* freed = smem + cur;
-        cur = cur ? 0u : (uint32_t)Cfg::STAGE_BYTES;
+        cur = (cur + Cfg::STAGE_BYTES == (uint32_t)(S * Cfg::STAGE_BYTES)) ? 0u : cur + (uint32_t)Cfg::STAGE_BYTES;
         P64_READ(wA, xA, wlane + cur, xlane + cur);           // (T+1).a
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -1075,56 +1080,168 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
 }
 
 // =============================================================================================
-// NT kernel, fp32 (exact fmaf chain): block tile 16 (rows m) x 64 (channels n), BK = 32 floats,
-// 4 waves each 16 channels x 16 rows = ONE accumulator tile: the dependent MFMA chain over K is
-// the critical path of this weight-bandwidth-bound path (M = B*N_e is tiny), so the work is
-// spread over as many waves as possible.  One accumulator per output, K strictly ascending.
+// NT kernel, fp32 (exact fmaf chain): block tile 16*RT (rows) x 64 (channels), BK = 32 floats, 4 waves each
+// 16 channels x 16*RT rows = RT accumulator tiles.  One accumulator per output, K strictly ascending: the
+// dependent v_mfma_f32_16x16x4 chain over K is the floor of this path (M = B * N_e is tiny).
+// Rows are the batch folded into one axis (row R = b * M + m, resolved per row when the source pointers and the
+// epilogue rows are set up), so a tile may straddle windows and the 29..70-row windows of the encoder do not each
+// pad to a multiple of the tile.  What bounds the kernel is the operand stream: every row tile streams its 64-channel
+// slab of W (K x 256 B) through LDS, and at ~30 KB in flight per block the chip sustains ~7 TB/s of it whatever the
+// source (L2 or MALL: an XCD-local tile order changed nothing).  RT = 2 halves the number of times W is streamed and
+// gives each wave two independent chains; it is used when that still leaves enough blocks (launch_gemm_nt).
 // =============================================================================================
-#define NF_BM 16
 #define NF_BN 64
 #define NF_BK 32
-// 5 stages and TWO K tiles per barrier: the step is bound by its own chain (16 ds_read_b32 -> wait -> 8 dependent
-// v_mfma_f32_16x16x4 -> barrier), not by the LDS-DMA; with two tiles per iteration the 32 fragment reads go out
-// together and there is one barrier / one vmcnt wait per 64 channels of K.  The order of the chain is unchanged.
-#define NF_STAGES 5
-#define NF_STAGE_BYTES ((NF_BM + NF_BN) * 128)      // 10 KiB
-
-struct NfPtrs {
-    const char* x;                                   // waves 0,1 stage the two X pieces
-    const char* w[2];
-    int xinc;
+#ifndef AEW_FN_ABLATE
+#define AEW_FN_ABLATE 0           /* 1: tools library; switches in aew_gemm_nt_t.reserved (tools/f32_ablate.py) */
+#endif
+#define NF_ABL(g, bit) (AEW_FN_ABLATE && ((g).reserved & (bit)))   /* 1 no MFMA, 2 no operand DMA, 4 no fragment reads, 8 no epilogue, 16 no barrier */
+// Ring of S stages, TWO K tiles per barrier: the fragment reads of both go out together and there is one barrier / one
+// vmcnt wait per 64 channels of K; S - 2 tiles are in flight.  That depth is what matters: a K tile is 256 cycles of
+// MFMA per chain but ~3500 cycles of LDS-DMA latency on a loaded chip, and the rows are so few that a launch is 100-400
+// blocks - the bytes in flight per CU bound the operand stream (5 stages: 30 KB per block, ~7 TB/s chip-wide, 53 us for
+// the 1.9 GFLOP of encoder layer 1 whose chains alone are 15 us).  Launches of <= 256 blocks therefore take the whole
+// LDS of their CU (12-14 stages).  Past the last tile the ring is topped up from the zero page so that the counted
+// waits stay uniform.  The order of every chain is unchanged.
+template <int RT, int S>
+struct NfCfg {
+    static constexpr int BM = 16 * RT, STAGE_BYTES = (BM + NF_BN) * 128, LDS_BYTES = S * STAGE_BYTES;
+    static_assert(S >= 4 && (S - 2) * 3 <= 63 && LDS_BYTES <= 160 * 1024, "ring depth");
 };
 
-__device__ __forceinline__ void nf_setup_x(const aew_gemm_nt_t& g, int seg, int b, int m0, int wave, int lane,
-                                           NfPtrs& P) {
-    // 80 staged rows = 10 pieces of 8 rows: pieces 0,1 = X (waves 0,1), 2..9 = W (two per wave)
+struct NfPtrs {
+    const char* x;
+    const char* w[2];
+    int xinc, winc;
+};
+
+template <int RT>
+__device__ __forceinline__ void nf_setup_x(const aew_gemm_nt_t& g, int seg, int R0, int wave, int lane, NfPtrs& P) {
+    // staged rows = 2 RT + 8 pieces of 8 rows: the X pieces, then W (two per wave).  EVERY wave stages an X piece
+    // (RT = 1: waves 2, 3 write pieces 0, 1 a second time - same bytes, same place): all waves then run the same
+    // instruction stream with the same vmcnt, and a taken branch costs this loop ~40 cycles (tools/f32_ablate.py)
     const int lr = lane >> 3, pc = lane & 7;
-    const int r = (wave & 1) * 8 + lr;
+    const int r = (wave & (2 * RT - 1)) * 8 + lr;
+    const int R = R0 + r, bb = min(R / g.M, g.batch - 1);
     const aew_seg_t s = g.seg[seg];
     bool ok;
-    const char* src = seg_row_ptr_sel(s, b, m0 + r, 4, ok) + (nt_swz(r, pc) << 4);
+    const char* src = seg_row_ptr_sel(s, bb, R - bb * g.M, 4, ok) + (nt_swz(r, pc) << 4);
+    ok = ok && R < g.M * g.batch;
     P.x = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
     P.xinc = ok ? NF_BK * 4 : 0;
 }
 
+template <int RT>
 __device__ __forceinline__ void nf_issue(char* stage, int wave, NfPtrs& P) {
-    if (wave < 2) {
-        glds16(P.x, stage + wave * 1024);
-        P.x += P.xinc;
-    }
+    glds16(P.x, stage + (wave & (2 * RT - 1)) * 1024);
+    P.x += P.xinc;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        glds16(P.w[j], stage + NF_BM * 128 + (wave + 4 * j) * 1024);
-        P.w[j] += NF_BK * 4;
+        glds16(P.w[j], stage + 16 * RT * 128 + (wave + 4 * j) * 1024);
+        P.w[j] += P.winc;
     }
 }
 
+// Fragments.  v_mfma_f32_16x16x4_f32 takes k = 4 s + kq from lane (fi, kq = lane >> 4) at step s.  Reading that with
+// ds_read_b32 costs 16 LDS instructions per K tile and wave for 8 MFMAs, and b32 reads of 16 rows x 16 bytes run at
+// ~4.5 cycles each (2-way bank conflict at 16-byte granularity; tools/ubench/nf_prims): the LDS pipe was as busy as the
+// MFMA pipe.  Instead lane (fi, kq) reads the 16-byte chunk 4 j + kq of its row (k = 16 j + 4 kq + e in register e:
+// 2 ds_read_b128 per operand and K tile) and a 4 x 4 transpose between register index and 16-lane group puts
+// k = 16 j + 4 s + kq into register s: two v_permlane32_swap and two v_permlane16_swap per chunk, on the otherwise idle
+// VALU.  The MFMAs see exactly the operands they saw before - same chain, same order.
+__device__ __forceinline__ void nf_tr(f32x4_t& v) {
+    // (elements go through named floats: __builtin_bit_cast applied directly to an ext-vector element lvalue reads
+    // element 0 for every index with this compiler - ROCm 7.2 clang)
+    const float f0 = v[0], f1 = v[1], f2 = v[2], f3 = v[3];
+    unsigned a = __float_as_uint(f0), b = __float_as_uint(f1), c = __float_as_uint(f2), d = __float_as_uint(f3);
+    auto r = __builtin_amdgcn_permlane32_swap(a, c, false, false);   // lanes 32-63 of a <-> lanes 0-31 of c
+    a = r[0]; c = r[1];
+    r = __builtin_amdgcn_permlane32_swap(b, d, false, false);
+    b = r[0]; d = r[1];
+    r = __builtin_amdgcn_permlane16_swap(a, b, false, false);        // odd 16-lane rows of a <-> even rows of b
+    a = r[0]; b = r[1];
+    r = __builtin_amdgcn_permlane16_swap(c, d, false, false);
+    c = r[0]; d = r[1];
+    v = (f32x4_t){__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d)};
+}
+
+template <int RT>
+struct NfFrag {
+    f32x4_t w[2], x[RT][2];                                  // chunk group j = 0, 1 of the K tile
+};
+
+#define NF_DS_READ16(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory")
+
+template <int RT>
+__device__ __forceinline__ void nf_read(NfFrag<RT>& F, uint32_t wl, uint32_t xl) {
+    NF_DS_READ16(F.w[0], wl);
+    NF_DS_READ16(F.x[0][0], xl);
+    if constexpr (RT == 2) NF_DS_READ16(F.x[1][0], xl + 2048u);
+    NF_DS_READ16(F.w[1], wl ^ 64u);
+    NF_DS_READ16(F.x[0][1], xl ^ 64u);
+    if constexpr (RT == 2) NF_DS_READ16(F.x[1][1], (xl + 2048u) ^ 64u);
+}
+
+template <int RT>
+__device__ __forceinline__ void nf_ready(NfFrag<RT>& F) {
+    if constexpr (RT == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F.w[0]), "+v"(F.w[1]), "+v"(F.x[0][0]), "+v"(F.x[0][1]), "+v"(F.x[1][0]), "+v"(F.x[1][1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F.w[0]), "+v"(F.w[1]), "+v"(F.x[0][0]), "+v"(F.x[0][1]));
+}
+
+template <int RT>
+__device__ __forceinline__ void nf_transpose(NfFrag<RT>& F) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        nf_tr(F.w[j]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) nf_tr(F.x[r][j]);
+    }
+}
+
+// The 8 (x RT) MFMAs of a K tile as ONE asm block: an issue slot between two MFMAs on the same accumulator costs ~43
+// cycles (MI355X_MICROARCH.md), and left to itself the compiler threads the transposes of the next fragments between
+// them.  k = 16 j + 4 e + kq: ascending.
+__device__ __forceinline__ void nf_mfma8(f32x4_t& acc, const f32x4_t& w0, const f32x4_t& x0, const f32x4_t& w1, const f32x4_t& x1) {
+    const float a0 = w0[0], a1 = w0[1], a2 = w0[2], a3 = w0[3], a4 = w1[0], a5 = w1[1], a6 = w1[2], a7 = w1[3];
+    const float b0 = x0[0], b1 = x0[1], b2 = x0[2], b3 = x0[3], b4 = x1[0], b5 = x1[1], b6 = x1[2], b7 = x1[3];
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %9, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %6, %14, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %7, %15, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %8, %16, %0"
+                 : "+a"(acc)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7),
+                   "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7));
+}
+
+template <int RT>
+__device__ __forceinline__ void nf_chain(NfFrag<RT>& F, f32x4_t (&acc)[RT], bool skip_mfma) {
+    if (skip_mfma) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) asm volatile("" ::"v"(F.w[0]), "v"(F.w[1]), "v"(F.x[r][0]), "v"(F.x[r][1]));
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) nf_mfma8(acc[r], F.w[0], F.x[r][0], F.w[1], F.x[r][1]);
+}
+
+template <int RT, int S>
 __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef NfCfg<RT, S> Cfg;
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * NF_BM, n0 = blockIdx.y * NF_BN, b = blockIdx.z;
+    const int rows = g.M * g.batch, n_rt = (rows + Cfg::BM - 1) / Cfg::BM;
+    const int nt_i = blockIdx.x / n_rt;
+    const int R0 = (blockIdx.x - nt_i * n_rt) * Cfg::BM, n0 = nt_i * NF_BN;
     const int nkt = g.K_total / NF_BK;
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     NfPtrs P;
     {
         const int lr = lane >> 3, pc = lane & 7;
@@ -1134,81 +1251,79 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
             const int r = (wave + 4 * j) * 8 + lr;
             P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 4 + (nt_swz(r, pc) << 4);
         }
+        P.winc = NF_BK * 4;
     }
-    int seg = 0, left = g.seg[0].k_len / NF_BK, slot = 0;      // left = K tiles still to issue from `seg`
-    nf_setup_x(g, 0, b, m0, wave, lane, P);
+    const bool no_mfma = NF_ABL(g, 1), no_dma = NF_ABL(g, 2), no_reads = NF_ABL(g, 4), no_barrier = NF_ABL(g, 16),
+               no_tr = NF_ABL(g, 32), no_issue = NF_ABL(g, 64), no_wait = NF_ABL(g, 128);
+    int seg = 0, left = g.seg[0].k_len / NF_BK, issued = 0;      // left = K tiles still to issue from `seg`
+    uint32_t slot = 0;                                           // byte offset of the stage the next tile goes to
+    nf_setup_x<RT>(g, 0, R0, wave, lane, P);
     auto issue_next = [&]() {
-        if (left == 0) {                                       // the only scalar loads of the K loop
-            ++seg;
-            left = g.seg[seg].k_len / NF_BK;
-            nf_setup_x(g, seg, b, m0, wave, lane, P);
+        if (__builtin_expect(left == 0, 0)) {                  // the only scalar loads of the K loop
+            if (issued >= nkt) {                               // K exhausted: keep the ring (and vmcnt) uniform
+                P.x = P.w[0] = P.w[1] = reinterpret_cast<const char*>(aew_zero_page);
+                P.xinc = P.winc = 0;
+                left = 1 << 30;
+            } else {
+                ++seg;
+                left = g.seg[seg].k_len / NF_BK;
+                nf_setup_x<RT>(g, seg, R0, wave, lane, P);
+            }
         }
-        nf_issue(smem + slot * NF_STAGE_BYTES, wave, P);
-        slot = (slot + 1 == NF_STAGES) ? 0 : slot + 1;
+        if (!no_dma) nf_issue<RT>(smem + slot, wave, P);
+        slot = (slot + Cfg::STAGE_BYTES == (uint32_t)Cfg::LDS_BYTES) ? 0u : slot + Cfg::STAGE_BYTES;
         --left;
+        ++issued;
     };
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (i < nkt) issue_next();                               // tiles 0, 1, 2
+    for (int i = 0; i < S - 1; ++i) issue_next();                // tiles 0 .. S-2
     const int fi = lane & 15, kq = lane >> 4;
-    const int rw = wave * 16 + fi;
-    int stage = 0;
-    auto tile = [&](const char* xs) {                            // one K tile: 8 MFMA steps of the chain, k ascending
-        const char* ws = xs + NF_BM * 128;
-        float wv[8], xv[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            wv[ks] = *reinterpret_cast<const float*>(ws + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
-            xv[ks] = *reinterpret_cast<const float*>(xs + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], xv[ks], acc, 0, 0, 0);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem);
+    // lane (fi, kq) reads chunk kq (j = 0) / 4 + kq (j = 1: address ^ 64) of its rows; stages are multiples of 128 bytes
+    const uint32_t xlane = lds0 + fi * 128 + (nt_swz(fi, kq) << 4);
+    const uint32_t wlane = lds0 + Cfg::BM * 128 + (wave * 16 + fi) * 128 + (nt_swz(fi, kq) << 4);
+    NfFrag<RT> A, B;
+    p64_wait_vm<(S - 2) * 3>();
+    __builtin_amdgcn_s_barrier();
+    nf_read<RT>(A, wlane, xlane);
+    nf_ready<RT>(A);
+    nf_transpose<RT>(A);
+    uint32_t cur = 0;                                            // stage of tile T
+    // Per K tile T: [tile T+1 landed] barrier -> stage of T-1 is free: top the ring up into it -> start the reads of
+    // T+1 -> chain of T (its fragments were read and transposed one step earlier) -> wait for T+1, transpose it.
+    // (the wait closes the step: registers an asm read is still filling must not be live across the loop's back
+    // edge, where the compiler is free to copy them)
+    auto step = [&](NfFrag<RT>& F, NfFrag<RT>& Nx) {
+        if (!no_wait) p64_wait_vm<(S - 3) * 3>();
+        if (!no_barrier) __builtin_amdgcn_s_barrier();
+        if (!no_issue) issue_next();
+        cur = (cur + Cfg::STAGE_BYTES == (uint32_t)Cfg::LDS_BYTES) ? 0u : cur + Cfg::STAGE_BYTES;
+        if (!no_reads) nf_read<RT>(Nx, wlane + cur, xlane + cur);
+        nf_chain<RT>(F, acc, no_mfma);
+        if (!no_reads) nf_ready<RT>(Nx);
+        if (!no_tr) nf_transpose<RT>(Nx);
     };
-    for (int t = 0; t < nkt; t += 2) {
-        // tiles t and t+1 have landed once only tile t+2 (issued last) may be outstanding: 3 loads on waves 0,1
-        // (X piece + two W pieces), 2 on waves 2,3
-        if (t + 2 < nkt) {
-            if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 3 < nkt) issue_next();                           // into the stages of tiles t-2, t-1: every wave is past them
-        if (t + 4 < nkt) issue_next();
-        const char* x0 = smem + stage * NF_STAGE_BYTES;
-        stage = (stage + 1 == NF_STAGES) ? 0 : stage + 1;
-        const char* x1 = smem + stage * NF_STAGE_BYTES;
-        stage = (stage + 1 == NF_STAGES) ? 0 : stage + 1;
-        if (t + 1 < nkt) {
-            const char* w0 = x0 + NF_BM * 128;
-            const char* w1 = x1 + NF_BM * 128;
-            float wv[16], xv[16];                                // both tiles' fragments in flight at once
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                wv[ks] = *reinterpret_cast<const float*>(w0 + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
-                xv[ks] = *reinterpret_cast<const float*>(x0 + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                wv[8 + ks] = *reinterpret_cast<const float*>(w1 + rw * 128 + (nt_swz(rw, ks) << 4) + kq * 4);
-                xv[8 + ks] = *reinterpret_cast<const float*>(x1 + fi * 128 + (nt_swz(fi, ks) << 4) + kq * 4);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], xv[ks], acc, 0, 0, 0);
-        } else {
-            tile(x0);                                            // odd tile count: the last one alone
-        }
+    for (int t = 0; t + 1 < nkt; t += 2) {
+        step(A, B);
+        step(B, A);
     }
+    if (nkt & 1) step(A, B);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the top-up loads still target this block's LDS
     unsigned zc = 0;
-    {
-        const int m = m0 + fi;
+    const EpiUni U = epi_uni(g);
+    if (NF_ABL(g, 8)) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) asm volatile("" ::"v"(acc[r]));
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int R = R0 + 16 * r + fi;
         const int n = n0 + wave * 16 + 4 * kq;
-        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-        if (m < g.M && n < g.N) {
-            const EpiRow R = epi_row(g, b, m);
-            epi_store<4>(g, epi_uni(g), R, b, n, v, zc, g.flags);
+        float v[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+        if (R < rows && n < g.N) {
+            const int bb = R / g.M, m = R - bb * g.M;
+            const EpiRow Rw = epi_row(g, bb, m);
+            epi_store<4>(g, U, Rw, bb, n, v, zc, g.flags);
         }
     }
     if (g.flags & AEW_EF_COUNT_ZERO) {
@@ -1769,6 +1884,8 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
 static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kernel
 static int g_nt_rows192 = 1;      // default shape: 0 never, 1 cost model, 2 always use 192-row tiles
+static int g_nf_deep = 256;         // fp32 NT: launches of <= this many blocks get one block per CU and a 12-14 stage ring
+static int g_nt_small_deep = 256;   // 64-row launches of <= this many blocks (one per CU) use the 5-stage ring (120 KiB)
 static int g_nt_small_tiles = 128; // default shape: launches of <= this many 256x128 tiles use 64-row tiles
 static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 128 = 4 fat waves (128x64), both on
                                    // 256x128 tiles; 256 = 8 fat waves on 256x256 tiles where N_pad allows
@@ -1787,6 +1904,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), (P64Cfg<4, 2, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 4, 2>), (P64Cfg<4, 4, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), (P64Cfg<4, 1, 2>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 1, 2, 5>), (5 * P64Cfg<4, 1, 2>::STAGE_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 1>), (NtCfg<8, 1>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
@@ -1801,7 +1919,9 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8, 2>), (NtCfg<8, 2>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
 #undef AEW_SET_NT
-    AEW_SET_LDS(k_gemm_nt_f32, NF_STAGES * NF_STAGE_BYTES)
+    AEW_SET_LDS((k_gemm_nt_f32<1, 7>), (NfCfg<1, 7>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<1, 14>), (NfCfg<1, 14>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<2, 12>), (NfCfg<2, 12>::LDS_BYTES))
     AEW_SET_LDS(k_gemm_tn_bf16_big, TNB_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
@@ -1919,6 +2039,8 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     do {                                                                                                      \
         if (!ABL && t192)                                                                                      \
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), grid, dim3((NtCfg<3, 1, 192>::THREADS)), (NtCfg<3, 1, 192>::LDS_BYTES), st, g); \
+        else if (!ABL && p64r && (int)grid.x <= g_nt_small_deep)                                               \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 1, 2, 5>), grid, dim3(128), (5 * P64Cfg<4, 1, 2>::STAGE_BYTES), st, g); \
         else if (!ABL && p64r)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), grid, dim3(128), (P64Cfg<4, 1, 2>::LDS_BYTES), st, g); \
         else if (!ABL && p256)                                                                                 \
@@ -1952,8 +2074,17 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     } else {
         const int rc = ensure_big_lds();
         if (rc) return rc;
-        dim3 grid((g.M + NF_BM - 1) / NF_BM, g.N_pad / NF_BN, g.batch);
-        hipLaunchKernelGGL(k_gemm_nt_f32, grid, dim3(256), NF_STAGES * NF_STAGE_BYTES, st, g);
+        // shape by block count (see the kernel's header): one block per CU with the whole LDS as ring where the launch
+        // is that small - 16-row tiles first (more, shorter chains), else 32-row tiles - and the 3-blocks-per-CU shape
+        // for anything larger
+        const int rows = g.M * g.batch, n_nt = g.N_pad / NF_BN;
+        const int tiles1 = ((rows + 15) / 16) * n_nt, tiles2 = ((rows + 31) / 32) * n_nt;
+        if (g_nf_deep && tiles1 <= g_nf_deep)
+            hipLaunchKernelGGL((k_gemm_nt_f32<1, 14>), dim3(tiles1), dim3(256), (NfCfg<1, 14>::LDS_BYTES), st, g);
+        else if (g_nf_deep && tiles2 <= g_nf_deep)
+            hipLaunchKernelGGL((k_gemm_nt_f32<2, 12>), dim3(tiles2), dim3(256), (NfCfg<2, 12>::LDS_BYTES), st, g);
+        else
+            hipLaunchKernelGGL((k_gemm_nt_f32<1, 7>), dim3(tiles1), dim3(256), (NfCfg<1, 7>::LDS_BYTES), st, g);
     }
     return (int)hipGetLastError();
 }

@@ -249,6 +249,8 @@ extern "C" int aew_sampler_run(const aew_sampler_t* s, void* stream) {
 }
 extern "C" int aew_set_nt_rows192(int mode) { g_nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n; return 0; }
+extern "C" int aew_set_nf_deep(int max_blocks) { g_nf_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
+extern "C" int aew_set_nt_small_deep(int max_blocks) { g_nt_small_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
 extern "C" int aew_set_nt_pipe(int mode) { g_nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_wave_rows(int rows) {
     if (rows != 0 && rows != 1 && rows != 64 && rows != 128 && rows != 256) return AEW_E_ARG;

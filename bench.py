@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--nt-rows192", dest="nt_rows192", type=int, default=-1, help="192-row NT tiles: 0 never, 1 cost model, 2 always")
     ap.add_argument("--nt-small", dest="nt_small", type=int, default=-1, help="tile-count threshold for 64-row NT tiles")
     ap.add_argument("--side-lanes", dest="side_lanes", type=int, default=0, help="side lanes the wgrads rotate over (1..4)")
+    ap.add_argument("--nt-deep", dest="nt_deep", type=int, default=-1, help="64-row NT launches of <= this many blocks use the 5-stage ring")
+    ap.add_argument("--nf-deep", dest="nf_deep", type=int, default=-1, help="fp32 NT: launches of <= this many blocks use the deep ring (0 never)")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     ap.add_argument("--engine-only", action="store_true", help="headline = the engine-level step (no module surface / loader)")
     return ap.parse_args()
@@ -158,7 +160,7 @@ def pmc_traffic():
             import csv
             n = tot = 0.0
             for r in csv.DictReader(open(path)):
-                if "k_gemm_nt_bf16" in r["kernel"]:
+                if "k_gemm_nt_bf16<" in r["kernel"]:               # the tiled kernel only (not _p64 / k_fn)
                     k = float(r["launches"])
                     n += k
                     tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
@@ -211,6 +213,10 @@ def main():
         lib.aew_set_nt_rows192(args.nt_rows192)
     if args.nt_small >= 0:
         lib.aew_set_nt_small_tiles(args.nt_small)
+    if args.nf_deep >= 0:
+        lib.aew_set_nf_deep(args.nf_deep)
+    if args.nt_deep >= 0:
+        lib.aew_set_nt_small_deep(args.nt_deep)
     if args.tn_blocks:
         lib.aew_set_tn_target_blocks(args.tn_blocks)
     if os.environ.get("AEW_TNB") is not None:                    # A/B aid: big-tile wgrad kernel off (0) / split-K block target
@@ -315,19 +321,50 @@ def main():
                 for lab, v in sorted(per.items(), key=lambda kv: -kv[1]):
                     fh.write(f"{v:9.4f}  {lab}\n")
         fl = eng.flops_per_step()
-        # forward + dgrad of the gated stack / post network run on the bf16 NT kernels (k_gemm_nt_bf16 and, for the
-        # long-K multi-segment GEMMs, k_fn), wgrad on the bf16 TN kernel  (90.4 MFLOP per output sample per step)
+        # Forward + dgrad of the gated stack / post network run on the bf16 NT kernels, wgrad on the bf16 TN kernel
+        # (90.4 MFLOP per output sample per step, 2/3 of it NT).  The NT work is spread over three kernels -
+        # k_gemm_nt_bf16 (the dominant one: 256- / 192-row tiles), k_gemm_nt_bf16_p64 (64-row tiles for launches of a
+        # few tiles: upsampler, encoder dgrad, ...) and k_fn (the two 20-segment GEMMs) - so times are grouped by the
+        # kernel each op dispatches to (aew_nt_kernel), the way a rocprofv3 kernel trace groups them by name, and the
+        # algorithmic NT FLOPs are apportioned by the FLOPs the descriptors execute (padding is near-uniform).
+        plans = [eng.fwd_a, eng.fwd_b, eng.bwd] + ([eng.cb] if hasattr(eng, "cb") else []) + [eng.opt]
+        ops_all = [op for pl in plans for op in pl.ops]
+        KNAME = {0: "k_gemm_nt_bf16", 1: "k_gemm_nt_bf16_p64", 2: "k_fn"}
+        byk = {k: {"ms": 0.0, "launches": 0, "exec_flops": 0.0} for k in KNAME}
+        for i in range(min(cnt.value, cap)):
+            op = ops_all[i % len(ops_all)]
+            if op.kind != L.OP_GEMM_NT or op.u.nt.dtype != L.BF16:
+                continue
+            g = op.u.nt
+            kid = lib.aew_nt_kernel(C.byref(g))
+            if kid not in byk:
+                continue
+            ex = 2.0 * g.M * g.batch * g.N_pad * g.K_total + (2.0 * g.M * g.batch * g.N2_pad * (g.N_pad // 2) if g.W2 else 0.0)
+            byk[kid]["ms"] += ms[i] / n_t
+            byk[kid]["launches"] += 1
+            byk[kid]["exec_flops"] += ex / n_t
         nt_flops, nt_ms = fl["step"] * 2.0 / 3.0, cls_ms.get(1, 0.0)
-        n_launch = max(cls_n.get(1, 0) // n_t, 1)
-        achieved = nt_flops / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
+        ex_all = sum(v["exec_flops"] for v in byk.values()) or 1.0
+        for k, v in byk.items():
+            v["launches"] //= n_t
+            v["alg_flops"] = nt_flops * v["exec_flops"] / ex_all
+            v["tflops"] = v["alg_flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+        dom = byk[0]
+        n_launch = max(dom["launches"], 1)
+        achieved = dom["tflops"]
         traffic, src = pmc_traffic()
         roof = {"bound": "mfma", "kernel": "k_gemm_nt_bf16", "achieved": round(achieved, 2), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": traffic,
-                "launches_per_step": n_launch, "avg_launch_ms": round(nt_ms / n_launch, 5),
-                "alg_flops_per_launch": nt_flops / n_launch,
+                "launches_per_step": n_launch, "avg_launch_ms": round(dom["ms"] / n_launch, 5),
+                "alg_flops_per_launch": dom["alg_flops"] / n_launch,
+                "by_kernel": {KNAME[k]: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+                                         "tflops": round(v["tflops"], 1)} for k, v in byk.items()},
+                "all_bf16_nt": {"achieved": round(nt_flops / (nt_ms * 1e-3) / 1e12, 2) if nt_ms > 0 else 0.0,
+                                "launches": max(cls_n.get(1, 0) // n_t, 1), "ms_per_step": round(nt_ms, 4)},
                 "tn_bf16": {"achieved": round((fl["step"] / 3.0) / (cls_ms.get(2, 1e9) * 1e-3) / 1e12, 2),
                             "ms_per_step": round(cls_ms.get(2, 0.0), 4)},
                 "ms_per_step_by_class": {str(k): round(v, 4) for k, v in sorted(cls_ms.items())}}
+        nt_ms = dom["ms"]
         # the same launches against the HBM roofline: measured bytes per launch (PMC) / measured time per launch.  At
         # K = 256..1024 with 3-4 activation tensors in and out the stack's intensity (~240 FLOP/B) is below the ridge
         # (2500 / 8 = 312), see profiles/r01_op_roofline.txt

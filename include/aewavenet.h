@@ -461,8 +461,20 @@ int aew_set_nt_pipe(int on);
 /* impl = 2 descriptors (full-N kernels, aew_fn.hip): 1 (default) use them where the shape is covered, 0 run every
  * impl = 2 descriptor on the tiled kernels instead (A/B and bisecting aid; same results). */
 int aew_set_fn(int on);
+/* Which kernel a GEMM_NT descriptor dispatches to under the current settings: 0 k_gemm_nt_bf16 (256- / 192-row tiles),
+ * 1 k_gemm_nt_bf16_p64 (64-row tiles, small launches), 2 k_fn, 3 k_gemm_nt_f32, 4 the scalar check kernel, 5 an A/B
+ * shape.  Measurement aid: lets a caller group per-op times by kernel the way a rocprofv3 kernel trace does. */
+int aew_nt_kernel(const aew_gemm_nt_t* g);
 /* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
 int aew_set_nt_small_tiles(int n);
+/* ... and of those, launches of <= max_blocks blocks (default 256: one block per CU) run a 5-stage operand ring
+ * instead of 2 stages: their K loop is DMA latency, not MFMA (0 = never; same results). */
+int aew_set_nt_small_deep(int max_blocks);
+/* fp32 NT kernel: launches of <= max_blocks blocks (default 256 = one per CU) run with a 12-14 stage operand ring
+ * (the whole LDS of the CU; 16-row tiles if that fits the limit, else 32-row tiles), larger ones with 5 stages and
+ * three blocks per CU.  0 = always the 5-stage shape.  The chains themselves - one per output, k ascending - do not
+ * change (bit-identical results). */
+int aew_set_nf_deep(int max_blocks);
 /* default NT shape only: 192 x 128 tiles (8 waves of 48x64) instead of 256 x 128 — 0 never, 1 (default) where the
  * per-CU cost model prefers them, 2 always.  Results are bit-identical either way. */
 int aew_set_nt_rows192(int mode);
