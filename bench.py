@@ -2,12 +2,14 @@
 """bench.py — 16 kHz audio samples / second / training step of the VQ-VAE-EMA WaveNet
 autoencoder (par/arch.vqvae-ema.json shape) on N MI355X, data-parallel.
 
-A step (chassis.py:131-171) = a fresh batch from pinned host memory through the device prefetcher ->
-`model.run(wav, mel, voice, jitter)` -> `loss.backward()` -> `FusedAdam.step()` (gradient / EMA-statistic collectives
-inside for N > 1), on the drop-in module surface (autoencoder_model.AutoEncoder), over one batch of 8 windows x 5000
-output samples per GPU (BASELINE.json configs[1]; weak scaling), synthetic data, random-init weights.  The headline
-`value` is that step.  `engine_only` repeats the measurement below the module surface (TrainEngine forward / backward /
-adam on one resident batch: round 1's number).
+A step (chassis.py:151-171) = `model.run(wav, mel, voice, jitter)` -> `loss.backward()` ->
+`FusedAdam.step()` (gradient / EMA-statistic collectives inside for N > 1) on the drop-in module surface
+(autoencoder_model.AutoEncoder), over one batch of 8 windows x 5000 output samples per GPU (BASELINE.json configs[1];
+weak scaling), synthetic data, random-init weights.  The headline `value` is that step with the batches (a pool of 8
+distinct ones, jitter indices included) already resident in HBM, as the contract asks.  `host_fed` is the same step fed
+from pinned host memory through the device prefetcher (H2D on a copy stream, jitter generated on the device): the
+PCIe-inclusive rate, reported beside `value`.  `engine_only` repeats the measurement below the module surface
+(TrainEngine forward / backward / adam on one resident batch: round 1's number).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus N ...          # spawns N ranks itself (torch.distributed.run) when WORLD_SIZE is unset
@@ -251,7 +253,26 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the step through the boundary ----------------------------------------------------------------------
+    # `value`: inputs already resident in HBM when the timed region starts (the bench contract; the reference's run()
+    # takes device tensors too, chassis.py:151-171) - a pool of distinct batches with their jitter indices.
+    # `host_fed`: the same step fed from pinned host batches through the prefetcher (PCIe-inclusive; never `value`).
+    jit = DeviceJitter(args.jitter_prob, seed=99 + rank)
+    src = host_batches(model, args.batch, rank)
+    resident = []
+    for _ in range(8):
+        wav, mel, voice, _none = next(src)
+        resident.append((wav.to(device), mel.to(device), voice.to(device), jit(args.batch, mel.shape[2], device)))
+    cursor = [0]
+
     def step():
+        wav, mel, voice, jitter = resident[cursor[0] % len(resident)]
+        cursor[0] += 1
+        opt.zero_grad()
+        pred, target, loss = model.run(wav, mel, voice, jitter)
+        loss.backward()
+        opt.step()
+
+    def host_step():
         wav, mel, voice, jitter = next(loader)
         opt.zero_grad()
         pred, target, loss = model.run(wav, mel, voice, jitter)
@@ -285,6 +306,7 @@ def main():
     dt = timed(head_fn)
     loss_val = float(eng.loss_buf[0])
     dt_other = timed(other_fn)
+    dt_host = timed(host_step)
 
     # ---- per-kernel timing for the roofline (outside the timed region) ----------------------
     roof = None
@@ -395,8 +417,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "VQ-VAE-EMA (arch.vqvae-ema shape: 2x10 gated layers, 368 res / 256 dil "
                                    "/ 256 skip, K=4096 d=32) fwd+bwd+Adam",
-                       "timed_region": {"boundary": "pinned host batch -> DevicePrefetcher (H2D copy stream, jitter on the device) "
-                                                    "-> AutoEncoder.run -> loss.backward() -> FusedAdam.step()",
+                       "timed_region": {"boundary": "AutoEncoder.run(device tensors) -> loss.backward() -> FusedAdam.step(), batches resident in HBM",
                                         "engine": "TrainEngine.forward / backward / adam_step on one resident batch"}[names[0]],
                        "global_batch": n_ranks * args.batch, "n_win_batch": args.n_win, "jitter_prob": args.jitter_prob,
                        "parallelism": f"dp{n_ranks}" + ("" if n_ranks == 1 else (" reduce-scatter + sharded Adam + all-gather" if sharded else " all-reduce")
@@ -405,6 +426,9 @@ def main():
                        "decoder": "bf16 MFMA, fp32 accumulate", "encoder_vq": "fp32 MFMA exact chain (forward), bf16 MFMA (backward)"},
             names[1] + "_only" if names[1] == "engine" else "through_boundary":
                 {"ms_per_step": 1e3 * dt_other / args.steps, "value": samples / dt_other, "unit": "samples/s"},
+            "host_fed": {"ms_per_step": 1e3 * dt_host / args.steps, "value": samples / dt_host, "unit": "samples/s",
+                         "path": "pinned host batch -> DevicePrefetcher (H2D on a copy stream, jitter generated on the device) -> the "
+                                 "same step: PCIe-inclusive, reported beside `value`, never as it"},
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_ms_by_tag": {str(k): round(v, 4) for k, v in sorted(kern.items())},
         }
