@@ -199,11 +199,11 @@ def _real_worker(rank, world, port, bn, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bn", ["vqvae-ema", "ae"])
-def test_dp_real_steps_match_single_process_global_batch(bn):
+@pytest.mark.parametrize("bn,world", [("vqvae-ema", 2), ("ae", 2), ("vqvae-ema", 3)])
+def test_dp_real_steps_match_single_process_global_batch(bn, world):
     """Sum-type loss (VQ-VAE-EMA: summed gradients, one codebook from summed EMA statistics) and mean-type loss (AE:
-    the optimizer scales the summed gradient by 1 / world): two ranks with one window each == one process with both."""
-    world = 2
+    the optimizer scales the summed gradient by 1 / world): N ranks with one window each == one process with all N.
+    world = 3: shards that do not divide the regions (the replicated remainder), a ring that is not a power of two."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -214,13 +214,15 @@ def test_dp_real_steps_match_single_process_global_batch(bn):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, o0, ref), (_, o1, _) = res
+    (_, o0, ref), (_, o1, _) = res[0], res[-1]
     T = lambda a: None if a is None else torch.from_numpy(a)
     o0 = {k: tuple(T(a) for a in v) for k, v in o0.items()}
     o1 = {k: tuple(T(a) for a in v) for k, v in o1.items()}
     p_ref, m_ref, e_ref = (T(a) for a in ref)
     scale = float(p_ref.abs().max())
-    for name, tol in (("allreduce", 2e-5), ("sharded", 2e-5), ("sharded_bf16", 2e-2)):
+    # bf16 transport: Adam's normalised update moves a parameter by up to lr per step whatever the size of its gradient,
+    # so rounding a near-zero summed gradient can cost a sizeable part of 2 steps x lr = 2e-2 on a few parameters
+    for name, tol in (("allreduce", 2e-5), ("sharded", 2e-5), ("sharded_bf16", 3e-2)):
         pa, ma, ea = o0[name]
         pb, mb, eb = o1[name]
         assert torch.equal(pa, pb), name                                   # the replicas stay identical
