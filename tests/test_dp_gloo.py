@@ -175,7 +175,9 @@ def _real_worker(rank, world, port, bn, q):
         for name in ("allreduce", "sharded", "sharded_bf16"):
             _seed_engine(eng)
             eng.set_inputs(*mine)
-            for it in range(2):                                   # two steps: the second sees the exchanged state
+            # two steps: the second sees the exchanged state.  bf16 transport is held to ONE step: its rounding moves a
+            # few parameters by ~lr in step 1, after which code assignments can flip and the trajectories part for real
+            for it in range(1 if name.endswith("bf16") else 2):
                 if name == "allreduce":
                     d.train_step(eng, 1e-2, gs)
                 else:
@@ -190,10 +192,11 @@ def _real_worker(rank, world, port, bn, q):
             one = emulate(M.TrainEngine(hps, B=world, device="cpu", n_mel=5))
             _seed_engine(one)
             one.set_inputs(*batch)
+            ref = []
             for it in range(2):
                 one.forward(); one.backward(); one.adam_step(1e-2, 1.0)
-            ref = (one.ps.params[:n].numpy().copy(), one.adam_m[:n].numpy().copy(),
-                   one.emb.numpy().copy() if one.bn_type == "vqvae-ema" else None)
+                ref.append((one.ps.params[:n].numpy().copy(), one.adam_m[:n].numpy().copy(),
+                            one.emb.numpy().copy() if one.bn_type == "vqvae-ema" else None))
         q.put((rank, out, ref))
     finally:
         dist.destroy_process_group()
@@ -218,11 +221,11 @@ def test_dp_real_steps_match_single_process_global_batch(bn, world):
     T = lambda a: None if a is None else torch.from_numpy(a)
     o0 = {k: tuple(T(a) for a in v) for k, v in o0.items()}
     o1 = {k: tuple(T(a) for a in v) for k, v in o1.items()}
-    p_ref, m_ref, e_ref = (T(a) for a in ref)
-    scale = float(p_ref.abs().max())
-    # bf16 transport: Adam's normalised update moves a parameter by up to lr per step whatever the size of its gradient,
-    # so rounding a near-zero summed gradient can cost a sizeable part of 2 steps x lr = 2e-2 on a few parameters
-    for name, tol in (("allreduce", 2e-5), ("sharded", 2e-5), ("sharded_bf16", 3e-2)):
+    # bf16 transport: Adam's normalised update moves a parameter by up to lr whatever the size of its gradient, so
+    # rounding a near-zero summed gradient can cost a sizeable part of lr = 1e-2 on a few parameters
+    for name, tol in (("allreduce", 2e-5), ("sharded", 2e-5), ("sharded_bf16", 1.5e-2)):
+        p_ref, m_ref, e_ref = (T(a) for a in ref[0 if name.endswith("bf16") else 1])
+        scale = float(p_ref.abs().max())
         pa, ma, ea = o0[name]
         pb, mb, eb = o1[name]
         assert torch.equal(pa, pb), name                                   # the replicas stay identical
@@ -230,7 +233,7 @@ def test_dp_real_steps_match_single_process_global_batch(bn, world):
         assert float((pa - p_ref).abs().max()) <= tol * scale, (name, float((pa - p_ref).abs().max()), scale)
         # (bf16 transport rounds every summed gradient to 8 bits of mantissa; Adam's normalised update then moves
         # near-zero-gradient parameters differently in step 1, which step 2's moments see: looser bound)
-        mtol = 0.1 if name.endswith("bf16") else tol
+        mtol = 1e-2 if name.endswith("bf16") else tol             # one step: m = (1 - beta1) g, g rounded to bf16
         assert float((ma - m_ref).abs().max()) <= mtol * max(float(m_ref.abs().max()), 1e-12), name
         if e_ref is not None:
             assert torch.equal(ea, eb)
