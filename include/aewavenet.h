@@ -470,6 +470,8 @@ int aew_set_nt_small_tiles(int n);
 /* ... and of those, launches of <= max_blocks blocks (default 256: one block per CU) run a 5-stage operand ring
  * instead of 2 stages: their K loop is DMA latency, not MFMA (0 = never; same results). */
 int aew_set_nt_small_deep(int max_blocks);
+/* ... as 8 waves of 16 rows x 64 channels (default) or 2 waves of 64 x 64 per block (A/B; same results). */
+int aew_set_nt_small_waves(int waves);
 /* fp32 NT kernel: launches of <= max_blocks blocks (default 256 = one per CU) run with a 12-14 stage operand ring
  * (the whole LDS of the CU; 16-row tiles if that fits the limit, else 32-row tiles), larger ones with 5 stages and
  * three blocks per CU.  0 = always the 5-stage shape.  The chains themselves - one per output, k ascending - do not
