@@ -392,7 +392,10 @@ class DecoderPlan:
                                 F3, F3)
 
     # -- forward ---------------------------------------------------------------------------
-    def build_forward(self, plan: Plan, need_onehot: bool = True):
+    def build_forward(self, plan: Plan, need_onehot: bool = True, after_logits=None, after_nll=None):
+        """after_logits / after_nll: callables(plan) that append side-lane ops reading the logits / the per-position
+        nll (the caller's per-step diagnostics): placed here they run under the softmax and the loss reduction
+        instead of after the plan's last main-lane op."""
         B, g, hps, p = self.B, self.g, self.hps, self.pre
         Rp, Dp, Sp, Pp, Qp, Cp, Lp = self.Rp, self.Dp, self.Sp, self.Pp, self.Qp, self.Cp, self.Lp
         impl = self.impl
@@ -531,8 +534,12 @@ class DecoderPlan:
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.w, Qp, Qp, B, [self.h1.seg(Pp)], self.Wp2.ptr,
                                        flags=L.EF_BIAS, out0=self.logits.view(),
                                        bias_ptr=self.bias_vec["post2"], impl=impl), "post2", TAG_POST)
+        if after_logits is not None:
+            after_logits(plan)
         # 8. fused log-softmax + NLL (wavenet.py:543-547)
         plan.add(L.OP_SOFTMAX_NLL, self._softmax(False, 0.0), "softmax_nll", TAG_LOSS)
+        if after_nll is not None:
+            after_nll(plan)
 
     def _fill_spk(self, sb):
         p, ps = self.pre, self.ps

@@ -34,6 +34,8 @@ class TrainEngine:
     update_codebook_every_step: refresh emb from the EMA statistics each step (standard
     VQ-VAE-EMA); the reference only refreshes at global_step == 10000 (chassis.py:175-176).
     """
+    diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
+                              # forward plan; A/B: 8.02 -> 7.99 ms per step)
 
     def __init__(self, hps, B: int, device, n_mel: Optional[int] = None, loss_mode: str = "intended",
                  take_compat: bool = False, update_codebook_every_step: bool = True, impl: int = 0,
@@ -221,7 +223,54 @@ class TrainEngine:
             self.pack_late.emit(fb, "pack weights (backward layouts)")
         for op in fb.ops[-1:] if self.pack_late.recs else []:
             op.tag = TAG_PACK
-        self.dec.build_forward(fb)
+        # Per-step diagnostics (what the reference's loss modules report, vqema_bn.py:251-264, chassis.py:266-270) are
+        # side-lane ops placed where their inputs become final, not after the plan's last op (a side op starts after
+        # every main-lane op that precedes it in the plan: appended at the end they were ~0.09 ms of exposed tail):
+        #   codebook / encoder-output statistics  right here, under the whole decoder forward
+        #   peak log-probability statistics       after the logits GEMM, under the softmax
+        #   rec / tprb_m / com                    after the softmax, under the loss reduction
+        n_pos_m = B * (w - 1)
+        self.diag = ws.alloc("diag.out", 16, torch.float32)              # [0..5] (vqema_bn.py:254-260)
+        self.diag_pk = ws.alloc("diag.peak", 16, torch.float32)          # [6..8] (vqema_bn.py:261-263)
+        self.diag_scratch = ws.alloc("scratch.diag", 512, torch.float32)
+        self.met_buf = ws.alloc("diag.metrics", 8, torch.float32)        # [1] rec, [2] tprb_m, [3] com
+        if bn in ("vqvae-ema", "vqvae"):
+            dv = L.VqDiag()
+            dv.ze, dv.Q, dv.d, dv.d_pitch = self.lin.ptr, self.Q, hps.bn_n_out, self.lin.pitch
+            dv.K = hps.bn_vq_n_embed
+            dv.emb = self.emb.data_ptr() if bn == "vqvae-ema" else ps.ptr("bottleneck.emb")
+            if bn == "vqvae-ema":
+                dv.hist, dv.n_sum = self.ind_hist.data_ptr(), self.n_sum_diag.data_ptr()
+            dv.B, dv.w, dv.n_quant = B, w, hps.n_quant
+            dv.scratch, dv.out = self.diag_scratch.data_ptr(), self.diag.data_ptr()
+            with fb.side(1):
+                fb.add(L.OP_VQ_DIAG, dv, "diagnostics (codebook)", TAG_LOSS)
+
+        def after_logits(plan):
+            dg = L.VqDiag()
+            lgm = self.dec.logits
+            dg.logits, dg.bs, dg.pitch, dg.B, dg.w, dg.n_quant = lgm.ptr, lgm.bs, lgm.pitch, B, w, hps.n_quant
+            dg.scratch, dg.out = self.diag_scratch.data_ptr(), self.diag_pk.data_ptr()
+            with plan.side(1):
+                plan.add(L.OP_VQ_DIAG, dg, "diagnostics (peak)", TAG_LOSS)
+
+        def after_nll(plan):
+            met = L.Reduce()
+            mterms = [(self.dec.nll.data_ptr(), B * w, 1.0 / n_pos_m), (self.dec.ptgt.data_ptr(), B * w, 1.0 / n_pos_m)]
+            if bn in ("vqvae-ema", "vqvae"):
+                mterms.append((self.min_dist.data_ptr(), self.Q, float(hps.bn_vq_gamma) / self.Q))
+            met.n_terms = len(mterms)
+            for i, (p_, n_, s_) in enumerate(mterms):
+                met.x[i], met.n[i], met.scale[i], met.post_scale[i] = p_, n_, s_, 1.0
+            met.out = self.met_buf.data_ptr()
+            with plan.side(1):
+                plan.add(L.OP_REDUCE, met, "metrics", TAG_LOSS)
+
+        if self.diag_early:
+            self.dec.build_forward(fb, after_logits=after_logits, after_nll=after_nll)
+        else:                                                  # A/B: all of them after the plan's last main-lane op
+            self.dec.build_forward(fb)
+            self._diag_tail = (after_logits, after_nll)
         red = L.Reduce()
         nll_ptr = self.dec.nll.data_ptr()
         terms = []
@@ -246,35 +295,8 @@ class TrainEngine:
             self._red_index = len(fb.ops)
         red.out = self.loss_buf.data_ptr()
         fb.add(L.OP_REDUCE, red, "loss", TAG_LOSS)
-        # what run() reports next to the loss every step (chassis.py:266-270 tprb_m, the loss modules' `rec` / `com`):
-        # one more reduction op on a side lane instead of a handful of framework kernels behind the step
-        self.met_buf = ws.alloc("diag.metrics", 8, torch.float32)        # [1] rec, [2] tprb_m, [3] com
-        met = L.Reduce()
-        mterms = [(nll_ptr, B * w, 1.0 / n_pos), (self.dec.ptgt.data_ptr(), B * w, 1.0 / n_pos)]
-        if bn in ("vqvae-ema", "vqvae"):
-            mterms.append((self.min_dist.data_ptr(), self.Q, float(hps.bn_vq_gamma) / self.Q))
-        met.n_terms = len(mterms)
-        for i, (p_, n_, s_) in enumerate(mterms):
-            met.x[i], met.n[i], met.scale[i], met.post_scale[i] = p_, n_, s_, 1.0
-        met.out = self.met_buf.data_ptr()
-        with fb.side(1):
-            fb.add(L.OP_REDUCE, met, "metrics", TAG_LOSS)
-        # per-step diagnostics the reference's loss modules report (vqema_bn.py:251-264): one fused reduction op,
-        # off the critical chain
-        self.diag = ws.alloc("diag.out", 16, torch.float32)
-        self.diag_scratch = ws.alloc("scratch.diag", 512, torch.float32)
-        dg = L.VqDiag()
-        if bn in ("vqvae-ema", "vqvae"):
-            dg.ze, dg.Q, dg.d, dg.d_pitch = self.lin.ptr, self.Q, hps.bn_n_out, self.lin.pitch
-            dg.K = hps.bn_vq_n_embed
-            dg.emb = self.emb.data_ptr() if bn == "vqvae-ema" else ps.ptr("bottleneck.emb")
-            if bn == "vqvae-ema":
-                dg.hist, dg.n_sum = self.ind_hist.data_ptr(), self.n_sum_diag.data_ptr()
-        lgm = self.dec.logits
-        dg.logits, dg.bs, dg.pitch, dg.B, dg.w, dg.n_quant = lgm.ptr, lgm.bs, lgm.pitch, B, w, hps.n_quant
-        dg.scratch, dg.out = self.diag_scratch.data_ptr(), self.diag.data_ptr()
-        with fb.side(1):
-            fb.add(L.OP_VQ_DIAG, dg, "diagnostics", TAG_LOSS)
+        for hook in getattr(self, "_diag_tail", ()):
+            hook(fb)
         # ===== backward
         self.bwd = bw = Plan("bwd")
         bw.zero(ws, "grads")
@@ -283,8 +305,21 @@ class TrainEngine:
         if bn == "vqvae-ema" and self.loss_mode == "head":
             nll_scale = 0.0
         self.dec.build_backward(bw, nll_scale)
+        # gradient statistics of run() (autoencoder_model.py:252-257 mel_grad_sd / bn_grad_sd; mfcc_inverter.py:100-106
+        # mel_grad_sd / mel_grad_mean): by-products of this backward, reduced on a side lane as soon as their input is
+        # final (d(loss)/d(code) here, under the encoder backward)
+        self.gstat = ws.alloc("diag.gstat", 8, torch.float32)            # [0:4] mel (mean, std, sum, sumsq), [4:8] bn
+
+        def moments(mat, cols, slot, nm):
+            mo = L.Moments()
+            mo.x, mo.rows, mo.cols, mo.batch = mat.view(), mat.rows, cols, B
+            mo.out = self.gstat.data_ptr() + 4 * slot
+            with bw.side(1):
+                bw.add(L.OP_MOMENTS, mo, f"grad stats ({nm})", TAG_LOSS)
         with bw.side(1):                                       # after every decoder wgrad on any side lane
             self.unpack_dec.emit(bw, "unpack grads (decoder)", join=True)
+        if self.enc is not None:
+            moments(self.dec.dlc_src, hps.bn_n_out, 4, "bn")
         if self.enc is not None:
             dcode = self.dec.dlc_src                      # d(loss)/d(code) [B][Ne][dp]
             Ep = ru(hps.enc_n_out, 64)
@@ -325,17 +360,8 @@ class TrainEngine:
                                          out1=self.enc.dpre[9].view(), aux1=self.enc.r[9].view(), impl=impl),
                    "d.bn.linear", TAG_VQ)
             self.enc.build_backward(bw, need_input_grad=True)
-        # gradient statistics of run() (autoencoder_model.py:252-257 mel_grad_sd / bn_grad_sd; mfcc_inverter.py:100-106
-        # mel_grad_sd / mel_grad_mean): by-products of this backward, reduced on a side lane
-        self.gstat = ws.alloc("diag.gstat", 8, torch.float32)            # [0:4] mel (mean, std, sum, sumsq), [4:8] bn
-        stats = [(self.enc.dy[0], self.n_mel, 0, "mel"), (self.dec.dlc_src, hps.bn_n_out, 4, "bn")] \
-            if self.enc is not None else [(self.dec.dlc_src, self.n_mel, 0, "mel")]
-        with bw.side(1):
-            for mat, cols, slot, nm in stats:
-                mo = L.Moments()
-                mo.x, mo.rows, mo.cols, mo.batch = mat.view(), mat.rows, cols, B
-                mo.out = self.gstat.data_ptr() + 4 * slot
-                bw.add(L.OP_MOMENTS, mo, f"grad stats ({nm})", TAG_LOSS)
+        # (mel gradient statistics: its input is the last thing the backward writes)
+        moments(self.enc.dy[0] if self.enc is not None else self.dec.dlc_src, self.n_mel, 0, "mel")
         self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads the side-lane encoder wgrad slabs
         # Deferred EMA (data parallel): the EMA accumulators are not read again before the codebook
         # refresh, so the cross-rank sum of z_sum | n_sum can run asynchronously under the whole

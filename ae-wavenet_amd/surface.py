@@ -423,8 +423,8 @@ class HipModelBase(nn.Module):
         mb = eng.met_buf                                           # the "metrics" reduction op of the forward plan
         m["rec"] = mb[1]
         self.tprb_m = mb[2]                                        # chassis.py:266-270
-        dg = eng.diag                                              # AEW_OP_VQ_DIAG: one fused reduction op per step
-        m["pk_m"], m["pk_sd"], m["pk_nuq"] = dg[6], dg[7], dg[8]    # vqema_bn.py:261-263
+        dg, pk = eng.diag, eng.diag_pk                             # AEW_OP_VQ_DIAG ops of the forward plan (side lanes)
+        m["pk_m"], m["pk_sd"], m["pk_nuq"] = pk[6], pk[7], pk[8]    # vqema_bn.py:261-263
         if eng.bn_type in ("vqvae-ema", "vqvae"):
             m["com"] = mb[3]
             m["min_ze"], m["max_ze"], m["min_emb"], m["max_emb"] = dg[0], dg[1], dg[2], dg[3]   # vqema_bn.py:254-257

@@ -234,6 +234,9 @@ def main():
     _E.DecoderPlan.split_chains = args.chains == 2
     if args.side_lanes:
         _E.DecoderPlan.n_side_lanes = args.side_lanes
+    if os.environ.get("AEW_DIAG_EARLY") is not None:             # A/B aid: 0 = per-step diagnostics at the tail of the forward plan
+        from ae_wavenet_amd import model as _M
+        _M.TrainEngine.diag_early = os.environ["AEW_DIAG_EARLY"] == "1"
     if os.environ.get("AEW_SPLIT_MULTISEG"):
         _E.DecoderPlan.split_multiseg = os.environ["AEW_SPLIT_MULTISEG"] == "1"
 

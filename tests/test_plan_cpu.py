@@ -141,7 +141,7 @@ def test_autoencoder_vqema_plan(golden_dir, mode, jk, loss_mode, gtag, ltag):
     cnt = eng.enc.zero_cnt[:9].numpy().astype(np.float64)
     numel = np.array([eng.B * eng.geom.enc_lens[i + 1] * hps.enc_n_out for i in range(9)], np.float64)
     np.testing.assert_allclose(cnt / numel, z["enc_frac_zero"], atol=1e-9)
-    check_diagnostics(eng.diag.numpy(), z, exact=(mode == "wide"))
+    check_diagnostics(np.concatenate([eng.diag.numpy()[:6], eng.diag_pk.numpy()[6:9]]), z, exact=(mode == "wide"))
 
 
 def check_diagnostics(dg, z, exact):
