@@ -1242,11 +1242,16 @@ __device__ __forceinline__ void nf_chain(NfFrag<RT>& F, f32x4_t (&acc)[RT], bool
     for (int r = 0; r < RT; ++r) nf_mfma8(acc[r], F.w[0], F.x[r][0], F.w[1], F.x[r][1]);
 }
 
-template <int RT, int S>
-__global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
+// LW = 1: four more waves per block that do nothing but stage operands (wave 4 + w issues what consumer wave w would):
+// an LDS-DMA instruction costs its wave 60-185 issue cycles, and three of them per K tile sat in front of every chain
+// step of a wave that has 264 cycles of MFMA per tile.  Loaders and consumers meet at the one barrier per tile.
+template <int RT, int S, int LW>
+__global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
     typedef NfCfg<RT, S> Cfg;
     extern __shared__ __attribute__((aligned(128))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wv & 3;
+    const bool loader = LW && wv >= 4, stages_own = !LW;       // stages_own: this wave issues its own LDS-DMA
     const int rows = g.M * g.batch, n_rt = (rows + Cfg::BM - 1) / Cfg::BM;
     const int nt_i = blockIdx.x / n_rt;
     const int R0 = (blockIdx.x - nt_i * n_rt) * Cfg::BM, n0 = nt_i * NF_BN;
@@ -1287,14 +1292,26 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
         --left;
         ++issued;
     };
-    for (int i = 0; i < S - 1; ++i) issue_next();                // tiles 0 .. S-2
+    if (loader || stages_own)
+        for (int i = 0; i < S - 1; ++i) issue_next();            // tiles 0 .. S-2
+    if (loader) {                                                // the consumers' schedule, minus everything but the DMA
+        p64_wait_vm<(S - 2) * 3>();
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nkt; ++t) {
+            p64_wait_vm<(S - 3) * 3>();
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the top-up loads still target this block's LDS
+        return;
+    }
     const int fi = lane & 15, kq = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem);
     // lane (fi, kq) reads chunk kq (j = 0) / 4 + kq (j = 1: address ^ 64) of its rows; stages are multiples of 128 bytes
     const uint32_t xlane = lds0 + fi * 128 + (nt_swz(fi, kq) << 4);
     const uint32_t wlane = lds0 + Cfg::BM * 128 + (wave * 16 + fi) * 128 + (nt_swz(fi, kq) << 4);
     NfFrag<RT> A, B;
-    p64_wait_vm<(S - 2) * 3>();
+    if (stages_own) p64_wait_vm<(S - 2) * 3>();
     __builtin_amdgcn_s_barrier();
     nf_read<RT>(A, wlane, xlane);
     nf_ready<RT>(A);
@@ -1305,9 +1322,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
     // (the wait closes the step: registers an asm read is still filling must not be live across the loop's back
     // edge, where the compiler is free to copy them)
     auto step = [&](NfFrag<RT>& F, NfFrag<RT>& Nx) {
-        if (!no_wait) p64_wait_vm<(S - 3) * 3>();
+        if (stages_own && !no_wait) p64_wait_vm<(S - 3) * 3>();
         if (!no_barrier) __builtin_amdgcn_s_barrier();
-        if (!no_issue) issue_next();
+        if (stages_own && !no_issue) issue_next();
         cur = (cur + Cfg::STAGE_BYTES == (uint32_t)Cfg::LDS_BYTES) ? 0u : cur + Cfg::STAGE_BYTES;
         if (!no_reads) nf_read<RT>(Nx, wlane + cur, xlane + cur);
         nf_chain<RT>(F, acc, no_mfma);
@@ -1319,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f32(const aew_gemm_nt_t g) {
         step(B, A);
     }
     if (nkt & 1) step(A, B);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the top-up loads still target this block's LDS
+    if (stages_own) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the top-up loads still target this block's LDS
     unsigned zc = 0;
     const EpiUni U = epi_uni(g);
     if (NF_ABL(g, 8)) {
@@ -1896,6 +1913,7 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
 static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kernel
 static int g_nt_rows192 = 1;      // default shape: 0 never, 1 cost model, 2 always use 192-row tiles
+static int g_nf_loaders = 1;        // fp32 NT: four dedicated loader waves per block (0: the consumer waves stage their own operands)
 static int g_nf_deep = 256;         // fp32 NT: launches of <= this many blocks get one block per CU and a 12-14 stage ring
 static int g_nt_small_w8 = 1;       // ... with 8 waves (16 rows x 64 channels each) instead of 2: the LDS-DMA issue is shared
 static int g_nt_small_deep = 256;   // 64-row launches of <= this many blocks (one per CU) use the 5-stage ring (120 KiB)
@@ -1933,9 +1951,12 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8, 2>), (NtCfg<8, 2>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
 #undef AEW_SET_NT
-    AEW_SET_LDS((k_gemm_nt_f32<1, 7>), (NfCfg<1, 7>::LDS_BYTES))
-    AEW_SET_LDS((k_gemm_nt_f32<1, 14>), (NfCfg<1, 14>::LDS_BYTES))
-    AEW_SET_LDS((k_gemm_nt_f32<2, 12>), (NfCfg<2, 12>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<1, 7, 0>), (NfCfg<1, 7>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<1, 14, 0>), (NfCfg<1, 14>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<2, 12, 0>), (NfCfg<2, 12>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<1, 7, 1>), (NfCfg<1, 7>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<1, 14, 1>), (NfCfg<1, 14>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<2, 12, 1>), (NfCfg<2, 12>::LDS_BYTES))
     AEW_SET_LDS(k_gemm_tn_bf16_big, TNB_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
@@ -2095,12 +2116,15 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         // for anything larger
         const int rows = g.M * g.batch, n_nt = g.N_pad / NF_BN;
         const int tiles1 = ((rows + 15) / 16) * n_nt, tiles2 = ((rows + 31) / 32) * n_nt;
-        if (g_nf_deep && tiles1 <= g_nf_deep)
-            hipLaunchKernelGGL((k_gemm_nt_f32<1, 14>), dim3(tiles1), dim3(256), (NfCfg<1, 14>::LDS_BYTES), st, g);
-        else if (g_nf_deep && tiles2 <= g_nf_deep)
-            hipLaunchKernelGGL((k_gemm_nt_f32<2, 12>), dim3(tiles2), dim3(256), (NfCfg<2, 12>::LDS_BYTES), st, g);
-        else
-            hipLaunchKernelGGL((k_gemm_nt_f32<1, 7>), dim3(tiles1), dim3(256), (NfCfg<1, 7>::LDS_BYTES), st, g);
+#define AEW_NF_GO(RT, S, GRID)                                                                                       \
+    do {                                                                                                             \
+        if (g_nf_loaders) hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 1>), dim3(GRID), dim3(512), (NfCfg<RT, S>::LDS_BYTES), st, g); \
+        else hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 0>), dim3(GRID), dim3(256), (NfCfg<RT, S>::LDS_BYTES), st, g);  \
+    } while (0)
+        if (g_nf_deep && tiles1 <= g_nf_deep) AEW_NF_GO(1, 14, tiles1);
+        else if (g_nf_deep && tiles2 <= g_nf_deep) AEW_NF_GO(2, 12, tiles2);
+        else AEW_NF_GO(1, 7, tiles1);
+#undef AEW_NF_GO
     }
     return (int)hipGetLastError();
 }

@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--side-lanes", dest="side_lanes", type=int, default=0, help="side lanes the wgrads rotate over (1..4)")
     ap.add_argument("--nt-deep", dest="nt_deep", type=int, default=-1, help="64-row NT launches of <= this many blocks use the 5-stage ring")
     ap.add_argument("--nt-small-waves", dest="nt_small_waves", type=int, default=-1, help="waves per block of the deep 64-row NT shape (2|8)")
+    ap.add_argument("--nf-loaders", dest="nf_loaders", type=int, default=-1, help="fp32 NT: dedicated loader waves (0|1)")
     ap.add_argument("--nf-deep", dest="nf_deep", type=int, default=-1, help="fp32 NT: launches of <= this many blocks use the deep ring (0 never)")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     ap.add_argument("--engine-only", action="store_true", help="headline = the engine-level step (no module surface / loader)")
@@ -216,6 +217,8 @@ def main():
         lib.aew_set_nt_rows192(args.nt_rows192)
     if args.nt_small >= 0:
         lib.aew_set_nt_small_tiles(args.nt_small)
+    if args.nf_loaders >= 0:
+        lib.aew_set_nf_loaders(args.nf_loaders)
     if args.nf_deep >= 0:
         lib.aew_set_nf_deep(args.nf_deep)
     if args.nt_small_waves >= 0:

@@ -477,6 +477,9 @@ int aew_set_nt_small_waves(int waves);
  * three blocks per CU.  0 = always the 5-stage shape.  The chains themselves - one per output, k ascending - do not
  * change (bit-identical results). */
 int aew_set_nf_deep(int max_blocks);
+/* fp32 NT kernel: 1 (default) four dedicated loader waves per block issue the LDS-DMA, 0 the four compute waves stage
+ * their own operands (A/B; same results). */
+int aew_set_nf_loaders(int on);
 /* default NT shape only: 192 x 128 tiles (8 waves of 48x64) instead of 256 x 128 — 0 never, 1 (default) where the
  * per-CU cost model prefers them, 2 always.  Results are bit-identical either way. */
 int aew_set_nt_rows192(int mode);

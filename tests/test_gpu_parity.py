@@ -146,8 +146,9 @@ def test_gemm_nt(dtype, epi):
                 for n in res:
                     assert torch.equal(res[n], results[0][n]), (n, "shape", shape, "pipe", pipe, "small", small)
         # the 64-row shape in its three forms: 8 waves + 5-stage ring (default for small launches), 2 waves + 5 stages,
-        # 2 waves + 2 stages; the fp32 kernel with the deep (one block per CU) and the shallow ring
-        for waves, deep, nf_deep in ((8, 256, 256), (2, 256, 0), (2, 0, 256)):
+        # 2 waves + 2 stages; the fp32 kernel with the deep (one block per CU) and the shallow ring, with and without
+        # its dedicated loader waves
+        for waves, deep, nf_deep, nf_ld in ((8, 256, 256, 1), (2, 256, 0, 1), (2, 0, 256, 0), (8, 256, 0, 0)):
             lib.aew_set_nt_rows192(0)
             lib.aew_set_nt_wave_rows(64)
             lib.aew_set_nt_pipe(1)
@@ -155,13 +156,14 @@ def test_gemm_nt(dtype, epi):
             lib.aew_set_nt_small_waves(waves)
             lib.aew_set_nt_small_deep(deep)
             lib.aew_set_nf_deep(nf_deep)
+            lib.aew_set_nf_loaders(nf_ld)
             ws_g = _mirror(ws_c, DEV)
             p = Plan("nt")
             p.add(L.OP_GEMM_NT, _nt_case(ws_g, dtype, epi, 0), "nt")
             p.run(stream())
             torch.cuda.synchronize()
             for n in ("O0", "O1", "O2"):
-                assert torch.equal(ws_g.get(n).float().cpu(), results[0][n]), (n, "small-launch form", waves, deep, nf_deep)
+                assert torch.equal(ws_g.get(n).float().cpu(), results[0][n]), (n, "small-launch form", waves, deep, nf_deep, nf_ld)
     finally:
         lib.aew_set_nt_wave_rows(64)
         lib.aew_set_nt_pipe(1)
@@ -170,6 +172,7 @@ def test_gemm_nt(dtype, epi):
         lib.aew_set_nt_small_waves(8)
         lib.aew_set_nt_small_deep(256)
         lib.aew_set_nf_deep(256)
+        lib.aew_set_nf_loaders(1)
     ws_e = Workspace("cpu")
     for n, t in ws_c.bufs.items():
         ws_e.bufs[n] = t.clone()
