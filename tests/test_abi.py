@@ -50,3 +50,36 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", L.LIB_PATH + ".absent")
     with pytest.raises(L.AewError):
         L.load()
+
+
+def test_nt_kernel_query_follows_the_dispatch_rules():
+    """aew_nt_kernel (host-side logic only): which kernel a GEMM_NT descriptor runs on.  bench.py groups its roofline
+    by it, so it has to follow launch_gemm_nt: large bf16 launches -> the tiled kernel, launches of few tiles -> the
+    64-row shape, impl = 2 on a covered shape -> the full-N kernel, fp32 -> the exact-chain kernel, impl = 1 -> check."""
+    from ae_wavenet_amd.plan import Mat, Workspace, make_nt
+    lib = L.load()
+    ws = Workspace("cpu")
+    x = Mat.new(ws, "x", 8, 6100, 384, L.BF16)
+    W = Mat.new(ws, "W", 1, 512, 768, L.BF16)
+    y = Mat.new(ws, "y", 8, 6100, 512, L.BF16)
+    segs = [x.seg(384), x.seg(384, row_off=16)]
+    q = lambda g: lib.aew_nt_kernel(C.byref(g))
+    assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view())) == 0
+    assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view(), impl=2)) == 2
+    assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view(), impl=1)) == 4
+    assert q(make_nt(L.BF16, 70, 512, 512, 8, segs, W.ptr, out0=y.view())) == 1           # 8 x 4 tiles of 256 rows
+    lib.aew_set_nt_small_tiles(0)
+    try:
+        assert q(make_nt(L.BF16, 70, 512, 512, 8, segs, W.ptr, out0=y.view())) == 0
+    finally:
+        lib.aew_set_nt_small_tiles(128)
+    lib.aew_set_fn(0)
+    try:
+        assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view(), impl=2)) == 0
+    finally:
+        lib.aew_set_fn(1)
+    xf = Mat.new(ws, "xf", 8, 80, 768, L.F32)
+    Wf = Mat.new(ws, "Wf", 1, 768, 768, L.F32)
+    yf = Mat.new(ws, "yf", 8, 80, 768, L.F32)
+    assert q(make_nt(L.F32, 70, 768, 768, 8, [xf.seg(768)], Wf.ptr, out0=yf.view())) == 3
+    assert lib.aew_nt_kernel(None) == -1
