@@ -8,13 +8,14 @@ import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ae_wavenet_amd import _lib as L, config, model as M
+from ae_wavenet_amd import _lib as L, autoencoder_model as ae, config
 from ae_wavenet_amd.plan import Plan
 
 dev = "cuda:0"
 hps = config.make_hps("vqvae-ema", n_win_batch=5000, n_batch=8)
 torch.manual_seed(0)
-eng = M.TrainEngine(hps, B=8, device=dev, n_mel=39)
+model = ae.AutoEncoder(hps, n_mel=39).to(dev)              # Xavier weights, codebook gain 10 (the engine alone starts from zeros)
+eng = model._ensure_engine(8)
 g = eng.geom
 gen = torch.Generator().manual_seed(1)
 eng.set_inputs(torch.randint(0, 256, (8, g.enc_in_len), generator=gen).float().to(dev), torch.randn(8, 39, g.mel_len, generator=gen).to(dev),
