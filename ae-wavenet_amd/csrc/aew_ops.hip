@@ -226,6 +226,50 @@ __global__ __launch_bounds__(256) void k_vq_stats(const aew_vq_stats_t p) {
     }
 }
 
+// Few queries (a training step: Q = 232 against K x d = 131 072 accumulators): the kernel above spends its time
+// finding out that almost every code has no query.  Here the outputs are cleared first and one wave per query does
+// the work of its code if it is the FIRST query that maps to it: the same ascending-q chain of fp32 adds starting
+// from 0, so the results are bit-identical.  Q <= 1024 (the index list lives in LDS).
+__global__ __launch_bounds__(256) void k_vq_stats_few(const aew_vq_stats_t p) {
+    __shared__ int sh_ind[1024];
+    for (int i = threadIdx.x; i < p.Q; i += blockDim.x) sh_ind[i] = (int)p.ind[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);           // one wave per query
+    if (q >= p.Q) return;
+    const int k = sh_ind[q];
+    // 64 queries per ballot: matches before q mean another wave owns code k; the matches from q on are visited in
+    // ascending order through the set bits of the masks
+    const int nch = (p.Q + 63) >> 6;
+    float s = 0.f, n = 0.f;                                       // lane j < d accumulates channel j (d <= 64)
+    for (int c = 0; c < nch; ++c) {
+        const int i = c * 64 + lane;
+        unsigned long long m = __ballot(i < p.Q && sh_ind[i] == k);
+        if (c * 64 < q) {
+            const unsigned long long before = (q - c * 64 >= 64) ? ~0ull : ((1ull << (q - c * 64)) - 1ull);
+            if (m & before) return;                               // an earlier query owns code k
+            m &= ~before;
+        }
+        while (m) {                                               // 16 rows in flight, then added in order: a collapsed
+            int qi[16], cnt = 0;                                  // codebook sends every query to one code (232 rows)
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (m) { qi[u] = c * 64 + __builtin_ctzll(m); m &= m - 1; cnt = u + 1; } else qi[u] = 0;
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (u < cnt && lane < p.d) ? p.ze[(int64_t)qi[u] * p.d_pitch + lane] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < cnt) { s = __fadd_rn(s, v[u]); n = __fadd_rn(n, 1.0f); }
+        }
+    }
+    if (lane < p.d) p.z_sum[(int64_t)k * p.d + lane] = s;
+    if (lane == 0) {
+        p.n_sum[k] = n;
+        if (p.hist) p.hist[k] += n;
+    }
+}
+
 __global__ void k_vq_ema(const aew_vq_ema_t p) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)p.K * p.d) return;
@@ -1004,7 +1048,17 @@ static int launch_vq_nearest(const aew_vq_nearest_t& p, hipStream_t st) {
     hipLaunchKernelGGL(k_vq_nearest, dim3(p.Q), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
+static int launch_zero(const aew_zero_t& z, hipStream_t st);
 static int launch_vq_stats(const aew_vq_stats_t& p, hipStream_t st) {
+    if (p.Q > 0 && p.Q <= 1024 && p.d <= 64 && (int64_t)p.K * p.d >= 16 * (int64_t)p.Q) {
+        // few queries, many codes: clear the accumulators, then one wave per query (k_vq_stats_few)
+        aew_zero_t z1 = {p.z_sum, (int64_t)p.K * p.d * 4}, z2 = {p.n_sum, (int64_t)p.K * 4};
+        int rc = launch_zero(z1, st);
+        if (rc == 0) rc = launch_zero(z2, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_vq_stats_few, dim3((p.Q + 3) / 4), dim3(256), 0, st, p);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_vq_stats, dim3(cdiv64((int64_t)p.K * p.d, 256)), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
