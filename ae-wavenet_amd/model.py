@@ -211,7 +211,8 @@ class TrainEngine:
                     # EMA runs at the START of part B (after the optional cross-rank sum); the
                     # codebook refresh is deferred to after backward so that forward and backward
                     # of one step see the same emb
-                    fb.add(L.OP_VQ_EMA, em, "vq.ema", TAG_VQ)
+                    with fb.side(3):                           # nothing in the forward / backward reads the accumulators
+                        fb.add(L.OP_VQ_EMA, em, "vq.ema", TAG_VQ)
             elif bn == "vae":
                 va = self._vae_op(False)
                 fa.add(L.OP_VAE, va, "vae.sample", TAG_VQ)
