@@ -285,6 +285,62 @@ def test_gemm_tn_big_tiles(Np, ks):
         assert err <= 2e-3 * scale, (tag, err, scale)
 
 
+@pytest.mark.parametrize("dtype", [BF, F3])
+def test_moments_and_vq_stats_ops(dtype):
+    """The two small reductions added in round 2 against the plan interpreter: AEW_OP_MOMENTS over a strided view with
+    rows outside the view (read as zero), both storage types; VQ_STATS in its few-queries form (one wave per query owns
+    its code) on a collapsed assignment (every query on two codes: the 16-rows-in-flight path) - bit-identical to the
+    interpreter's ascending-order sums, like the many-queries form."""
+    gen = torch.Generator().manual_seed(3)
+    ws_c = Workspace("cpu")
+    B, R, pitch, cols = 3, 57, 128, 39
+    ws_c.alloc("x", B * R * pitch, PL.TORCH_DT[dtype])
+    _fill(ws_c, "x", gen)
+    ws_c.alloc("mom", 8, torch.float32)
+    Q, K, d = 232, 4096, 32
+    ws_c.alloc("ze", Q * 64, torch.float32); _fill(ws_c, "ze", gen)
+    ind = torch.randint(0, K, (Q,), generator=gen)
+    ind[5:] = torch.where(torch.arange(Q - 5) % 3 == 0, torch.tensor(17), torch.tensor(4000))     # two crowded codes
+    ws_c.bufs["ind"] = ind.clone()
+    for n, sz in (("zsum", K * d), ("nsum", K), ("hist", K)):
+        ws_c.alloc(n, sz, torch.float32)
+    ws_c.get("hist").fill_(2.0)
+
+    def build(ws):
+        x = Mat(ws, "x", B, R, pitch, dtype)
+        mo = L.Moments()
+        mo.x, mo.rows, mo.cols, mo.batch = x.view(row_off=-3, hi=R - 4), R, cols, B        # 3 + 4 rows read as zero
+        mo.out = ws.get("mom").data_ptr()
+        vs = L.VqStats()
+        vs.ze, vs.ind, vs.Q, vs.K, vs.d, vs.d_pitch = ws.get("ze").data_ptr(), ws.get("ind").data_ptr(), Q, K, d, 64
+        vs.z_sum, vs.n_sum, vs.hist = ws.get("zsum").data_ptr(), ws.get("nsum").data_ptr(), ws.get("hist").data_ptr()
+        p = Plan("t")
+        p.add(L.OP_MOMENTS, mo, "moments")
+        p.add(L.OP_VQ_STATS, vs, "vq.stats")
+        return p
+    ws_g = _mirror(ws_c, DEV)
+    build(ws_g).run(stream())
+    torch.cuda.synchronize()
+    ws_e = Workspace("cpu")
+    for n, t in ws_c.bufs.items():
+        ws_e.bufs[n] = t.clone()
+    Emu(ws_e).run(build(ws_e))
+    got, ref = ws_g.get("mom")[:4].cpu(), ws_e.get("mom")[:4]
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (got, ref)
+    # ascending-q fp32 chains, restated here (vqema_bn.py:172-188 sums in this order)
+    ze = ws_c.get("ze")[:Q * 64].view(Q, 64)[:, :d].numpy()
+    zs = np.zeros((K, d), np.float32)
+    ns = np.zeros(K, np.float32)
+    for q in range(Q):
+        k = int(ind[q])
+        zs[k] = zs[k] + ze[q]
+        ns[k] += 1.0
+    assert np.array_equal(ws_g.get("zsum")[:K * d].cpu().numpy().reshape(K, d), zs)
+    assert np.array_equal(ws_g.get("nsum")[:K].cpu().numpy(), ns)
+    assert np.array_equal(ws_g.get("hist")[:K].cpu().numpy(), ns + 2.0)
+    assert torch.allclose(ws_e.get("zsum")[:K * d].view(K, d), torch.from_numpy(zs), rtol=1e-6, atol=1e-6)     # the interpreter too
+
+
 # ----------------------------------------------------------------------------------------------
 # whole training steps on the reduced-width golden models: GPU vs interpreter vs golden
 # ----------------------------------------------------------------------------------------------
