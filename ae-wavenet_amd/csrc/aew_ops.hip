@@ -504,6 +504,40 @@ __global__ __launch_bounds__(256) void k_softmax_nll(const aew_softmax_nll_t p) 
     const int b = (int)(pos / p.w), u = (int)(pos % p.w);
     const float* lg = p.logits + (int64_t)b * p.bs + (int64_t)u * p.pitch;
     const bool live = u < p.w - 1;
+    if (p.Q == 256 && p.Q_pad == 256 && (p.pitch & 3) == 0 && (p.bs & 3) == 0 && (!p.backward || ((p.dl_pitch | p.dl_bs) & 3) == 0)) {
+        // the reference's 256 classes: the row is ONE 16-byte load per lane, every pass runs on registers and the
+        // gradient leaves as one 8-byte store per lane (the general path below re-reads the row per pass, 4 bytes a lane)
+        const float4 v4 = *reinterpret_cast<const float4*>(lg + 4 * lane);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float mx4 = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __expf(v[r] - mx4);
+        const float se4 = wave_sum((e[0] + e[1]) + (e[2] + e[3]));
+        const float lse4 = mx4 + __logf(se4);
+        const int tgt4 = live ? (int)p.wav[(int64_t)b * p.wav_pitch + p.tgt_off + u + 1] : 0;
+        if (!p.backward) {
+            // the lane that holds the target class reports (its value never leaves the registers)
+            if (lane == (tgt4 >> 2)) {
+                const int r = tgt4 & 3;
+                const float lp = (r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3]) - lse4;
+                p.nll[pos] = live ? -lp : 0.f;
+                if (p.ptgt) p.ptgt[pos] = live ? __expf(lp) : 0.f;
+            }
+        } else {
+            uint16_t* dl4 = p.dlogits + (int64_t)b * p.dl_bs + (int64_t)u * p.dl_pitch;
+            const float scale4 = p.gmul ? p.scale * p.gmul[0] : p.scale;
+            const float inv = 1.0f / se4;                          // exp(v - lse) = e / se
+            uint16_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = live ? (e[r] * inv - ((4 * lane + r) == tgt4 ? 1.f : 0.f)) * scale4 : 0.f;
+                o[r] = f2bf(g);
+            }
+            *reinterpret_cast<uint2*>(dl4 + 4 * lane) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int c = lane; c < p.Q; c += 64) mx = fmaxf(mx, lg[c]);
     mx = wave_max(mx);
