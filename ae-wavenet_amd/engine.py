@@ -151,20 +151,23 @@ class Packer:
     unpack wgrad slabs (fp32)  -> flat grads (fp32), summing `slabs` partials."""
 
     def __init__(self, ps: ParamStore, pack_tbl: CopyTableBuilder, unpack_tbl: CopyTableBuilder,
-                 late_tbl: Optional[CopyTableBuilder] = None):
+                 late_tbl: Optional[CopyTableBuilder] = None, first_tbl: Optional[CopyTableBuilder] = None):
         self.ps, self.pack_tbl, self.unpack_tbl = ps, pack_tbl, unpack_tbl
         self.late_tbl = late_tbl            # packs that only the backward reads (dgrad layouts): off the forward's start
+        self.first_tbl = first_tbl          # packs the very first GEMM of the step needs (first=True): the only ones it waits for
 
     def rec(self, pname: str, p_off: int, p_strides: Sequence[int], dims: Sequence[int],
             w_mat: Optional[Mat], w_off: int, w_strides: Sequence[int],
             g_ptr: int = 0, g_strides: Optional[Sequence[int]] = None, slabs: int = 0, slab_stride: int = 0,
-            g_off: Optional[int] = None, late: bool = False):
+            g_off: Optional[int] = None, late: bool = False, first: bool = False):
         """One rectangular piece.  p_* address the parameter tensor (elements, relative to the
         parameter), w_* the packed forward matrix, g_* the wgrad slab (defaults to the same
         layout as the packed matrix)."""
         ps = self.ps
         if w_mat is not None:
             tbl = self.late_tbl if (late and self.late_tbl is not None) else self.pack_tbl
+            if first and not late and self.first_tbl is not None:
+                tbl = self.first_tbl
             tbl.add(ps.ptr(pname) + 4 * p_off, w_mat.ptr + w_off * ESIZE[w_mat.dtype],
                     dims, p_strides, w_strides, F3, w_mat.dtype)
         if g_ptr:
@@ -794,7 +797,7 @@ class EncoderPlan:
         for i, (f, s) in enumerate(zip(G.ENCODER_FILTERS, G.ENCODER_STRIDES)):
             nm = f"encoder.net.{i}.conv."
             Wm = Mat.new(ws, f"enc.wp.{i}", 1, Ep, f * cinp, F3)
-            packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], Wm, 0, [f * cinp, 1, cinp])
+            packer.rec(nm + "weight", 0, [cin * f, f, 1], [E, cin, f], Wm, 0, [f * cinp, 1, cinp], first=(i == 0))
             self.W.append(Wm)
             # dgrad layouts, bf16: [ci][k*Eb + co] <- W[co][ci][k]  (per output phase for strided layers)
             if s == 1:
@@ -811,12 +814,15 @@ class EncoderPlan:
                     phs.append(WT)
                 self.WT.append(phs)
             bt = ws.alloc(f"enc.wp.bias{i}", Ep, torch.float32)
-            packer.pack_tbl.add(ps.ptr(nm + "bias"), bt.data_ptr(), [E], [1], [1], F3, F3)
+            (packer.first_tbl if (i == 0 and packer.first_tbl is not None) else packer.pack_tbl).add(
+                ps.ptr(nm + "bias"), bt.data_ptr(), [E], [1], [1], F3, F3)
             self.bias.append(bt)
             cin, cinp, cinb = E, Ep, Eb
         self.gbuf = {}
 
-    def build_forward(self, plan: Plan):
+    def build_forward(self, plan: Plan, join_before_layer1=False):
+        """join_before_layer1: join spec (see Plan.add) for the layer-1 GEMM - the side lane that packs the weights of
+        layers 1.. while layer 0 (whose own weights were packed on the main lane) runs."""
         B, impl, Ep = self.B, self.impl, self.Ep
         plan.zero(self.ws, "enc.zero_cnt")
         cinp = self.Mp
@@ -828,7 +834,8 @@ class EncoderPlan:
                 F3, Y.rows, self.E, Ep, B, segs, self.W[i].ptr, flags=flags, out0=Y.view(), out1=Rm.view(),
                 out2=self.yb[i + 1].view(),
                 aux0=X.view(row_off=(f - 1) // 2) if res else null_view(), bias_ptr=self.bias[i].data_ptr(),
-                counter_ptr=self.zero_cnt.data_ptr() + 8 * i, impl=impl), f"enc.{i}", TAG_ENC)
+                counter_ptr=self.zero_cnt.data_ptr() + 8 * i, impl=impl), f"enc.{i}", TAG_ENC,
+                join=join_before_layer1 if i == 1 else False)
             cinp = Ep
 
     def build_backward(self, plan: Plan, need_input_grad: bool = True):

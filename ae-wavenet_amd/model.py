@@ -34,6 +34,7 @@ class TrainEngine:
     update_codebook_every_step: refresh emb from the EMA statistics each step (standard
     VQ-VAE-EMA); the reference only refreshes at global_step == 10000 (chassis.py:175-176).
     """
+    PACK_LANE = 2             # side lane of the forward-layout weight pack (layers 1.. of the encoder, biases, bottleneck)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
                               # forward plan; A/B: 8.02 -> 7.99 ms per step)
 
@@ -87,7 +88,10 @@ class TrainEngine:
         self.unpack_dec = CopyTableBuilder(ws, "tbl.unpack_dec")
         self.in_tbl = CopyTableBuilder(ws, "tbl.in")
         self.pack_late = CopyTableBuilder(ws, "tbl.pack_late")      # dgrad layouts of the encoder weights: backward only
-        self.pk = Packer(ps, self.pack_tbl, self.unpack_tbl, late_tbl=self.pack_late)
+        # the encoder's first layer waits for its own (small) weight pack only; the rest of the forward-layout packs
+        # (57 MB of fp32 encoder weights, biases, bottleneck) run on a side lane under layer 0
+        self.pack_first = CopyTableBuilder(ws, "tbl.pack_first") if with_enc else None
+        self.pk = Packer(ps, self.pack_tbl, self.unpack_tbl, late_tbl=self.pack_late, first_tbl=self.pack_first)
         self.pk_dec = Packer(ps, self.pack_dec, self.unpack_dec)
         Mp = ru(self.n_mel, 64)
         self.mel_cl = Mat.new(ws, "mel_cl", B, g.mel_len, Mp, F3)
@@ -171,7 +175,7 @@ class TrainEngine:
         pack_slot = len(fa.ops)
         self.in_tbl.emit(fa, "mel->channels-last")
         if self.enc is not None:
-            self.enc.build_forward(fa)
+            self.enc.build_forward(fa, join_before_layer1=("lane", self.PACK_LANE) if self.pack_first is not None else False)
             E, Ep = hps.enc_n_out, ru(hps.enc_n_out, 64)
             y9 = self.enc.y[9]
             flags = L.EF_BIAS if bn == "ae" else 0
@@ -398,7 +402,12 @@ class TrainEngine:
         pk_plan = Plan("pack")
         with pk_plan.side():                                   # joined by the end of fwd_a
             self.pack_dec.emit(pk_plan, "pack weights (decoder)")
-        self.pack_tbl.emit(pk_plan, "pack weights")
+        if self.pack_first is not None and self.pack_first.recs:
+            self.pack_first.emit(pk_plan, "pack weights (encoder layer 0)")
+            with pk_plan.side(self.PACK_LANE):
+                self.pack_tbl.emit(pk_plan, "pack weights")
+        else:
+            self.pack_tbl.emit(pk_plan, "pack weights")
         fa.ops[pack_slot:pack_slot] = pk_plan.ops
         fa.labels[pack_slot:pack_slot] = pk_plan.labels
         for op in pk_plan.ops:
