@@ -184,6 +184,82 @@ __global__ __launch_bounds__(256) void k_vq_nearest_part(const aew_vq_nearest_t 
         reinterpret_cast<int*>(pd)[1] = bi;
     }
 }
+// The same partial scan for QB queries per block: a thread keeps ITS code row (D floats) and its squared norm in
+// registers and meets QB encoder outputs staged in LDS - the row is fetched once instead of once per query (the fetch
+// is one 128-byte row per lane, the expensive access of the scan).  Every (query, code) distance is the same ascending
+// fma chain as in vq_scan and the minimum takes the lowest index on ties, so indices and distances are bit-identical.
+template <int D, int QB>
+__global__ __launch_bounds__(256) void k_vq_nearest_part_mq(const aew_vq_nearest_t p) {
+    __shared__ float sh_z[QB][D];
+    __shared__ float sh_zn[QB];
+    __shared__ float sh_d[QB][4];
+    __shared__ int sh_i[QB][4];
+    const int s = blockIdx.x, q0 = blockIdx.y * QB;
+    const int per = (p.K + p.n_split - 1) / p.n_split;           // <= 256 (launcher)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nq = min(QB, p.Q - q0);
+    for (int e = threadIdx.x; e < QB * D; e += 256) {
+        const int qi = e / D, j = e - qi * D;
+        sh_z[qi][j] = qi < nq ? p.ze[(int64_t)(q0 + qi) * p.d_pitch + j] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < QB) {                                      // ||z||: the chain of vq_znorm
+        float zz = 0.f;
+        for (int j = 0; j < D; ++j) zz = __fmaf_rn(sh_z[threadIdx.x][j], sh_z[threadIdx.x][j], zz);
+        sh_zn[threadIdx.x] = sqrtf(zz);
+    }
+    const int k = s * per + threadIdx.x;
+    const bool live = threadIdx.x < per && k < p.K;
+    float c[D];
+    float qq = 0.f;
+    {
+        const float* cp = p.emb + (int64_t)(live ? k : 0) * D;
+#pragma unroll
+        for (int j = 0; j < D; j += 4) {
+            const float4 c4 = *reinterpret_cast<const float4*>(cp + j);
+            c[j] = c4.x; c[j + 1] = c4.y; c[j + 2] = c4.z; c[j + 3] = c4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) qq = __fmaf_rn(c[j], c[j], qq);
+    }
+    const float sq = sqrtf(qq);
+    __syncthreads();
+#pragma unroll 1
+    for (int qi = 0; qi < nq; ++qi) {
+        float dd = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float t = __fsub_rn(sh_z[qi][j], c[j]);
+            dd = __fmaf_rn(t, t, dd);
+        }
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        if (live) {
+            const float v = p.metric == 0 ? __fdiv_rn(sqrtf(dd), __fadd_rn(sh_zn[qi], sq)) : dd;
+            if (v < best) { best = v; bi = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { sh_d[qi][wv] = best; sh_i[qi][wv] = bi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < nq) {
+        const int qi = threadIdx.x;
+        float best = sh_d[qi][0];
+        int bi = sh_i[qi][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sh_d[qi][w] < best || (sh_d[qi][w] == best && sh_i[qi][w] < bi)) { best = sh_d[qi][w]; bi = sh_i[qi][w]; }
+        float* pd = reinterpret_cast<float*>(p.scratch) + ((int64_t)(q0 + qi) * p.n_split + s) * 2;
+        pd[0] = best;
+        reinterpret_cast<int*>(pd)[1] = bi;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_vq_nearest_combine(const aew_vq_nearest_t p) {
     const int q = blockIdx.x;
     const float* pd = reinterpret_cast<const float*>(p.scratch) + (int64_t)q * p.n_split * 2;
@@ -1075,7 +1151,14 @@ static int launch_copy(const aew_copy_table_t& t, hipStream_t st) {
 static int launch_vq_nearest(const aew_vq_nearest_t& p, hipStream_t st) {
     if (p.scratch && p.n_split > 1) {
         if (p.n_split > 64 || ((uintptr_t)p.scratch & 7)) return AEW_E_ARG;
-        hipLaunchKernelGGL(k_vq_nearest_part, dim3(p.n_split, p.Q), dim3(256), 0, st, p);
+        const int per = (p.K + p.n_split - 1) / p.n_split;
+        const bool al = (((uintptr_t)p.emb) & 15) == 0;
+        if (per <= 256 && al && p.d == 32 && p.Q >= 16)
+            hipLaunchKernelGGL((k_vq_nearest_part_mq<32, 8>), dim3(p.n_split, (p.Q + 7) / 8), dim3(256), 0, st, p);
+        else if (per <= 256 && al && p.d == 64 && p.Q >= 16)
+            hipLaunchKernelGGL((k_vq_nearest_part_mq<64, 8>), dim3(p.n_split, (p.Q + 7) / 8), dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL(k_vq_nearest_part, dim3(p.n_split, p.Q), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_vq_nearest_combine, dim3(p.Q), dim3(64), 0, st, p);
         return (int)hipGetLastError();
     }
