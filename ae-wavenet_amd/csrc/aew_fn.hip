@@ -661,6 +661,7 @@ static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st) {
 // rooflines are grouped by the kernel that ran, like a rocprofv3 kernel trace groups them by name).
 //   0 k_gemm_nt_bf16 (256- or 192-row tiles)   1 k_gemm_nt_bf16_p64 (64-row tiles: launches of few tiles)
 //   2 k_fn (full-N loader / consumer)          3 k_gemm_nt_f32        4 k_gemm_nt_check      5 an A/B shape
+//   6 k_gemm_nt_bf16_win (one LDS window for both taps of a dilated pair)
 extern "C" int aew_nt_kernel(const aew_gemm_nt_t* gp) {
     if (!gp) return AEW_E_ARG;
     const aew_gemm_nt_t& g = *gp;
@@ -671,5 +672,8 @@ extern "C" int aew_nt_kernel(const aew_gemm_nt_t* gp) {
     bool zspan = true;
     for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
     const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
-    return (g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan) ? 1 : 0;
+    if (g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan) return 1;
+    return win_dwp(g) ? 6 : 0;
 }
+
+extern "C" int aew_set_nt_window(int max_dist) { g_nt_window = max_dist < 0 ? 0 : (max_dist > 64 ? 64 : max_dist); return 0; }

@@ -1907,6 +1907,9 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
     g.out[(int64_t)slab * g.out_batch_stride + (int64_t)n * g.K_total + k] = acc;
 }
 
+#include "aew_win.hip"                                // k_gemm_nt_bf16_win: one LDS window for both dilation taps
+
+#ifndef AEW_DEV_KERNELS_ONLY   /* a development TU (ISA inspection of single kernels) stops here */
 // =============================================================================================
 // host-side launchers
 // =============================================================================================
@@ -2066,6 +2069,10 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             const int tiles192 = ((g.M + 191) / 192) * g.batch * (g.N_pad / NT_BN);
             const int c256 = ((tiles256 + 255) / 256) * 256, c192 = ((tiles192 + 255) / 256) * 192;
             t192 = g_nt_rows192 == 2 || c192 * 10 < c256 * 9;
+        }
+        if (!p64r && g_nt_wave_rows == 64) {                 // both taps of a dilated pair from one LDS window
+            const int dwp = win_dwp(g);
+            if (dwp) return launch_win(g, dwp, t192, st);
         }
         const int bm = p64r ? 64 : (p128 ? 128 : (t192 ? 192 : NT_BM)), bn = (p128 || p64r) ? 128 : (wide ? 256 : NT_BN);
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
@@ -2233,3 +2240,4 @@ static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
     }
     return (int)hipGetLastError();
 }
+#endif  /* AEW_DEV_KERNELS_ONLY */

@@ -483,6 +483,11 @@ int aew_set_nf_loaders(int on);
 /* default NT shape only: 192 x 128 tiles (8 waves of 48x64) instead of 256 x 128 — 0 never, 1 (default) where the
  * per-CU cost model prefers them, 2 always.  Results are bit-identical either way. */
 int aew_set_nt_rows192(int mode);
+/* default NT shape only: descriptors whose first two segments are the SAME buffer at row offsets d <= max_dist apart
+ * (the two taps of a dilated convolution, wavenet.py:100-101, and of its input gradient) stage ONE LDS window of
+ * 256 + d rows per K tile and issue both taps' MFMAs from it (k_gemm_nt_bf16_win).  Default 64 (the largest
+ * supported), 0 = never.  Results agree with the two-segment kernel to fp32 accumulation order, not bit for bit. */
+int aew_set_nt_window(int max_dist);
 /* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
 int aew_set_lanes(int on);
 

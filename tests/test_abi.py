@@ -64,18 +64,27 @@ def test_nt_kernel_query_follows_the_dispatch_rules():
     y = Mat.new(ws, "y", 8, 6100, 512, L.BF16)
     segs = [x.seg(384), x.seg(384, row_off=16)]
     q = lambda g: lib.aew_nt_kernel(C.byref(g))
-    assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view())) == 0
+    # two taps of one tensor, 16 rows apart: the one-window kernel; 128 rows apart (or with it switched off): the
+    # two-segment kernel
+    far = [x.seg(384), x.seg(384, row_off=128)]
+    assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view())) == 6
+    assert q(make_nt(L.BF16, 5900, 512, 512, 8, far, W.ptr, out0=y.view())) == 0
+    lib.aew_set_nt_window(8)
+    try:
+        assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view())) == 0
+    finally:
+        lib.aew_set_nt_window(64)
     assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view(), impl=2)) == 2
     assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view(), impl=1)) == 4
     assert q(make_nt(L.BF16, 70, 512, 512, 8, segs, W.ptr, out0=y.view())) == 1           # 8 x 4 tiles of 256 rows
     lib.aew_set_nt_small_tiles(0)
     try:
-        assert q(make_nt(L.BF16, 70, 512, 512, 8, segs, W.ptr, out0=y.view())) == 0
+        assert q(make_nt(L.BF16, 70, 512, 512, 8, far, W.ptr, out0=y.view())) == 0
     finally:
         lib.aew_set_nt_small_tiles(128)
     lib.aew_set_fn(0)
     try:
-        assert q(make_nt(L.BF16, 6000, 512, 512, 8, segs, W.ptr, out0=y.view(), impl=2)) == 0
+        assert q(make_nt(L.BF16, 5900, 512, 512, 8, far, W.ptr, out0=y.view(), impl=2)) == 0
     finally:
         lib.aew_set_fn(1)
     xf = Mat.new(ws, "xf", 8, 80, 768, L.F32)

@@ -190,6 +190,82 @@ def test_gemm_nt(dtype, epi):
         assert torch.equal(results[0]["O0"], results[1]["O0"])
 
 
+def _win_case(ws, kind, d, impl):
+    """The two shapes the decoder runs on the window kernel: the gated layer (wavenet.py:100-101: x[t], x[t+d] of one
+    tensor + the conditioning projection) and its input gradient (dfg[t], dfg[t-d], rows outside dfg read as zero)."""
+    B = 2
+    if kind == "gated":
+        Lin, K, Kc, Np = 777, 384, 128, 256
+        X = Mat(ws, "X", B, Lin, K, BF)
+        Cn = Mat(ws, "C", B, Lin + 40, Kc, BF)
+        Wm = Mat(ws, "W", 1, Np, 2 * K + Kc, BF)
+        O0, O1, O2 = (Mat(ws, n, B, Lin, 128, BF) for n in ("O0", "O1", "O2"))
+        segs = [X.seg(K), X.seg(K, row_off=d), Cn.seg(Kc, row_off=d + 3)]
+        return make_nt(BF, Lin - d, 128, Np, B, segs, Wm.ptr, epi=L.EPI_GATED, out0=O0.view(), out1=O1.view(),
+                       out2=O2.view(), bias_ptr=ws.get("bias").data_ptr(), bias_bs=256, impl=impl)
+    Lout, K, Np = 700, 256, 384
+    Dm = Mat(ws, "X", B, Lout, K, BF)
+    Wm = Mat(ws, "W", 1, Np, 2 * K, BF)
+    O0 = Mat(ws, "O0", B, Lout + d, Np, BF)
+    A0 = Mat(ws, "A0", B, Lout + d, Np, BF)
+    segs = [Dm.seg(K), Dm.seg(K, row_off=-d)]
+    return make_nt(BF, Lout + d, 368, Np, B, segs, Wm.ptr, flags=L.EF_ADD_AUX0, out0=O0.view(),
+                   aux0=A0.view(row_off=-d, hi=Lout), impl=impl)
+
+
+@pytest.mark.parametrize("kind", ["gated", "dx"])
+@pytest.mark.parametrize("d", [1, 2, 4, 8, 16, 32, 64, 5, 48])
+def test_gemm_nt_window(kind, d):
+    """k_gemm_nt_bf16_win (one LDS window for both dilation taps) against the two-segment kernel (same products,
+    other summation order: agreement to fp32 rounding, i.e. at most one bf16 ulp in a few outputs), the scalar check
+    kernel and the CPU interpreter."""
+    gen = torch.Generator().manual_seed(11 + d)
+    ws_c = Workspace("cpu")
+    ws_c.alloc("X", 2 * 777 * 384, torch.bfloat16); ws_c.alloc("C", 2 * 817 * 128, torch.bfloat16)
+    ws_c.alloc("W", 384 * 896, torch.bfloat16)
+    for n in ("O0", "O1", "O2", "A0"):
+        ws_c.alloc(n, 2 * 800 * 384, torch.bfloat16)
+    ws_c.alloc("bias", 2 * 256, torch.float32)
+    for n in ("X", "C", "A0", "bias"):
+        _fill(ws_c, n, gen)
+    _fill(ws_c, "W", gen, 0.06)
+    lib = L.load()
+    res = {}
+    try:
+        lib.aew_set_nt_small_tiles(0)
+        # win192: the 192-row tile form of the window kernel (what the cost model picks for the shorter layers)
+        for tag, impl, win, r192 in (("win", 0, 64, 0), ("win192", 0, 64, 2), ("two", 0, 0, 0), ("chk", 1, 0, 0)):
+            lib.aew_set_nt_window(win)
+            lib.aew_set_nt_rows192(r192)
+            ws_g = _mirror(ws_c, DEV)
+            p = Plan("nt")
+            op = p.add(L.OP_GEMM_NT, _win_case(ws_g, kind, d, impl), "nt")
+            assert lib.aew_nt_kernel(C.byref(op.u.nt)) == {"win": 6, "win192": 6, "two": 0, "chk": 4}[tag]
+            p.run(stream())
+            torch.cuda.synchronize()
+            res[tag] = {n: ws_g.get(n).float().cpu() for n in ("O0", "O1", "O2")}
+    finally:
+        lib.aew_set_nt_small_tiles(128)
+        lib.aew_set_nt_window(64)
+        lib.aew_set_nt_rows192(1)
+    ws_e = Workspace("cpu")
+    for n, t in ws_c.bufs.items():
+        ws_e.bufs[n] = t.clone()
+    p = Plan("nt")
+    p.add(L.OP_GEMM_NT, _win_case(ws_e, kind, d, 0), "nt")
+    Emu(ws_e).run(p)
+    for n in ("O0", "O1", "O2"):
+        ref = ws_e.get(n).float()
+        scale = max(1.0, ref.abs().max().item())
+        for tag in ("win", "win192", "two", "chk"):
+            err = (res[tag][n] - ref).abs().max().item()
+            assert err <= 2e-2 * scale, (n, tag, err)
+        assert torch.equal(res["win"][n], res["win192"][n]), n                    # same chain per output, other tiling
+        dw = (res["win"][n] - res["two"][n]).abs()
+        assert dw.max().item() <= 2.0 ** -7 * scale, (n, dw.max().item())        # one bf16 ulp at the top binade
+        assert (dw > 0).float().mean().item() < 0.05, (n, (dw > 0).float().mean().item())
+
+
 @pytest.mark.parametrize("dtype", [BF, F3])
 @pytest.mark.parametrize("safe,Mc", [(0, 777), (1, 777), (0, 5000)])
 def test_gemm_tn(dtype, safe, Mc):

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the engine-level training step under different kernel settings, ONE process, one box
+(box-to-box spread is +-0.15 ms, so only interleaved runs on one box are comparable: profiles/r02_notes.md).
+
+    python tools/ab_step.py base "nt_window=0" "nt_window=16" [--rounds 4 --steps 20 --per-op nt_window=0]
+
+A configuration is a comma list of `setter=value` (aew_set_<setter>(value)); `base` = the defaults.  Setters that
+change kernel choice at launch time only (nt_window, nt_rows192, nt_small_tiles, ...) are safe to flip on a built
+engine: the captured graphs are dropped and re-captured.  Prints ms/step per configuration and round, and with
+--per-op the per-op HIP-event table (serial plan order) of the named configurations.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DEFAULTS = {"nt_window": 64, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 1, "fn": 1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="+")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
+    ap.add_argument("--per-op", dest="per_op", action="append", default=[])
+    ap.add_argument("--out", default=None, help="directory for the per-op tables")
+    args = ap.parse_args()
+    import torch
+    from ae_wavenet_amd import _lib as L, autoencoder_model as ae, config
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=0.12)
+    torch.manual_seed(2507)
+    model = ae.AutoEncoder(hps, n_mel=39).to(dev)
+    eng = model._ensure_engine(args.batch)
+    g = eng.geom
+    gen = torch.Generator().manual_seed(0)
+    wav = torch.randint(0, 256, (args.batch, g.enc_in_len), generator=gen).float().to(dev)
+    mel = torch.randn(args.batch, 39, g.mel_len, generator=gen).to(dev)
+    voice = torch.randint(0, 40, (args.batch,), generator=gen).to(dev)
+    jitter = torch.arange(g.embed_len).repeat(args.batch, 1).to(dev)
+    eng.set_inputs(wav, mel, voice, jitter)
+    plans = [p for p in (eng.fwd_a, eng.fwd_b, eng.bwd, getattr(eng, "bwd_a", None), getattr(eng, "bwd_b", None),
+                         getattr(eng, "cb", None), getattr(eng, "fwd_b_noema", None), getattr(eng, "ema_plan", None))
+             if p is not None]
+
+    def apply(cfg):
+        vals = dict(DEFAULTS)
+        if cfg != "base":
+            for kv in cfg.split(","):
+                k, v = kv.split("=")
+                vals[k] = int(v)
+        for k, v in vals.items():
+            getattr(lib, "aew_set_" + k)(v)
+        for p in plans:
+            p.invalidate_graph()
+
+    def step():
+        eng.forward()
+        eng.backward()
+        eng.adam_step(1e-4, 1.0)
+
+    def timed(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    res = {c: [] for c in args.configs}
+    for r in range(args.rounds):
+        for c in args.configs:
+            apply(c)
+            for _ in range(3):
+                step()
+            res[c].append(timed(args.steps))
+    for c in args.configs:
+        v = res[c]
+        print(f"{c:40s} " + " ".join(f"{x:7.3f}" for x in v) + f"   min {min(v):.3f} ms/step", flush=True)
+    import ctypes as C
+    for c in args.per_op:
+        apply(c)
+        lib.aew_set_lanes(0)
+        for _ in range(2):
+            step()
+        lib.aew_timing_enable(1)
+        n_t = 3
+        for _ in range(n_t):
+            eng.forward(None, timing=True)
+            eng.backward(timing=True)
+            eng.adam_step(1e-4, 1.0)
+        cap = 1 << 16
+        ms = (C.c_float * cap)()
+        tags = (C.c_int32 * cap)()
+        cnt = C.c_int(0)
+        L.check(lib.aew_timing_read(ms, tags, cap, C.byref(cnt)), "timing_read")
+        lib.aew_timing_enable(0)
+        labels = eng.fwd_a.labels + eng.fwd_b.labels + eng.bwd.labels + (eng.cb.labels if hasattr(eng, "cb") else []) + eng.opt.labels
+        per, cls = {}, {}
+        for i in range(min(cnt.value, cap)):
+            lab = labels[i % len(labels)]
+            per[lab] = per.get(lab, 0.0) + ms[i] / n_t
+            k = tags[i] // 100
+            cls[k] = cls.get(k, 0.0) + ms[i] / n_t
+        grp = {}
+        import re
+        for lab, v in per.items():
+            key = re.sub(r"\d+", "#", lab)
+            grp[key] = grp.get(key, 0.0) + v
+        print(f"--- per-op (serial order), config {c}: classes " + " ".join(f"{k}:{v:.3f}" for k, v in sorted(cls.items()))
+              + f" sum {sum(cls.values()):.3f} ms")
+        for key, v in sorted(grp.items(), key=lambda kv: -kv[1])[:40]:
+            print(f"   {v:8.4f}  {key}")
+        if args.out:
+            os.makedirs(args.out, exist_ok=True)
+            with open(os.path.join(args.out, "per_op_" + c.replace("=", "").replace(",", "_") + ".txt"), "w") as fh:
+                for lab, v in sorted(per.items(), key=lambda kv: -kv[1]):
+                    fh.write(f"{v:9.4f}  {lab}\n")
+        apply("base")
+
+
+if __name__ == "__main__":
+    main()
