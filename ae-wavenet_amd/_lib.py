@@ -22,7 +22,7 @@ EF_OUT2_COPY = 1 << 10
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
- OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC, OP_MOMENTS) = range(1, 24)
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC, OP_MOMENTS, OP_GEMM_TN_GROUP) = range(1, 25)
 
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -49,7 +49,12 @@ class GemmNT(C.Structure):
 class GemmTN(C.Structure):
     _fields_ = [("dtype", i32), ("impl", i32), ("Mc", i32), ("batch", i32), ("N", i32),
                 ("N_pad", i32), ("g", Seg), ("n_segs", i32), ("K_total", i32),
-                ("seg", Seg * MAX_SEGS), ("out", vp), ("out_batch_stride", i64)]
+                ("seg", Seg * MAX_SEGS), ("out", vp), ("out_batch_stride", i64),
+                ("snap_out", vp), ("snap_bs", i64), ("snap_k", i32), ("pad_", i32)]
+
+
+class GemmTNGroup(C.Structure):
+    _fields_ = [("descs", vp), ("tile_map", vp), ("n_descs", i32), ("n_blocks", i32)]
 
 
 class CopyRec(C.Structure):
@@ -108,7 +113,7 @@ class SpkBwd(C.Structure):
                 ("off_proj_sig", vp), ("off_proj_gate", vp), ("off_spk_w", i64),
                 ("off_spk_b", i64), ("B", i32), ("L", i32), ("D", i32), ("D_pad", i32),
                 ("C_lc", i32), ("G", i32), ("n_speakers", i32), ("colsum", vp), ("gc", vp),
-                ("grads", vp)]
+                ("grads", vp), ("colsum_running", i32), ("pad_", i32)]
 
 
 class BaseGather(C.Structure):
@@ -186,7 +191,7 @@ class _OpU(C.Union):
                 ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
                 ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
                 ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag), ("mfcc", Mfcc),
-                ("mom", Moments)]
+                ("mom", Moments), ("tng", GemmTNGroup)]
 
 
 class Op(C.Structure):
@@ -198,7 +203,7 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
             OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit",
-            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc", OP_MOMENTS: "mom"}
+            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc", OP_MOMENTS: "mom", OP_GEMM_TN_GROUP: "tng"}
 
 # ---- autoregressive sampler (aew_actor_t / aew_sampler_t) ----
 ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMPLE = -1, 0, 1, 2, 3, 4, 5, 6
@@ -259,6 +264,7 @@ def load():
     lib.aew_selftest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.aew_tn_slabs.argtypes = [C.c_void_p]
     lib.aew_tn_fold.argtypes = [C.c_void_p]
+    lib.aew_tn_group_check.argtypes = [C.c_void_p]
     lib.aew_nt_kernel.argtypes = [C.c_void_p]
     lib.aew_graph_capture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.aew_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
@@ -269,7 +275,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 13:
+    if lib.aew_abi_version() != 14:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -293,4 +299,4 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
            "aew_set_lanes", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nt_small_waves", "aew_set_nf_deep", "aew_set_nf_loaders", "aew_set_nt_rows192",
-           "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window")
+           "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_tn_group_check")

@@ -1555,32 +1555,22 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
 // 4 waves as 2 (k) x 2 (n): each wave owns 64 (k cols of the A segment) x 64 (n cols of G) of the
 // 128 x 128 output tile (4x4 MFMA tiles -> one transpose-read per MFMA).  3-stage LDS ring with
 // counted vmcnt like the NT kernel.
-template <int SAFE>
-__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits,
-                                                                int rows_per_split, int fold_batch) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+//
+// tn_bf16_tile: one output tile (kt, nt) contracted over rows [r_lo, r_hi) of the batch elements [b_lo, b_hi), in
+// that order, result to `out` ([N_pad][K_total] fp32).  SNAP: after each batch element the running sums of column
+// g.snap_k go to g.snap_out (see aewavenet.h; the caller passes SNAP only when the block contracts over everything).
+template <int SAFE, bool SNAP>
+__device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem, int kt, int nt, int b_lo, int b_hi,
+                                             int r_lo, int r_hi, float* out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 1, wn = wave >> 1;
-    const int nkt = g.K_total / TN_BT;
-    // XCD-aware order: the output tiles that contract over the same (batch, row chunk) are
-    // consecutive on ONE XCD, so the G / A rows of that chunk are fetched into its L2 once.
-    const int n_tiles = nkt * (g.N_pad / TN_BT);
-    const int n_chunks = splits * (fold_batch ? 1 : g.batch);
-    const int L = blockIdx.x, seq = L >> 3;
-    const int chunk = (seq / n_tiles) * 8 + (L & 7);
-    if (chunk >= n_chunks) return;
-    const int tile = seq % n_tiles;
-    const int kt = tile % nkt, nt = tile / nkt;
     const int n0 = nt * TN_BT;
-    const int sp = chunk % splits, bz = chunk / splits;
     const TnTile tt = tn_locate(g, kt, TN_BT);
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int b_lo = fold_batch ? 0 : bz, b_hi = fold_batch ? g.batch : bz + 1;
-    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
     const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
     const int total = nst * (b_hi - b_lo);
     TnPtrs<2> P;
@@ -1599,6 +1589,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     if (total > 0) issue_next();
     if (total > 1) issue_next();
     int stage = 0;
+    // SNAP: the lanes that hold column snap_k of this tile (if it lies in it): acc[si][j][sr] of lanes with
+    // (lane >> 4) == sg in the waves with (wave & 1) == sw
+    const int srel = SNAP ? g.snap_k - tt.koff : -1;
+    const bool snap_here = SNAP && g.snap_out && srel >= 0 && srel < TN_BT;
+    int c_in_b = 0, bdone = b_lo;
     for (int t = 0; t < total; ++t) {
         if (t + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 loads per stage per wave
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1618,9 +1613,24 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+        if (SNAP && ++c_in_b == nst) {                 // wave-uniform, once per batch element
+            c_in_b = 0;
+            if (snap_here && wk == (srel >> 6) && (lane >> 4) == ((srel >> 2) & 3)) {
+                const int si = (srel >> 4) & 3, sr = srel & 3;
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n0 + wn * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v = (i == si && r == sr) ? acc[i][j][r] : v;
+                    so[j * 16] = v;
+                }
+            }
+            ++bdone;
+        }
     }
-    const int slab = fold_batch ? sp : (bz * splits + sp);
-    float* out = g.out + (int64_t)slab * g.out_batch_stride;
     const int q = lane & 15, gq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1632,6 +1642,39 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
     }
+}
+
+template <int SAFE>
+__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_tn_t g, int splits,
+                                                                int rows_per_split, int fold_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkt = g.K_total / TN_BT;
+    // XCD-aware order: the output tiles that contract over the same (batch, row chunk) are
+    // consecutive on ONE XCD, so the G / A rows of that chunk are fetched into its L2 once.
+    const int n_tiles = nkt * (g.N_pad / TN_BT);
+    const int n_chunks = splits * (fold_batch ? 1 : g.batch);
+    const int L = blockIdx.x, seq = L >> 3;
+    const int chunk = (seq / n_tiles) * 8 + (L & 7);
+    if (chunk >= n_chunks) return;
+    const int tile = seq % n_tiles;
+    const int sp = chunk % splits, bz = chunk / splits;
+    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
+    const int slab = fold_batch ? sp : (bz * splits + sp);
+    tn_bf16_tile<SAFE, false>(g, smem, tile % nkt, tile / nkt, fold_batch ? 0 : bz, fold_batch ? g.batch : bz + 1,
+                              r_lo, r_hi, g.out + (int64_t)slab * g.out_batch_stride);
+}
+
+// Grouped form (aew_gemm_tn_group_t): block p takes tile tile_map[p] of descriptor table `descs` (device memory,
+// read with scalar loads: the index is wave-uniform and the table is never written while a plan runs) and contracts
+// it over every row of every batch element - one result, no slabs.
+__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp(const aew_gemm_tn_t* __restrict__ descs,
+                                                                    const int32_t* __restrict__ tile_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rec = __builtin_amdgcn_readfirstlane(tile_map[blockIdx.x]);
+    if (rec < 0) return;
+    const aew_gemm_tn_t& g = descs[rec >> 16];
+    const int tile = rec & 0xffff, nkt = g.K_total / TN_BT;
+    tn_bf16_tile<0, true>(g, smem, tile % nkt, tile / nkt, 0, g.batch, 0, g.Mc, g.out);
 }
 
 // =============================================================================================
@@ -1963,6 +2006,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16_big, TNB_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16_grp, TN_LDS_BYTES)
 #undef AEW_SET_LDS
     done = 1;
     return 0;
@@ -2199,6 +2243,34 @@ extern "C" int aew_tn_fold(const aew_gemm_tn_t* g) {
 }
 
 extern "C" int aew_set_tn_fold_rows(int rows) { g_tn_fold_rows = rows; return 0; }
+
+// host copy of a group's descriptors is not available (they live in device memory): the builder validated them with
+// aew_tn_group_check before uploading
+extern "C" int aew_tn_group_check(const aew_gemm_tn_t* g) {
+    if (!g) return AEW_E_ARG;
+    if (g->dtype != AEW_BF16 || g->n_segs < 1 || g->n_segs > AEW_MAX_SEGS || g->Mc <= 0 || g->batch <= 0 || !g->out)
+        return AEW_E_ARG;
+    int ksum = 0;
+    for (int s = 0; s < g->n_segs; ++s) {
+        const int rc = check_seg(g->seg[s], 2, TN_BT);
+        if (rc) return rc;
+        ksum += g->seg[s].k_len;
+    }
+    aew_seg_t gg = g->g; gg.k_len = TN_BT;
+    const int rc = check_seg(gg, 2, TN_BT);
+    if (rc) return rc;
+    if (ksum != g->K_total || g->N_pad % TN_BT || (g->N_pad / TN_BT) * (g->K_total / TN_BT) > 0xffff) return AEW_E_ARG;
+    if (g->snap_out && (g->snap_k < 0 || g->snap_k >= g->K_total)) return AEW_E_ARG;
+    return 0;
+}
+
+static int launch_gemm_tn_group(const aew_gemm_tn_group_t& p, hipStream_t st) {
+    if (!p.descs || !p.tile_map || p.n_descs <= 0 || p.n_blocks <= 0) return AEW_E_ARG;
+    const int rc = ensure_big_lds();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gemm_tn_bf16_grp, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
+    return (int)hipGetLastError();
+}
 
 static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.Mc <= 0 || g.batch <= 0 || !g.out) return AEW_E_ARG;

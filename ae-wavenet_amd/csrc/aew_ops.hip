@@ -491,13 +491,19 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
         const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
         const int64_t ov = ov0 + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
         float bsum = 0.f;
-        for (int b = 0; b < p.B; ++b) bsum += ok ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+        // per-batch column sum of dfg (colsum_running: the buffer holds the sums over batch elements 0..b)
+        auto cs_of = [&](int b) -> float {
+            if (!ok) return 0.f;
+            const float v = p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
+            return (p.colsum_running && b > 0) ? v - p.colsum[((int64_t)(b - 1) * p.L + l) * 2 * p.D_pad + n] : v;
+        };
+        for (int b = 0; b < p.B; ++b) bsum += cs_of(b);
         if (ok && ob >= 0) p.grads[ob + co] = bsum;
         for (int j = 0; j < p.G; ++j) {
             const float vj = ok ? p.params[ov + j] : 0.f;
             float gv = 0.f;
             for (int b = 0; b < p.B; ++b) {
-                const float cs = ok ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+                const float cs = cs_of(b);
                 gv += cs * p.gc[b * p.G + j];
                 const float part = wave_sum(cs * vj);
                 if (lane == 0) atomicAdd(&sh[b * p.G + j], part);

@@ -50,6 +50,7 @@ static int dispatch(const aew_op_t& op, hipStream_t st) {
         case AEW_OP_VQ_DIAG: return launch_vq_diag(op.u.diag, st);
         case AEW_OP_MFCC: return launch_mfcc(op.u.mfcc, st);
         case AEW_OP_MOMENTS: return launch_moments(op.u.mom, st);
+        case AEW_OP_GEMM_TN_GROUP: return launch_gemm_tn_group(op.u.tng, st);
         default: return AEW_E_UNSUP;
     }
 }

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib as L
 from . import geometry as G
-from .plan import (CopyTableBuilder, ESIZE, Mat, Plan, Workspace, make_nt, make_tn, null_view, ru)
+from .plan import (CopyTableBuilder, ESIZE, Mat, Plan, TnGroupBuilder, Workspace, make_nt, make_tn, null_view, ru)
 
 BF, F3 = L.BF16, L.F32
 
@@ -199,6 +199,17 @@ class DecoderPlan:
     # the tiled kernels on this workload (fused layer 100-121 us vs 77-104 us for the pair; profiles/r02_notes.md:
     # with one block per CU nothing runs under the epilogue's 220 KB of stores per tile) and stay opt-in (AEW_FN_OPS).
     fn_ops = frozenset(("skip", "dcond"))
+    wgrad_group = 64          # weight gradients of the gated stack (fg + res per layer), the skip weights and the post
+                              # network as grouped launches (AEW_OP_GEMM_TN_GROUP) of this many layers: every output
+                              # tile contracts over the whole time axis and batch in one block - one fp32 result per
+                              # matrix instead of 8-90 split-K slabs that the unpack has to read back, and the ones-
+                              # channel column gives the per-batch bias sums as running snapshots.  >= n_layers: ONE
+                              # launch after the chain (768 tiles for the 20-layer stack = 3 blocks per CU); smaller
+                              # groups run under the chain but were measured slower (a group of 8 layers is ~270 blocks
+                              # of 0.9 ms each: one block per CU is bound by its own fill latency, and the chain's
+                              # kernels lose the LDS those blocks hold: 8.63 / 9.68 ms per step with groups of 8 / 4
+                              # against 7.68 with one launch and 7.75 with one split-K op per matrix).  0: one TN op per
+                              # matrix (round 2's form)
     split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
                               # measured slower (8.86 vs 8.62 ms/step): half-batch launches lose more than the
                               # overlap of their tails returns
@@ -211,6 +222,8 @@ class DecoderPlan:
         import os as _os
         if _os.environ.get("AEW_FN_OPS") is not None:          # A/B aid: comma list, "" = none
             self.fn_ops = frozenset(v for v in _os.environ["AEW_FN_OPS"].split(",") if v)
+        if _os.environ.get("AEW_WGRAD_GROUP") is not None:     # A/B aid: layers per grouped wgrad launch, 0 = off
+            self.wgrad_group = int(_os.environ["AEW_WGRAD_GROUP"])
         self.gmul_ptr = ws.bufs["loss.gmul"].data_ptr() if "loss.gmul" in ws.bufs else 0
         self.n_lc_in = n_lc_in
         self.lc_src, self.wav, self.voice, self.jitter = lc_src, wav, voice, jitter
@@ -608,18 +621,54 @@ class DecoderPlan:
         late_tbl = pk.unpack_tbl
         if early_tbl is not None:
             pk.unpack_tbl = early_tbl
+        # grouped weight gradients (wgrad_group layers per launch, impl 0 only: the check kernels keep one op per
+        # matrix).  A group is emitted right after the dz GEMM of its lowest layer, on a side lane; the last one after
+        # the chain, together with the skip and post-network weight gradients.  With the ones channel in x the fg
+        # descriptors also deliver the running per-batch column sums of dfg.
+        grouped = self.wgrad_group > 0 and self.impl == 0
+        snap_ok = grouped and self.R < Rp
+        grp: Optional[TnGroupBuilder] = None
+        n_groups = 0
+        tail_descs = []                                        # (name, descriptor): join the last group
+
+        def group_add(name, t, tag):
+            nonlocal grp
+            if grp is None:
+                grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}")
+            ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
+            t.out, t.out_batch_stride = ptr, stride
+            grp.add(t, "wgrad." + name)
+            self.gbuf[name] = (ptr, stride, 1)
+            return ptr, stride, 1
+
+        def wgrad_late(name, dtype, Mc, N, N_pad, gseg, segs, tag):
+            """A weight gradient whose operands exist early but whose result is only needed at the end: grouped mode
+            defers it into the last group (one result, unpacked by the late table)."""
+            if not grouped:
+                return self._wgrad(plan, name, dtype, Mc, N, N_pad, gseg, segs, tag) + (pk.unpack_tbl,)
+            t = make_tn(dtype, Mc, B, N, N_pad, gseg, segs)
+            ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
+            t.out, t.out_batch_stride = ptr, stride
+            tail_descs.append((name, t))
+            self.gbuf[name] = (ptr, stride, 1)
+            return ptr, stride, 1, late_tbl
+
         # ---- post network
         if ps.has(p + "post2.bias"):
             self._colsum(plan, self.dlogits, w, Q, ps.ptr(p + "post2.bias", True), label="db.post2")
-        gp, gs, gn = self._wgrad(plan, "p2", BF, w, Q, Qp, self.dlogits.seg(Qp), [self.h1.seg(Pp)], TAG_POST)
+        gp, gs, gn, tbl = wgrad_late("p2", BF, w, Q, Qp, self.dlogits.seg(Qp), [self.h1.seg(Pp)], TAG_POST)
+        keep_tbl, pk.unpack_tbl = pk.unpack_tbl, tbl
         pk.rec(p + "post2.weight", 0, [P, 1], [Q, P], None, 0, [Pp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+        pk.unpack_tbl = keep_tbl
         plan.add(L.OP_GEMM_NT, make_nt(BF, w, Pp, Pp, B, [self.dlogits.seg(Qp)], self.Wp2T.ptr,
                                        flags=L.EF_MUL_POS1, out0=self.dh1.view(), aux1=self.h1.view(),
                                        impl=impl), "d.post2", TAG_POST)
         if ps.has(p + "post1.bias"):
             self._colsum(plan, self.dh1, w, P, ps.ptr(p + "post1.bias", True), label="db.post1")
-        gp, gs, gn = self._wgrad(plan, "p1", BF, w, P, Pp, self.dh1.seg(Pp), [self.h0.seg(Sp)], TAG_POST)
+        gp, gs, gn, tbl = wgrad_late("p1", BF, w, P, Pp, self.dh1.seg(Pp), [self.h0.seg(Sp)], TAG_POST)
+        keep_tbl, pk.unpack_tbl = pk.unpack_tbl, tbl
         pk.rec(p + "post1.weight", 0, [S, 1], [P, S], None, 0, [Sp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+        pk.unpack_tbl = keep_tbl
         plan.add(L.OP_GEMM_NT, make_nt(BF, w, Sp, Sp, B, [self.dh1.seg(Pp)], self.Wp1T.ptr,
                                        flags=L.EF_MUL_POS1, out0=self.dskp.view(), aux1=self.h0.view(),
                                        impl=impl), "d.post1", TAG_POST)
@@ -645,16 +694,28 @@ class DecoderPlan:
                 with plan.side(self.EARLY_LANE):               # upper half of the cond gradient: inputs complete
                     plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, hsegs, self.VfgT_hi.ptr,
                                                    out0=self.dcond_part.view(), impl=impl), "dcond_hi", TAG_DCOND)
-            if not last:
-                gp, gs, gn = self._wgrad(plan, f"res{l}", BF, P_l, R, Rp, dx_next.seg(Rp, hi=P_l),
-                                         [self.z[l].seg(Dp)], TAG_WG_RS)
-                pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
             x = self.x[l]
-            gp, gs, gn = self._wgrad(plan, f"fg{l}", BF, P_l, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp),
-                                     [x.seg(Rp), x.seg(Rp, row_off=d), self.cond.seg(Cp, row_off=lg.cond_lead)],
-                                     TAG_WG_FG)
+            fg_segs = [x.seg(Rp), x.seg(Rp, row_off=d), self.cond.seg(Cp, row_off=lg.cond_lead)]
+            if grouped:
+                if not last:
+                    gp, gs, gn = group_add(f"res{l}", make_tn(BF, P_l, B, R, Rp, dx_next.seg(Rp, hi=P_l),
+                                                              [self.z[l].seg(Dp)]), TAG_WG_RS)
+                    pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+                t = make_tn(BF, P_l, B, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp), fg_segs)
+                if snap_ok:
+                    t.snap_out, t.snap_bs, t.snap_k = self.colsum_fg.data_ptr() + 4 * l * 2 * Dp, NL * 2 * Dp, R
+                gp, gs, gn = group_add(f"fg{l}", t, TAG_WG_FG)
+            else:
+                if not last:
+                    gp, gs, gn = self._wgrad(plan, f"res{l}", BF, P_l, R, Rp, dx_next.seg(Rp, hi=P_l),
+                                             [self.z[l].seg(Dp)], TAG_WG_RS)
+                    pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+                gp, gs, gn = self._wgrad(plan, f"fg{l}", BF, P_l, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp), fg_segs,
+                                         TAG_WG_FG)
             spb = gn // B if (gn % B == 0 and gn >= B) else 0     # slabs per batch (0: batch folded)
-            if self.R < Rp and spb > 0:
+            if snap_ok:
+                pass                                               # running column sums come from the grouped wgrad
+            elif self.R < Rp and spb > 0:
                 # x carries a constant 1.0 in pad channel R (base_gather ones_channel), so column R
                 # of this wgrad is sum_t dfg[t][n]: gather it per batch for the bias / speaker grads
                 colsum_tbl.add(gp + 4 * R, self.colsum_fg.data_ptr() + 4 * l * 2 * Dp, [B, 2 * Dp],
@@ -669,6 +730,17 @@ class DecoderPlan:
                            None, row0 * Kfg, [32 * Kfg, Kfg, 1, Rp], g_ptr=gp, slabs=gn, slab_stride=gs)
                     pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
                            None, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
+            if grouped and grp is not None and len(grp.descs) >= 2 * self.wgrad_group - 1 and l > 0:
+                # (2 descriptors per layer, the last layer has no res: a full group holds wgrad_group layers)
+                with plan.side(self._next_lane("tng")):
+                    grp.emit(plan, f"wgrad.group{n_groups} (layers {l}..{l + (len(grp.descs) + 1) // 2 - 1})", TAG_WG_FG)
+                grp = None
+                n_groups += 1
+                if early_tbl is not None:
+                    with plan.side(1):                             # the first group's gradients: unpacked mid-chain
+                        early_tbl.emit(plan, "unpack grads (decoder, upper layers)", join=True)
+                    pk.unpack_tbl = late_tbl
+                    early_tbl = None
             dx = self.dx[l]
             segs = [self.dfg[l].seg(2 * Dp), self.dfg[l].seg(2 * Dp, row_off=-d)]
             plan.add(L.OP_GEMM_NT, make_nt(
@@ -677,7 +749,7 @@ class DecoderPlan:
                 out0=dx.view(hi=lg.in_len),
                 aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=self._impl("dx")), f"dx.{l}", TAG_DX)
             dx_next = dx
-            if early_tbl is not None and l == NL // 2:
+            if not grouped and early_tbl is not None and l == NL // 2:
                 with plan.side(1):                                 # after the wgrads issued so far, on any lane
                     early_tbl.emit(plan, "unpack grads (decoder, upper layers)", join=True)
                 pk.unpack_tbl = late_tbl
@@ -687,8 +759,20 @@ class DecoderPlan:
         # ---- skip weights of all layers: ONE wgrad with NL segments (mirror of the deferred skip GEMM):
         # dW_skp[s][l*Dp + k] = sum_t dskp[t][s] * z_l[t + skip_lead_l][k].  640 tiles x batch fill the
         # chip without row splits, so it writes B slabs instead of ~128 per layer.
-        gp, gs, gn = self._wgrad(plan, "skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
-                                 [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
+        gp, gs, gn, _tbl = wgrad_late("skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
+                                      [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
+        if grouped:
+            for name, t in tail_descs:
+                if grp is None:
+                    grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}")
+                grp.add(t, "wgrad." + name)
+            with plan.side(self._next_lane("tng")):
+                grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)", TAG_WG_FG)
+            grp = None
+            if early_tbl is not None:                              # a single group: nothing was unpacked mid-chain
+                pk.unpack_tbl = late_tbl
+                late_tbl.recs.extend(early_tbl.recs)
+                early_tbl = None
         for l in range(NL):
             pk.rec(p + f"conv_layers.{l}.dil_skp.weight", 0, [D, 1], [S, D], None, 0, [NL * Dp, 1],
                    g_ptr=gp, slabs=gn, slab_stride=gs, g_off=l * Dp)
@@ -717,6 +801,7 @@ class DecoderPlan:
         sbw = L.SpkBwd()
         self._fill_spk(sbw)
         sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
+        sbw.colsum_running = int(snap_ok)
         with plan.side(1):                                         # reads the side lanes' wgrad slabs: side join
             colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
             plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)

@@ -145,6 +145,8 @@ class Plan:
             cls = 1 if payload.dtype == L.BF16 else 3
         elif kind == L.OP_GEMM_TN:
             cls = 2 if payload.dtype == L.BF16 else 4
+        elif kind == L.OP_GEMM_TN_GROUP:
+            cls = 2
         op.kind, op.tag = kind, tag + 100 * cls
         op.lane, op.join = self.lane, (10 + join[1] if isinstance(join, tuple) else int(join))
         setattr(op.u, L.OP_FIELD[kind], payload)
@@ -237,7 +239,62 @@ def make_tn(dtype: int, Mc: int, batch: int, N: int, N_pad: int, gseg: L.Seg, se
     for i, s in enumerate(segs):
         t.seg[i] = s
     t.K_total = sum(s.k_len for s in segs)
+    t.snap_k = -1
     return t
+
+
+class TnGroupBuilder:
+    """Collects bf16 TN descriptors and emits them as ONE grouped launch (AEW_OP_GEMM_TN_GROUP): every output tile
+    contracts over the whole time axis and all batch elements in one block, so each descriptor gets one result (no
+    split-K slabs).  Descriptors and tile map are uploaded to device memory at emit()."""
+
+    N_XCD = 8
+
+    def __init__(self, ws: Workspace, name: str):
+        self.ws, self.name = ws, name
+        self.descs: List[L.GemmTN] = []
+        self.labels: List[str] = []
+
+    def add(self, t: L.GemmTN, label: str):
+        L.check(L.load().aew_tn_group_check(C.byref(t)), f"grouped TN descriptor '{label}'")
+        self.descs.append(t)
+        self.labels.append(label)
+
+    def tile_map(self) -> List[int]:
+        """blockIdx -> desc << 16 | tile.  Workgroup p runs on XCD p % 8: the tiles of one descriptor (they share
+        the G rows along k tiles and the A rows along n tiles) go to one XCD where there are enough descriptors,
+        otherwise a descriptor is cut by n tile; longest-first onto the least loaded XCD."""
+        units = []                                           # (tiles, desc, [tile ids])
+        for d, t in enumerate(self.descs):
+            nkt, nnt = t.K_total // 128, t.N_pad // 128
+            if len(self.descs) >= self.N_XCD:
+                units.append((nkt * nnt, d, list(range(nkt * nnt))))
+            else:
+                for nt in range(nnt):
+                    units.append((nkt, d, [nt * nkt + kt for kt in range(nkt)]))
+        lists = [[] for _ in range(self.N_XCD)]
+        for n, d, tiles in sorted(units, key=lambda u: (-u[0], u[1], u[2][0])):
+            x = min(range(self.N_XCD), key=lambda i: (len(lists[i]), i))
+            lists[x].extend((d << 16) | tl for tl in tiles)
+        depth = max(len(l) for l in lists)
+        out = []
+        for i in range(depth):
+            for x in range(self.N_XCD):
+                out.append(lists[x][i] if i < len(lists[x]) else -1)
+        return out
+
+    def emit(self, plan: "Plan", label: str, tag: int = 0, join: bool = False):
+        if not self.descs:
+            return None
+        raw = bytes((L.GemmTN * len(self.descs))(*self.descs))
+        dt = self.ws.alloc(f"{self.name}.descs", (len(raw) + 7) // 8, torch.int64, zero=True)
+        dt[:(len(raw) + 7) // 8].copy_(torch.frombuffer(bytearray(raw + b"\0" * (-len(raw) % 8)), dtype=torch.int64))
+        tm = self.tile_map()
+        mt = self.ws.alloc(f"{self.name}.tiles", len(tm), torch.int32, zero=True)
+        mt[:len(tm)].copy_(torch.tensor(tm, dtype=torch.int32))
+        gp = L.GemmTNGroup()
+        gp.descs, gp.tile_map, gp.n_descs, gp.n_blocks = dt.data_ptr(), mt.data_ptr(), len(self.descs), len(tm)
+        return plan.add(L.OP_GEMM_TN_GROUP, gp, label, tag, join=join)
 
 
 class CopyTableBuilder:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 13
+#define AEW_ABI_VERSION 14
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -148,7 +148,31 @@ typedef struct {
     aew_seg_t seg[AEW_MAX_SEGS];
     float* out;                  /* fp32 [batch][N_pad][K_total] per-batch partial sums       */
     int64_t out_batch_stride;
+    /* Grouped form only (AEW_OP_GEMM_TN_GROUP: the contraction runs over the batch elements in order inside one
+     * block).  With snap_out != NULL the running column sum_{b' <= b} sum_m G[b'][m][n] * A[b'][m][snap_k] is
+     * written after every batch element b:  snap_out[b * snap_bs + n].  With a constant-one channel at snap_k
+     * (the pad channel R of x, aew_base_gather_t.ones_channel) that is the running column sum of G - the per-batch
+     * bias / speaker-embedding gradients come out of the weight-gradient GEMM for free (aew_spk_bwd_t.colsum_running). */
+    float* snap_out;
+    int64_t snap_bs;
+    int32_t snap_k;              /* column of the concatenated K axis; < 0: none                */
+    int32_t pad_;
 } aew_gemm_tn_t;
+
+/* ---------------------------------------------------------------------------------------
+ * Grouped weight gradients: the output tiles of SEVERAL TN descriptors as one launch, each tile contracting over
+ * the WHOLE time axis and all batch elements (k ascending, b ascending) in one block.  One fp32 result per
+ * descriptor (desc.out[N_pad][K_total], no split-K slabs to write and sum), and enough tiles to fill the chip
+ * without splitting (20 layers x (4 x 7 + 3 x 2) tiles in the decoder).  Descriptors and the tile map live in
+ * DEVICE memory (built once per plan).  tile_map[p] = desc << 16 | tile (tile = nt * (K_total / 128) + kt), or -1:
+ * block p idles.  Workgroup p runs on XCD p % 8, so the builder places tiles that share operands on one XCD.
+ * bf16 only.  Same products as aew_gemm_tn_t ops; the summation order differs (one chain instead of slabs).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const aew_gemm_tn_t* descs;  /* device                                                      */
+    const int32_t* tile_map;     /* device                                                      */
+    int32_t n_descs, n_blocks;
+} aew_gemm_tn_group_t;
 
 /* ---------------------------------------------------------------------------------------
  * table-driven strided copy / convert / reduce (weight pack, gradient unpack, NCL<->NLC)
@@ -256,6 +280,9 @@ typedef struct {                 /* backward of the above from per-batch column 
     const float* colsum;         /* [B][L][2*D_pad]                                           */
     const float* gc;             /* [B][G]                                                    */
     float* grads;                /* flat fp32 gradient buffer (same offsets as params)        */
+    int32_t colsum_running;      /* 1: colsum[b] holds the sum over batch elements 0..b (aew_gemm_tn_t.snap_out);
+                                    the per-batch value is colsum[b] - colsum[b-1]              */
+    int32_t pad_;
 } aew_spk_bwd_t;
 
 typedef struct {                 /* base layer as a column gather (wavenet.py:348-351)        */
@@ -400,7 +427,7 @@ enum {
     AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
     AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
     AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG, AEW_OP_MFCC,
-    AEW_OP_MOMENTS
+    AEW_OP_MOMENTS, AEW_OP_GEMM_TN_GROUP
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
@@ -425,7 +452,7 @@ typedef struct {
         aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
         aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
         aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit; aew_vq_diag_t diag; aew_mfcc_t mfcc;
-        aew_moments_t mom;
+        aew_moments_t mom; aew_gemm_tn_group_t tng;
     } u;
 } aew_op_t;
 
@@ -493,6 +520,9 @@ int aew_set_lanes(int on);
 
 /* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */
 int aew_tn_slabs(const aew_gemm_tn_t* g);
+/* Validate one descriptor of a grouped launch (aew_gemm_tn_group_t.descs lives in device memory, so the launcher
+ * cannot): 0 or AEW_E_*.  Host logic only. */
+int aew_tn_group_check(const aew_gemm_tn_t* g);
 /* 1 if the op's batch loop is folded into one slab per split (short contractions). */
 int aew_tn_fold(const aew_gemm_tn_t* g);
 /* Contraction length (rows x batch) up to which TN ops fold the batch; default 4096. */

@@ -170,6 +170,31 @@ class Emu:
             o = ooff + sl * t.out_batch_stride
             out[o:o + t.N_pad * t.K_total] += dW.reshape(-1)
 
+    def op_24(self, p):  # GEMM_TN_GROUP: every descriptor contracted over all rows of all batch elements, one result
+        rt, roff = self.flat(p.descs)
+        nbytes = p.n_descs * C.sizeof(L.GemmTN)
+        raw = bytes(rt[roff:roff + (nbytes + 7) // 8].numpy().tobytes())
+        descs = (L.GemmTN * p.n_descs).from_buffer_copy(raw[:nbytes])
+        tm = self.rd(p.tile_map, torch.arange(p.n_blocks)).tolist()
+        covered = {}
+        for rec in tm:
+            if rec >= 0:
+                covered.setdefault(int(rec) >> 16, set()).add(int(rec) & 0xffff)
+        for d, t in enumerate(descs):
+            # the tile map must name every output tile of every descriptor exactly once
+            n_tiles = (t.N_pad // 128) * (t.K_total // 128)
+            assert covered.get(d, set()) == set(range(n_tiles)), f"tile map of descriptor {d}"
+            assert sum(1 for rec in tm if rec >= 0 and (int(rec) >> 16) == d) == n_tiles
+            out, ooff = self.flat(t.out)
+            dW = torch.zeros(t.N_pad, t.K_total)
+            for b in range(t.batch):
+                Gm = self.seg_matrix(self._with_k(t.g, t.N_pad), b, t.Mc, t.dtype)
+                A = torch.cat([self.seg_matrix(t.seg[s], b, t.Mc, t.dtype) for s in range(t.n_segs)], dim=1)
+                dW += Gm.t() @ A
+                if t.snap_out:
+                    self.wr(t.snap_out, b * t.snap_bs + torch.arange(t.N_pad), dW[:, t.snap_k])
+            out[ooff:ooff + t.N_pad * t.K_total] = dW.reshape(-1)
+
     @staticmethod
     def _with_k(seg, k):
         s = L.Seg()
@@ -327,6 +352,8 @@ class Emu:
         gr, goff = self.flat(p.grads)
         Cc = p.C_lc + p.G
         cs = self.rd(p.colsum, torch.arange(p.B * p.L * 2 * p.D_pad)).view(p.B, p.L, 2 * p.D_pad)
+        if p.colsum_running:                                    # sums over batch elements 0..b -> per batch element
+            cs = torch.cat([cs[:1], cs[1:] - cs[:-1]], dim=0)
         gc = self.rd(p.gc, torch.arange(p.B * p.G)).view(p.B, p.G)
         pi = self._pack_idx(p.D)
         dgc = torch.zeros(p.B, p.G)

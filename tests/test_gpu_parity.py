@@ -318,6 +318,78 @@ def test_gemm_tn(dtype, safe, Mc):
         assert err <= (2e-3 if dtype == BF else 2e-5) * scale, ("impl", impl, "safe", safe, err, scale)
 
 
+def test_gemm_tn_group():
+    """AEW_OP_GEMM_TN_GROUP: several weight-gradient descriptors in one launch, each output tile contracted over all
+    rows of all batch elements in one block (one result, no slabs), plus the running per-batch snapshots of the
+    ones-channel column.  Against the CPU interpreter and against the per-matrix TN ops + slab sum."""
+    from ae_wavenet_amd.plan import TnGroupBuilder
+    gen = torch.Generator().manual_seed(5)
+    B = 3
+
+    def build(ws):
+        G1 = Mat(ws, "G1", B, 700, 256, BF)
+        A1 = Mat(ws, "A1", B, 740, 384, BF)
+        A2 = Mat(ws, "A2", B, 760, 128, BF)
+        G2 = Mat(ws, "G2", B, 650, 384, BF)
+        Z = Mat(ws, "Z", B, 650, 256, BF)
+        descs = []
+        t = make_tn(BF, 690, B, 256, 256, G1.seg(256), [A1.seg(384), A1.seg(384, row_off=9), A2.seg(128, row_off=31)])
+        t.out, t.out_batch_stride = ws.get("o1").data_ptr(), 256 * 896
+        t.snap_out, t.snap_bs, t.snap_k = ws.get("snap").data_ptr(), 256, 368
+        descs.append(t)
+        t = make_tn(BF, 650, B, 368, 384, G2.seg(384, hi=640), [Z.seg(256)])
+        t.out, t.out_batch_stride = ws.get("o2").data_ptr(), 384 * 256
+        descs.append(t)
+        t = make_tn(BF, 33, B, 256, 256, G1.seg(256, row_off=5), [Z.seg(256, row_off=-2)])    # shorter than one stage pair
+        t.out, t.out_batch_stride = ws.get("o3").data_ptr(), 256 * 256
+        descs.append(t)
+        return descs
+
+    ws_c = Workspace("cpu")
+    for n, sz in (("G1", B * 700 * 256), ("A1", B * 740 * 384), ("A2", B * 760 * 128), ("G2", B * 650 * 384), ("Z", B * 650 * 256)):
+        ws_c.alloc(n, sz, torch.bfloat16)
+        _fill(ws_c, n, gen)
+    ws_c.get("A1").view(-1)[:B * 740 * 384].view(B * 740, 384)[:, 368] = 1.0        # the ones channel
+    for n, sz in (("o1", 256 * 896), ("o2", 384 * 256), ("o3", 256 * 256), ("snap", B * 256)):
+        ws_c.alloc(n, sz, torch.float32)
+        ws_c.alloc(n + ".ref", 8 * sz, torch.float32)
+    ws_g = _mirror(ws_c, DEV)
+    for ws in (ws_c, ws_g):
+        gb = TnGroupBuilder(ws, "tng")
+        for i, t in enumerate(build(ws)):
+            gb.add(t, f"d{i}")
+        p = Plan("g")
+        gb.emit(p, "group")
+        if ws is ws_g:
+            tm = gb.tile_map()
+            assert sorted(r for r in tm if r >= 0) == sorted((d << 16) | tl for d, n in enumerate((14, 6, 4)) for tl in range(n))
+            p.run(stream())
+            torch.cuda.synchronize()
+        else:
+            Emu(ws).run(p)
+    for n in ("o1", "o2", "o3", "snap"):
+        ref, got = ws_c.get(n).float(), ws_g.get(n).float().cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (n, err)
+    # the per-matrix ops (split-K slabs summed afterwards) give the same matrices
+    for i, (t, n) in enumerate(zip(build(ws_g), ("o1", "o2", "o3"))):
+        slabs = L.tn_slabs(t)
+        assert slabs <= 8
+        t.out = ws_g.get(n + ".ref").data_ptr()
+        p = Plan("t")
+        p.add(L.OP_GEMM_TN, t, "tn")
+        p.run(stream())
+        torch.cuda.synchronize()
+        numel = t.N_pad * t.K_total
+        ref = ws_g.get(n + ".ref")[:slabs * t.out_batch_stride].view(slabs, -1)[:, :numel].sum(0).cpu()
+        got = ws_g.get(n)[:numel].cpu()
+        assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item()), n
+    # snapshots: running sums over the batch elements of column 368 (= column sums of G1 rows, since A1[:, 368] = 1)
+    g1 = ws_c.get("G1")[:B * 700 * 256].view(B, 700, 256).float()
+    run_sum = torch.cumsum(g1[:, :690].sum(1), 0)
+    assert (ws_g.get("snap")[:B * 256].view(B, 256).cpu() - run_sum).abs().max().item() <= 2e-3 * run_sum.abs().max().item()
+
+
 @pytest.mark.parametrize("Np,ks", [(256, (128, 128, 256)), (384, (128, 256)), (128 * 5, (384, 384, 128)), (512, (384, 384, 128))])
 def test_gemm_tn_big_tiles(Np, ks):
     """256 x 256-tile wgrad kernel (k_gemm_tn_bf16_big) against the 128 x 128 kernel and the scalar check kernel: halves of
@@ -459,7 +531,7 @@ def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.", "scratch.")):
     bad = []
     for n, tc in ec.ws.bufs.items():
         if n.startswith(skip_prefix) or ".wg." in n or n.startswith("enc.wg") or n.startswith("bn.wg") or "tbl." in n \
-                or n == "bn.vq_part":
+                or n == "bn.vq_part" or ".tng" in n or n.startswith("tng"):
             continue                     # wgrad slabs / search scratch: implementation detail; tables hold pointers
         tg = eg.ws.get(n).cpu()
         if tc.dtype in (torch.int64, torch.int32):
@@ -667,7 +739,7 @@ def test_full_width_step_vs_interpreter_buffer_by_buffer():
     assert worst_fwd < 2e-2
     # ---- backward from the GPU's forward state
     for n, t in ec.ws.bufs.items():
-        if "tbl." not in n:                                   # (the copy tables hold each workspace's own pointers)
+        if "tbl." not in n and ".tng" not in n:                                 # (the copy tables hold each workspace's own pointers)
             t.copy_(eg.ws.get(n).cpu())
     emu.run(ec.bwd)
     eg.backward()

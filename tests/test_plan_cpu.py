@@ -163,6 +163,8 @@ def test_unfolded_wgrad_and_ones_channel_colsum(golden_dir, monkeypatch):
     unpacking and the bias gradients taken from the constant-one pad channel of x."""
     monkeypatch.setitem(PL.TORCH_DT, L.BF16, torch.float32)
     monkeypatch.setitem(PL.ESIZE, L.BF16, 4)
+    from ae_wavenet_amd import engine as E
+    monkeypatch.setattr(E.DecoderPlan, "wgrad_group", 0)       # one TN op per matrix (the grouped form has no slabs)
     lib = L.load()
     lib.aew_set_tn_fold_rows(0)
     try:
@@ -179,6 +181,27 @@ def test_unfolded_wgrad_and_ones_channel_colsum(golden_dir, monkeypatch):
         check_grads(eng, z, "gint", "wide")
     finally:
         lib.aew_set_tn_fold_rows(4096)
+
+
+@pytest.mark.parametrize("group", [8, 3, 1])
+def test_grouped_wgrad_plan(golden_dir, monkeypatch, group):
+    """The default backward: the gated stack's weight gradients as grouped launches (AEW_OP_GEMM_TN_GROUP, one
+    result per matrix, every tile named once in the tile map: the interpreter checks that) and the per-batch
+    bias / speaker sums from the running ones-channel snapshots, for several group sizes."""
+    monkeypatch.setitem(PL.TORCH_DT, L.BF16, torch.float32)
+    monkeypatch.setitem(PL.ESIZE, L.BF16, 4)
+    from ae_wavenet_amd import engine as E
+    monkeypatch.setattr(E.DecoderPlan, "wgrad_group", group)
+    z = load(golden_dir, "mi_tiny_jitter.npz")
+    hps, eng = make_engine(z, "mfcc_inverter", 7)
+    NL = len(eng.geom.layers)
+    kinds = [op.kind for op in eng.bwd.ops]
+    assert kinds.count(L.OP_GEMM_TN_GROUP) == -(-NL // group)
+    assert not any(lab.startswith(("wgrad.fg", "wgrad.res", "colsum.dfg")) for lab in eng.bwd.labels)
+    spk = [op.u.spkb for op in eng.bwd.ops if op.kind == L.OP_SPK_BWD]
+    assert len(spk) == 1 and spk[0].colsum_running == 1
+    run(eng, z)
+    check_grads(eng, z, "grad", "wide")
 
 
 def test_autoencoder_vae_plan(golden_dir, mode):

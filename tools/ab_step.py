@@ -4,7 +4,9 @@
 
     python tools/ab_step.py base "nt_window=0" "nt_window=16" [--rounds 4 --steps 20 --per-op nt_window=0]
 
-A configuration is a comma list of `setter=value` (aew_set_<setter>(value)); `base` = the defaults.  Setters that
+A configuration is a comma list of `setter=value` (aew_set_<setter>(value)) and `E.attr=value` (a DecoderPlan class
+attribute that shapes the plan, e.g. E.wgrad_group=0: one engine is built per distinct set of them); `base` = the
+defaults.  Setters that
 change kernel choice at launch time only (nt_window, nt_rows192, nt_small_tiles, ...) are safe to flip on a built
 engine: the captured graphs are dropped and re-captured.  Prints ms/step per configuration and round, and with
 --per-op the per-op HIP-event table (serial plan order) of the named configurations.
@@ -31,36 +33,60 @@ def main():
     ap.add_argument("--out", default=None, help="directory for the per-op tables")
     args = ap.parse_args()
     import torch
-    from ae_wavenet_amd import _lib as L, autoencoder_model as ae, config
+    from ae_wavenet_amd import _lib as L, autoencoder_model as ae, config, engine as E
     lib = L.load()
     dev = torch.device("cuda", 0)
     hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=0.12)
-    torch.manual_seed(2507)
-    model = ae.AutoEncoder(hps, n_mel=39).to(dev)
-    eng = model._ensure_engine(args.batch)
-    g = eng.geom
-    gen = torch.Generator().manual_seed(0)
-    wav = torch.randint(0, 256, (args.batch, g.enc_in_len), generator=gen).float().to(dev)
-    mel = torch.randn(args.batch, 39, g.mel_len, generator=gen).to(dev)
-    voice = torch.randint(0, 40, (args.batch,), generator=gen).to(dev)
-    jitter = torch.arange(g.embed_len).repeat(args.batch, 1).to(dev)
-    eng.set_inputs(wav, mel, voice, jitter)
-    plans = [p for p in (eng.fwd_a, eng.fwd_b, eng.bwd, getattr(eng, "bwd_a", None), getattr(eng, "bwd_b", None),
-                         getattr(eng, "cb", None), getattr(eng, "fwd_b_noema", None), getattr(eng, "ema_plan", None))
-             if p is not None]
+    e_defaults = {}
 
-    def apply(cfg):
-        vals = dict(DEFAULTS)
+    def parse(cfg):
+        vals, evals = dict(DEFAULTS), {}
         if cfg != "base":
             for kv in cfg.split(","):
                 k, v = kv.split("=")
-                vals[k] = int(v)
+                if k.startswith("E."):
+                    evals[k[2:]] = int(v)
+                else:
+                    vals[k] = int(v)
+        return vals, tuple(sorted(evals.items()))
+
+    engines = {}
+
+    def engine_for(ekey):
+        if ekey not in engines:
+            for k, v in ekey:
+                e_defaults.setdefault(k, getattr(E.DecoderPlan, k))
+                setattr(E.DecoderPlan, k, v)
+            torch.manual_seed(2507)
+            model = ae.AutoEncoder(hps, n_mel=39).to(dev)
+            eng = model._ensure_engine(args.batch)
+            for k, v in e_defaults.items():
+                setattr(E.DecoderPlan, k, v)
+            g = eng.geom
+            gen = torch.Generator().manual_seed(0)
+            wav = torch.randint(0, 256, (args.batch, g.enc_in_len), generator=gen).float().to(dev)
+            mel = torch.randn(args.batch, 39, g.mel_len, generator=gen).to(dev)
+            voice = torch.randint(0, 40, (args.batch,), generator=gen).to(dev)
+            jitter = torch.arange(g.embed_len).repeat(args.batch, 1).to(dev)
+            eng.set_inputs(wav, mel, voice, jitter)
+            engines[ekey] = (model, eng)
+        return engines[ekey][1]
+
+    cur = [None]
+
+    def apply(cfg):
+        vals, ekey = parse(cfg)
+        eng = engine_for(ekey)
+        cur[0] = eng
         for k, v in vals.items():
             getattr(lib, "aew_set_" + k)(v)
-        for p in plans:
-            p.invalidate_graph()
+        for p in (eng.fwd_a, eng.fwd_b, eng.bwd, getattr(eng, "bwd_a", None), getattr(eng, "bwd_b", None),
+                  getattr(eng, "cb", None), getattr(eng, "fwd_b_noema", None), getattr(eng, "ema_plan", None)):
+            if p is not None:
+                p.invalidate_graph()
 
     def step():
+        eng = cur[0]
         eng.forward()
         eng.backward()
         eng.adam_step(1e-4, 1.0)
@@ -86,6 +112,7 @@ def main():
     import ctypes as C
     for c in args.per_op:
         apply(c)
+        eng = cur[0]
         lib.aew_set_lanes(0)
         for _ in range(2):
             step()
