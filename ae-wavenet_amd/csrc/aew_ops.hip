@@ -491,11 +491,11 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
         const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
         const int64_t ov = ov0 + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
         float bsum = 0.f;
-        // per-batch column sum of dfg (colsum_running: the buffer holds the sums over batch elements 0..b)
+        // per-batch column sum of dfg (layers below colsum_running: the buffer holds the sums over batch elements 0..b)
         auto cs_of = [&](int b) -> float {
             if (!ok) return 0.f;
             const float v = p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
-            return (p.colsum_running && b > 0) ? v - p.colsum[((int64_t)(b - 1) * p.L + l) * 2 * p.D_pad + n] : v;
+            return (l < p.colsum_running && b > 0) ? v - p.colsum[((int64_t)(b - 1) * p.L + l) * 2 * p.D_pad + n] : v;
         };
         for (int b = 0; b < p.B; ++b) bsum += cs_of(b);
         if (ok && ob >= 0) p.grads[ob + co] = bsum;

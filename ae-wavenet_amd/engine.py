@@ -210,6 +210,8 @@ class DecoderPlan:
                               # kernels lose the LDS those blocks hold: 8.63 / 9.68 ms per step with groups of 8 / 4
                               # against 7.68 with one launch and 7.75 with one split-K op per matrix).  0: one TN op per
                               # matrix (round 2's form)
+    wgrad_split_layers = 0    # with grouped wgrads: the TOP this-many layers keep one split-K TN op per matrix (they run
+                              # under the dgrad chain and fill its tile-wave tails), the rest go to the grouped launch
     split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
                               # measured slower (8.86 vs 8.62 ms/step): half-batch launches lose more than the
                               # overlap of their tails returns
@@ -696,7 +698,7 @@ class DecoderPlan:
                                                    out0=self.dcond_part.view(), impl=impl), "dcond_hi", TAG_DCOND)
             x = self.x[l]
             fg_segs = [x.seg(Rp), x.seg(Rp, row_off=d), self.cond.seg(Cp, row_off=lg.cond_lead)]
-            if grouped:
+            if grouped and l < NL - self.wgrad_split_layers:
                 if not last:
                     gp, gs, gn = group_add(f"res{l}", make_tn(BF, P_l, B, R, Rp, dx_next.seg(Rp, hi=P_l),
                                                               [self.z[l].seg(Dp)]), TAG_WG_RS)
@@ -713,7 +715,7 @@ class DecoderPlan:
                 gp, gs, gn = self._wgrad(plan, f"fg{l}", BF, P_l, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp), fg_segs,
                                          TAG_WG_FG)
             spb = gn // B if (gn % B == 0 and gn >= B) else 0     # slabs per batch (0: batch folded)
-            if snap_ok:
+            if snap_ok and l < NL - self.wgrad_split_layers:
                 pass                                               # running column sums come from the grouped wgrad
             elif self.R < Rp and spb > 0:
                 # x carries a constant 1.0 in pad channel R (base_gather ones_channel), so column R
@@ -801,7 +803,7 @@ class DecoderPlan:
         sbw = L.SpkBwd()
         self._fill_spk(sbw)
         sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
-        sbw.colsum_running = int(snap_ok)
+        sbw.colsum_running = max(0, NL - self.wgrad_split_layers) if snap_ok else 0
         with plan.side(1):                                         # reads the side lanes' wgrad slabs: side join
             colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
             plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)

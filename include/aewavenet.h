@@ -280,8 +280,8 @@ typedef struct {                 /* backward of the above from per-batch column 
     const float* colsum;         /* [B][L][2*D_pad]                                           */
     const float* gc;             /* [B][G]                                                    */
     float* grads;                /* flat fp32 gradient buffer (same offsets as params)        */
-    int32_t colsum_running;      /* 1: colsum[b] holds the sum over batch elements 0..b (aew_gemm_tn_t.snap_out);
-                                    the per-batch value is colsum[b] - colsum[b-1]              */
+    int32_t colsum_running;      /* layers l < colsum_running: colsum[b][l] holds the sum over batch elements 0..b
+                                    (aew_gemm_tn_t.snap_out); the per-batch value is colsum[b] - colsum[b-1]  */
     int32_t pad_;
 } aew_spk_bwd_t;
 

@@ -79,7 +79,7 @@ mfcc_inverter.mfcc.ProcessWav = _MfccStub
 # helpers
 # ------------------------------------------------------------------------------------
 sys.path.insert(0, HERE)
-from weights import np_weights    # noqa: E402
+from weights import grad_sketch, np_weights    # noqa: E402
 
 
 def load_np_weights(module, seed, skip=()):
@@ -348,6 +348,11 @@ def gen_mi():
         keep["gradslice." + k] = res["grad." + k][:8, :8]
     keep["param_names"] = np.array(json.dumps(
         {k: list(v.shape) for k, v in m.named_parameters()}))
+    # whole-tensor fingerprints of EVERY gradient (norm + seeded random projections, weights.grad_sketch)
+    pnames = [k for k, _ in m.named_parameters()]
+    for k, v in grad_sketch(pnames, {k: res["grad." + k] for k in pnames}).items():
+        keep["gsketch." + k] = v
+        keep["gnorm." + k] = np.float32(np.linalg.norm(res["grad." + k].astype(np.float64)))
     save("mi_full.npz", **keep)
     # BASELINE configs[0] as named: windows of real mu-law audio from dat/librispeech.some.dat (mel stays synthetic:
     # the MFCC needs librosa)
@@ -359,6 +364,9 @@ def gen_mi():
         if k.startswith("grad.") or k.startswith("gradslice."):
             full = res["grad." + k.split(".", 1)[1]]
             real[k] = full if k.startswith("grad.") else full[:8, :8]
+    for k, v in grad_sketch(pnames, {k: res["grad." + k] for k in pnames}).items():
+        real["gsketch." + k] = v
+        real["gnorm." + k] = np.float32(np.linalg.norm(res["grad." + k].astype(np.float64)))
     save("mi_full_real.npz", **real)
 
 

@@ -352,8 +352,10 @@ class Emu:
         gr, goff = self.flat(p.grads)
         Cc = p.C_lc + p.G
         cs = self.rd(p.colsum, torch.arange(p.B * p.L * 2 * p.D_pad)).view(p.B, p.L, 2 * p.D_pad)
-        if p.colsum_running:                                    # sums over batch elements 0..b -> per batch element
-            cs = torch.cat([cs[:1], cs[1:] - cs[:-1]], dim=0)
+        if p.colsum_running:                                    # lowest layers: sums over batch elements 0..b -> per element
+            r = min(p.colsum_running, p.L)
+            cs = cs.clone()
+            cs[1:, :r] = cs[1:, :r] - self.rd(p.colsum, torch.arange(p.B * p.L * 2 * p.D_pad)).view(p.B, p.L, 2 * p.D_pad)[:-1, :r]
         gc = self.rd(p.gc, torch.arange(p.B * p.G)).view(p.B, p.G)
         pi = self._pack_idx(p.D)
         dgc = torch.zeros(p.B, p.G)

@@ -169,12 +169,17 @@ def _real_worker(rank, world, port, bn, q):
         d.prepare_vae(eng)
         batch = _global_batch(eng.geom, 5, world)
         mine = [t[rank:rank + 1] for t in batch]
+        eps_all = None
+        if bn == "vae":                                           # the same noise in the N-rank and the 1-process run
+            eps_all = torch.randn(world, eng.eps.shape[1], eng.eps.shape[2], generator=torch.Generator().manual_seed(11))
+            eng.set_anneal_weight(0.3)
+            d.prepare_vae(eng)
         gs = d.grad_scale(M.MEAN_LOSS[eng.bn_type])
         out = {}
         n = eng.ps.numel
         for name in ("allreduce", "sharded", "sharded_bf16"):
             _seed_engine(eng)
-            eng.set_inputs(*mine)
+            eng.set_inputs(*mine, eps=None if eps_all is None else eps_all[rank:rank + 1])
             # two steps: the second sees the exchanged state.  bf16 transport is held to ONE step: its rounding moves a
             # few parameters by ~lr in step 1, after which code assignments can flip and the trajectories part for real
             for it in range(1 if name.endswith("bf16") else 2):
@@ -191,7 +196,9 @@ def _real_worker(rank, world, port, bn, q):
         if rank == 0:                                             # the same two steps in ONE process, global batch
             one = emulate(M.TrainEngine(hps, B=world, device="cpu", n_mel=5))
             _seed_engine(one)
-            one.set_inputs(*batch)
+            one.set_inputs(*batch, eps=eps_all)
+            if bn == "vae":
+                one.set_anneal_weight(0.3)
             ref = []
             for it in range(2):
                 one.forward(); one.backward(); one.adam_step(1e-2, 1.0)
@@ -202,11 +209,13 @@ def _real_worker(rank, world, port, bn, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bn,world", [("vqvae-ema", 2), ("ae", 2), ("vqvae-ema", 3)])
+@pytest.mark.parametrize("bn,world", [("vqvae-ema", 2), ("ae", 2), ("vqvae-ema", 3), ("vae", 2)])
 def test_dp_real_steps_match_single_process_global_batch(bn, world):
     """Sum-type loss (VQ-VAE-EMA: summed gradients, one codebook from summed EMA statistics) and mean-type loss (AE:
     the optimizer scales the summed gradient by 1 / world): N ranks with one window each == one process with all N.
-    world = 3: shards that do not divide the regions (the replicated remainder), a ring that is not a power of two."""
+    world = 3: shards that do not divide the regions (the replicated remainder), a ring that is not a power of two.
+    VAE (vae_bn.py:90-116): mean-type NLL + the KL SUM over all windows of the global batch behind a free-nats clamp - the
+    gate has to see the global KL (one scalar all-reduce) and the KL gradient must not be divided by world."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -25,7 +25,7 @@ from tests.plan_emulator import Emu
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-from weights import np_weights  # noqa: E402
+from weights import grad_sketch, np_weights  # noqa: E402
 
 DEV = "cuda:0"
 BF, F3 = L.BF16, L.F32
@@ -859,14 +859,24 @@ def test_mfcc_inverter_full_width_vs_reference_golden(golden_dir, fixture):
     assert cos > 0.99, cos
     for k in z:
         if k.startswith("grad."):
-            got, ref, lim = eng.ps.view(k[5:], grad=True).cpu().numpy(), z[k], 0.15
-        elif k.startswith("gradslice."):
-            # 8x8 corner of a large tensor, normalised by the corner's own maximum: looser bound
-            got, ref, lim = eng.ps.view(k[10:], grad=True).cpu().numpy()[:8, :8], z[k], 0.3
-        else:
+            got, ref = eng.ps.view(k[5:], grad=True).cpu().numpy(), z[k]
+            err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+            assert err < 0.15, (k, err)
+    # EVERY gradient as a whole tensor: relative L2 distance to the reference's gradient, estimated from the seeded
+    # random projections the fixture recorded (weights.grad_sketch; the estimator is good to +-25 %), and the norms.
+    # bf16 storage on a random-init net costs ~8 % relative L2 (ReLU-mask flips): bound 20 %.
+    sk = grad_sketch(list(shapes), {k: eng.ps.view(k, grad=True).cpu().numpy() for k in shapes})
+    worst = (0.0, "")
+    for k in shapes:
+        ref = z["gsketch." + k]
+        if float(z["gnorm." + k]) == 0.0:
             continue
-        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
-        assert err < lim, (k, err)
+        rel = float(np.linalg.norm(sk[k] - ref) / np.linalg.norm(ref))
+        worst = max(worst, (rel, k))
+        assert rel < 0.20, (k, rel)
+        gn = float(np.linalg.norm(eng.ps.view(k, grad=True).cpu().numpy().astype(np.float64)))
+        assert abs(gn / float(z["gnorm." + k]) - 1) < 0.08, (k, gn, float(z["gnorm." + k]))
+    print(f"{fixture}: worst whole-tensor relative L2 (sketch estimate) {worst}")
 
 
 def test_vae_and_deep_configs_full_size():

@@ -13,7 +13,7 @@ from ae_wavenet_amd import config, geometry
 from oracle import exact, ref_model as R
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-from weights import np_weights  # noqa: E402
+from weights import grad_sketch, np_weights  # noqa: E402
 
 RTOL, ATOL = 2e-5, 2e-6
 
@@ -316,6 +316,12 @@ def test_mfcc_inverter_full_width(golden_dir, fixture):
             close(sd[k[5:]].grad, z[k], 2e-3, 1e-7)
         elif k.startswith("gradslice."):
             close(sd[k[10:]].grad[:8, :8], z[k], 2e-3, 1e-7)
+    # every gradient, whole tensor: norm and seeded random projections recorded from the reference's gradients
+    sk = grad_sketch(list(shapes), {k: sd[k].grad.numpy() for k in shapes})
+    for k in shapes:
+        ref = z["gsketch." + k]
+        assert np.linalg.norm(sk[k] - ref) <= 2e-3 * max(np.linalg.norm(ref), 1e-12), k
+        close(torch.tensor(float(np.linalg.norm(sd[k].grad.numpy().astype(np.float64)))), z["gnorm." + k], 1e-3, 1e-12)
 
 
 def test_recloss(golden_dir):
