@@ -69,7 +69,15 @@ def restore(model, optim, ckpt: Dict[str, Any]) -> Dict[str, Any]:
 
 def save(path, model, optim, hps, epoch: int, step: int, optim_step: int,
          with_rng: bool = True) -> None:
-    """Write the dict of checkpoint.py:87-98.  Tensors go to CPU, contiguous."""
+    """Write the dict of checkpoint.py:87-98.  Tensors go to CPU, contiguous.
+
+    Data parallel with the sharded optimizer (dp.attach(model, sharded=True)): every rank holds the Adam moments of its
+    own shards only, so this call is COLLECTIVE - call it on ALL ranks; ranks that should not write pass path=None."""
+    dp = getattr(model, "_dp", None)
+    if dp is not None:
+        dp.sync_optimizer_state(model)
+    if path is None:
+        return
     sd = {k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()}
     ostate = optim.state_dict()
 

@@ -45,6 +45,42 @@ class DataParallel:
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.sharded, self.bf16_grads = False, False
         self._pending, self._st = [], None
+        self._bufs = {}                     # persistent transport buffers by (kind, region start, elements, dtype)
+        self.moments_step = -1              # engine step count for which every rank holds ALL Adam moments
+        self.timing = False                 # True: bracket every wait with events (exposed_ms())
+        self._tev = []
+
+    # ---- measurement: how long the compute stream actually stalls on collectives ---------------------------------
+    def _wait(self, work, what: str):
+        """work.wait() - with `timing` on, bracketed by events on the current stream: the elapsed time between them is
+        the part of the collective that was NOT hidden under compute (nothing else runs between the two records)."""
+        if not self.timing or not torch.cuda.is_available():
+            work.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        work.wait()
+        e1.record()
+        self._tev.append((what, e0, e1))
+
+    def exposed_ms(self, reset: bool = True):
+        """{wait point: total exposed ms since the last reset} (synchronises)."""
+        out = {}
+        if self._tev:
+            torch.cuda.synchronize()
+            for what, e0, e1 in self._tev:
+                out[what] = out.get(what, 0.0) + e0.elapsed_time(e1)
+        if reset:
+            self._tev = []
+        return out
+
+    def _buf(self, kind: str, start: int, numel: int, dtype, device) -> torch.Tensor:
+        key = (kind, start, numel, dtype)
+        t = self._bufs.get(key)
+        if t is None or t.device != device:
+            t = torch.empty(numel, dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
 
     def grad_scale(self, mean_loss: bool) -> float:
         """Factor the optimizer applies to the summed gradient: 1/world reproduces the
@@ -113,6 +149,7 @@ class DataParallel:
         n, lo = eng.ps.numel, eng.dec_grad_offset
         flat = eng.ps.grads
         work = {}
+        self.finish()                       # parameter all-gathers of a preceding sharded step
 
         def after_decoder():
             work["dec"] = dist.all_reduce(flat[lo:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -122,11 +159,12 @@ class DataParallel:
         eng.backward(after_decoder=after_decoder)
         if lo > 0:
             work["enc"] = dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        work["dec"].wait()
+        self._wait(work["dec"], "grads.decoder")
         eng.adam_step(lr, grad_scale, lo=lo, hi=n, **adam_kw)
         if lo > 0:
-            work["enc"].wait()
+            self._wait(work["enc"], "grads.encoder")
             eng.adam_step(lr, grad_scale, lo=0, hi=lo, count=False, **adam_kw)
+        self.moments_step = eng.step_count  # all-reduce schedule: every rank updates everything
 
     # ---- reduce-scatter + sharded Adam + all-gather ------------------------------------------------------------
     def _split(self, a: int, b: int):
@@ -144,17 +182,17 @@ class DataParallel:
         if s > 0:
             main = flat[a:a + self.world * s]
             mine = flat[a + self.rank * s: a + (self.rank + 1) * s]
+            # persistent transport buffers (one set per region: no allocation in the step); out of place is valid on
+            # every backend
             if bf16:
-                half = main.to(torch.bfloat16)
-                out = torch.empty(s, dtype=torch.bfloat16, device=flat.device)
+                half = self._buf("rs.in", a, self.world * s, torch.bfloat16, flat.device)
+                out = self._buf("rs.out", a, s, torch.bfloat16, flat.device)
+                half.copy_(main)                                 # fp32 -> bf16 (round to nearest even)
                 work.append(dist.reduce_scatter_tensor(out, half, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                fin.append(lambda: mine.copy_(out))
-                self._keep = (half, out)
             else:
-                out = torch.empty(s, dtype=flat.dtype, device=flat.device)     # out of place: valid on every backend
+                out = self._buf("rs.out", a, s, flat.dtype, flat.device)
                 work.append(dist.reduce_scatter_tensor(out, main, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                fin.append(lambda: mine.copy_(out))
-                self._keep = (out,)
+            fin.append(lambda: mine.copy_(out))
         if rem < b:
             work.append(dist.all_reduce(flat[rem:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return work, fin
@@ -169,7 +207,9 @@ class DataParallel:
             eng.adam_step(lr, grad_scale, lo=lo, hi=lo + s, count=count, **adam_kw)
             count = False
             main = eng.ps.params[a:a + self.world * s]
-            work.append(dist.all_gather_into_tensor(main, eng.ps.params[lo:lo + s].clone(), group=self.group, async_op=True))
+            src = self._buf("ag.in", a, s, main.dtype, main.device)     # (in place all-gather is not valid on every backend)
+            src.copy_(eng.ps.params[lo:lo + s])
+            work.append(dist.all_gather_into_tensor(main, src, group=self.group, async_op=True))
         if rem < b:
             eng.adam_step(lr, grad_scale, lo=rem, hi=b, count=count, **adam_kw)
         return work
@@ -177,7 +217,7 @@ class DataParallel:
     def finish(self):
         """Wait for the parameter all-gathers of the previous sharded step (called before the next forward)."""
         for w in getattr(self, "_pending", []):
-            w.wait()
+            self._wait(w, "params.all_gather")
         self._pending = []
 
     def backward_exchange(self, eng, bf16_grads: bool = False):
@@ -202,12 +242,12 @@ class DataParallel:
         n, lo = eng.ps.numel, eng.dec_grad_offset
         st, self._st = self._st, None
         for w in st["dec"][0]:
-            w.wait()
+            self._wait(w, "grads.decoder")
         for f in st["dec"][1]:
             f()
         pend = self._update_region(eng, lo, n, lr, grad_scale, True, adam_kw)      # decoder shards; all-gather in flight
         for w in st["head"][0]:
-            w.wait()
+            self._wait(w, "grads.encoder")
         for f in st["head"][1]:
             f()
         if lo > 0:
@@ -230,7 +270,8 @@ class DataParallel:
         self.optimizer_step(eng, lr, grad_scale, **adam_kw)
 
     def gather_moments(self, eng):
-        """All-gather the Adam moments (each rank holds valid moments for its own shards only under the sharded step)."""
+        """All-gather the Adam moments (each rank holds valid moments for its own shards only under the sharded step).
+        COLLECTIVE: every rank must call it."""
         if self.world == 1:
             return
         n, lo = eng.ps.numel, eng.dec_grad_offset
@@ -240,6 +281,21 @@ class DataParallel:
                 for buf in (eng.adam_m, eng.adam_v):
                     dist.all_gather_into_tensor(buf[a:a + self.world * s], buf[a + self.rank * s: a + (self.rank + 1) * s].clone(),
                                                 group=self.group)
+        self.moments_step = eng.step_count
+
+    def moments_complete(self, eng) -> bool:
+        """Does this rank hold the Adam moments of ALL parameters for the engine's current step?  (Always under the
+        all-reduce schedule; under the sharded one only right after gather_moments().)"""
+        return self.world == 1 or not self.sharded or eng.step_count == 0 or self.moments_step == eng.step_count
+
+    def sync_optimizer_state(self, model):
+        """Make model / optimizer state readable on every rank: waits for the parameter all-gathers in flight and
+        all-gathers the sharded Adam moments.  COLLECTIVE - call it on ALL ranks before any of them calls
+        optimizer.state_dict() / checkpoint.save() (checkpoint.save does it when the model is attached)."""
+        self.finish()
+        eng = getattr(model, "_engine", None)
+        if eng is not None and self.sharded and self.world > 1 and not self.moments_complete(eng):
+            self.gather_moments(eng)
 
     def allreduce_ema_async(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
         """Like allreduce_ema but returns the work handle (the engine then defers the EMA accumulation)."""
@@ -271,6 +327,7 @@ class DataParallel:
         dist.all_reduce(n_sum, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_params(self, eng, src: int = 0):
+        self.finish()
         dist.broadcast(eng.ps.params, src, group=self.group)
         if eng.bn_type == "vqvae-ema":
             for t in (eng.emb, eng.ema_numer, eng.ema_denom):

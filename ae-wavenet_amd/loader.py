@@ -35,6 +35,7 @@ class DevicePrefetcher:
         self.mfcc = mfcc
         self.copy_stream = torch.cuda.Stream(self.device)
         self._pinned = [dict() for _ in range(depth + 1)]      # slot -> {(item index): pinned tensor}
+        self._slot_ev = [None] * (depth + 1)                   # event after the slot's last H2D copies were issued
         self._slot = 0
         self._q = deque()
 
@@ -46,7 +47,8 @@ class DevicePrefetcher:
         # plain host memcpy.  (torch's copy_ into a PINNED tensor goes through the HIP runtime here and blocks until the
         # device is idle: 6 ms per call measured with a training step in flight, which serialised host and GPU and made
         # the step through this loader 15 ms instead of 8)
-        if t.is_contiguous() and t.dtype == buf.dtype and not t.requires_grad:
+        if t.device.type == "cpu" and t.is_contiguous() and t.dtype == buf.dtype and not t.requires_grad \
+                and t.dtype != torch.bfloat16:                    # (numpy has no bfloat16)
             np.copyto(buf.numpy(), t.numpy())
         else:
             buf.copy_(t)
@@ -59,6 +61,10 @@ class DevicePrefetcher:
             return False
         slot = self._slot
         self._slot = (self._slot + 1) % len(self._pinned)
+        if self._slot_ev[slot] is not None:
+            # the staging buffers of this slot are about to be overwritten by a plain host memcpy: the H2D copies that
+            # read them last time must have completed (they have, unless the copy stream lags depth + 1 batches behind)
+            self._slot_ev[slot].synchronize()
         out = []
         with torch.cuda.stream(self.copy_stream):
             for i, x in enumerate(items):
@@ -74,6 +80,7 @@ class DevicePrefetcher:
                 out[3] = self.jitter(mel.shape[0], mel.shape[2], self.device)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        self._slot_ev[slot] = ev
         self._q.append((tuple(out), ev))
         return True
 

@@ -521,7 +521,9 @@ class TrainEngine:
     def forward(self, ema_allreduce=None, timing=False):
         """timing=True forces eager launches (the per-op event timing needs them).
         ema_allreduce(z_sum, n_sum): cross-rank sum of the EMA statistics.  If it returns a work handle
-        (async collective) the EMA accumulation is deferred to finish_ema(), called by backward()."""
+        (async collective) the EMA accumulation is deferred to finish_ema(), called by backward() - or by the next
+        forward() if no backward came in between (forward-only use: the accumulation must not be lost)."""
+        self.finish_ema(timing)
         self._run(self.fwd_a, timing)
         if ema_allreduce is not None and self.bn_type == "vqvae-ema":
             work = ema_allreduce(self.z_sum, self.n_sum)

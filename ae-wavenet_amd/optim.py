@@ -90,6 +90,10 @@ class FusedAdam(torch.optim.Optimizer):
             return
         model = self.model
         model._opt_carry = (step, m.to(model._device), v.to(model._device))
+        model._opt_carry_partial = False
+        dp = getattr(model, "_dp", None)
+        if dp is not None:
+            dp.moments_step = step                               # every rank loads the complete state
         eng = model._engine
         if eng is not None:
             eng.adam_m[:total].copy_(model._opt_carry[1])

@@ -106,6 +106,7 @@ class HipModelBase(nn.Module):
         self._engine: Optional[TrainEngine] = None
         self._engines: Dict[int, TrainEngine] = {}      # engines by batch size (train B, sampling B = 1, ...)
         self._opt_carry = None                           # (step, exp_avg flat, exp_avg_sq flat) while no engine holds them
+        self._opt_carry_partial = False                  # carry saved from a sharded DP engine without a moment gather
         self._weights_epoch = 0                          # bumped whenever parameter values change behind torch's back
         self._device = torch.device("cpu")
         self._pending_state: Optional[Dict[str, torch.Tensor]] = None
@@ -194,7 +195,14 @@ class HipModelBase(nn.Module):
     _BUF_NAMES = {"bn_emb": "bottleneck.emb", "bn_ema_numer": "bottleneck.ema_numer",
                   "bn_ema_denom": "bottleneck.ema_denom", "bn_ind_hist": "bottleneck.ind_hist"}
 
+    def _dp_finish(self):
+        """Data parallel, sharded schedule: the parameter all-gathers of the last optimizer step may still be in
+        flight on the collective stream - everything that reads the parameters outside run() waits for them first."""
+        if self._dp is not None:
+            self._dp.finish()
+
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        self._dp_finish()
         self._sync_buffers_from_engine()
         sd = destination if destination is not None else {}
         for name, p in self.named_parameters():
@@ -230,6 +238,7 @@ class HipModelBase(nn.Module):
         # engine's flat buffer are copied out by this), then drop the engines; one is rebuilt
         # lazily on the next run() and the values (and the Adam moments) are copied back in.
         if self._engine is not None:
+            self._dp_finish()
             self._sync_buffers_from_engine()
             self._save_opt_carry()
         out = super()._apply(fn, recurse)
@@ -244,6 +253,7 @@ class HipModelBase(nn.Module):
 
     def _drop_engine(self):
         if self._engine is not None:
+            self._dp_finish()
             self._pull_params_to_cpu()
             self._save_opt_carry()
         self._engine = None
@@ -257,19 +267,28 @@ class HipModelBase(nn.Module):
         if eng is not None and (eng.step_count > 0 or self._opt_carry is None):
             n = eng.ps.numel
             self._opt_carry = (eng.step_count, eng.adam_m[:n].detach().clone(), eng.adam_v[:n].detach().clone())
+            # sharded data parallel: unless the moments were just gathered this rank's copy is valid for its own shards
+            # only - enough to continue training on a rebuilt engine (same shard layout), not to write a checkpoint
+            self._opt_carry_partial = self._dp is not None and not self._dp.moments_complete(eng)
 
     def _opt_state_flat(self):
         """(step, exp_avg flat, exp_avg_sq flat) from the live engine, else from the carry, else None."""
         eng = self._engine
         if eng is not None:
-            if self._dp is not None and self._dp.sharded:
-                self._dp.gather_moments(eng)              # collective: every rank reads its optimizer state together
+            if self._dp is not None and not self._dp.moments_complete(eng):
+                raise L.AewError("the Adam moments are sharded across the data-parallel ranks (each rank holds its own "
+                                 "1/world): call dp.sync_optimizer_state(model) - or checkpoint.save(...) - on ALL ranks "
+                                 "before reading optimizer state on any of them")
             n = eng.ps.numel
             return eng.step_count, eng.adam_m[:n], eng.adam_v[:n]
+        if self._opt_carry is not None and getattr(self, "_opt_carry_partial", False):
+            raise L.AewError("the carried Adam moments were saved from a sharded data-parallel engine without "
+                             "dp.sync_optimizer_state(model): they are complete for this rank's shards only")
         return self._opt_carry
 
     def _pull_params_to_cpu(self):
         eng = self._engine
+        self._dp_finish()
         self._sync_buffers_from_engine()
         with torch.no_grad():
             for name, pname in self._pnames:
@@ -300,6 +319,7 @@ class HipModelBase(nn.Module):
                              "move it to a cuda device first (no CPU execution path exists)")
         L.load()
         if eng is not None:
+            self._dp_finish()
             # another batch size (e.g. sample() uses B = 1 between training steps): parameters, EMA buffers and
             # Adam moments move to the other engine; engines are kept per batch size so that switching back does
             # not rebuild plans and graphs
@@ -359,6 +379,7 @@ class HipModelBase(nn.Module):
         if not self.training:
             return self.sample(wav, mel, voice, jitter)
         eng = self._ensure_engine(wav.shape[0])
+        self._dp_finish()
         eng.set_inputs(wav, mel, voice, jitter)
         eng.forward(self._ema_allreduce)
         return eng.logits().permute(0, 2, 1)
@@ -372,6 +393,7 @@ class HipModelBase(nn.Module):
         if wav.shape[0] != 1:
             raise L.AewError("sampling takes one window; replicas come from set_n_replicas()")
         R = max(1, int(self.n_replicas))
+        self._dp_finish()
         with torch.no_grad():
             eng = self._ensure_engine(1)
             eng.set_inputs(wav, mel, voice, jitter)

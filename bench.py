@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--nt-small-waves", dest="nt_small_waves", type=int, default=-1, help="waves per block of the deep 64-row NT shape (2|8)")
     ap.add_argument("--nf-loaders", dest="nf_loaders", type=int, default=-1, help="fp32 NT: dedicated loader waves (0|1)")
     ap.add_argument("--nf-deep", dest="nf_deep", type=int, default=-1, help="fp32 NT: launches of <= this many blocks use the deep ring (0 never)")
+    ap.add_argument("--nt-window", dest="nt_window", type=int, default=-1, help="largest dilation on the one-window NT kernel (0 off)")
+    ap.add_argument("--check-replicas", dest="check_replicas", action="store_true",
+                    help="N > 1: report the largest parameter difference between the ranks after the run")
     ap.add_argument("--per-op", default=None, help="write per-op HIP-event times (ms) to this file")
     ap.add_argument("--engine-only", action="store_true", help="headline = the engine-level step (no module surface / loader)")
     return ap.parse_args()
@@ -154,25 +157,45 @@ def cpu_baseline(hps, eng, seconds_budget=30.0):
                       f"{res[False]:.2f} s without; time per window is independent of the batch size on the CPU"}
 
 
-def pmc_traffic():
+def kernel_source_sha():
+    """sha256 over the kernel sources and the C header: ties a committed PMC table to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ae-wavenet_amd", "csrc")
+    for path in sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, "include", "aewavenet.h")]:
+        if path.endswith((".hip", ".h")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel_prefix, tag="r03"):
     """HBM bytes per launch (a number, as the bench contract asks) of the dominant kernel from the committed PMC passes
-    (profiles/r02_pmc_hbm_traffic.csv, else round 1's: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
-    command, FETCH doubled per MI355X_MICROARCH.md).  bench.py cannot collect PMCs itself."""
-    for name in ("r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
-        path = os.path.join(ROOT, "profiles", name)
-        try:
-            import csv
-            n = tot = 0.0
-            for r in csv.DictReader(open(path)):
-                if "k_gemm_nt_bf16<" in r["kernel"]:               # the tiled kernel only (not _p64 / k_fn)
-                    k = float(r["launches"])
-                    n += k
-                    tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
-            if n:
-                return round(tot / n), "profiles/" + name
-        except Exception:
-            continue
-    return None, None
+    (profiles/<tag>_pmc_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
+    FETCH doubled per MI355X_MICROARCH.md; written by tools/measure_round.sh together with <tag>_pmc_hbm_traffic.sha =
+    kernel_source_sha() of the sources it ran).  bench.py cannot collect PMCs itself, so the table is only used when
+    its sha matches the sources of THIS build; otherwise traffic is null.  Returns (bytes | None, source note)."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.csv")
+    sha_path = path[:-4] + ".sha"
+    try:
+        want = open(sha_path).read().strip()
+    except OSError:
+        return None, f"no profiles/{tag}_pmc_hbm_traffic.sha"
+    if want != kernel_source_sha():
+        return None, f"profiles/{tag}_pmc_hbm_traffic.csv is stale (kernel sources changed since it was measured)"
+    try:
+        import csv
+        n = tot = 0.0
+        for r in csv.DictReader(open(path)):
+            if kernel_prefix + "<" in r["kernel"]:
+                k = float(r["launches"])
+                n += k
+                tot += k * (float(r["fetch_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
+        if n:
+            return round(tot / n), f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2)"
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"
+    return None, f"kernel {kernel_prefix} not in profiles/{tag}_pmc_hbm_traffic.csv"
 
 
 def main():
@@ -217,6 +240,8 @@ def main():
         lib.aew_set_nt_rows192(args.nt_rows192)
     if args.nt_small >= 0:
         lib.aew_set_nt_small_tiles(args.nt_small)
+    if args.nt_window >= 0:
+        lib.aew_set_nt_window(args.nt_window)
     if args.nf_loaders >= 0:
         lib.aew_set_nf_loaders(args.nf_loaders)
     if args.nf_deep >= 0:
@@ -288,9 +313,14 @@ def main():
         loss.backward()
         opt.step()
 
+    from ae_wavenet_amd import model as _Mm
+    gscale = dp.grad_scale(_Mm.MEAN_LOSS[eng.bn_type]) if dp is not None else 1.0
+
     def engine_step():
-        if dp is not None:
-            dp.train_step(eng, args.lr, 1.0)
+        if dp is not None and sharded:                            # the same exchange schedule as the surface step
+            dp.train_step_sharded(eng, args.lr, gscale, bf16_grads=bf16_grads)
+        elif dp is not None:
+            dp.train_step(eng, args.lr, gscale)
         else:
             eng.forward()
             eng.backward()
@@ -316,6 +346,34 @@ def main():
     loss_val = float(eng.loss_buf[0])
     dt_other = timed(other_fn)
     dt_host = timed(host_step)
+    dp_info = None
+    if dp is not None:
+        # how much of the exchange the compute stream actually waits for: events around every collective wait, over a
+        # few extra steps outside the timed region (every rank; rank 0's numbers are printed)
+        dp.finish()
+        fence()
+        dp.timing = True
+        n_x = 5
+        for _ in range(n_x):
+            step()
+        dp.finish()
+        ex = dp.exposed_ms()
+        dp.timing = False
+        dp_info = {"exposed_collective_ms_per_step": round(sum(ex.values()) / n_x, 4),
+                   "by_wait_ms_per_step": {k: round(v / n_x, 4) for k, v in sorted(ex.items())},
+                   "backend": backend, "ranks_share_one_gpu": share}
+        if args.check_replicas:
+            fence()
+            n = eng.ps.numel
+            hi, lo_ = eng.ps.params[:n].clone(), eng.ps.params[:n].clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dp_info["replica_param_max_diff"] = float((hi - lo_).abs().max())
+            if eng.bn_type == "vqvae-ema":
+                hi, lo_ = eng.emb.clone(), eng.emb.clone()
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+                dp_info["replica_codebook_max_diff"] = float((hi - lo_).abs().max())
 
     # ---- per-kernel timing for the roofline (outside the timed region) ----------------------
     roof = None
@@ -360,7 +418,7 @@ def main():
         # algorithmic NT FLOPs are apportioned by the FLOPs the descriptors execute (padding is near-uniform).
         plans = [eng.fwd_a, eng.fwd_b, eng.bwd] + ([eng.cb] if hasattr(eng, "cb") else []) + [eng.opt]
         ops_all = [op for pl in plans for op in pl.ops]
-        KNAME = {0: "k_gemm_nt_bf16", 1: "k_gemm_nt_bf16_p64", 2: "k_fn"}
+        KNAME = {0: "k_gemm_nt_bf16", 1: "k_gemm_nt_bf16_p64", 2: "k_fn", 6: "k_gemm_nt_bf16_win"}
         byk = {k: {"ms": 0.0, "launches": 0, "exec_flops": 0.0} for k in KNAME}
         for i in range(min(cnt.value, cap)):
             op = ops_all[i % len(ops_all)]
@@ -380,11 +438,12 @@ def main():
             v["launches"] //= n_t
             v["alg_flops"] = nt_flops * v["exec_flops"] / ex_all
             v["tflops"] = v["alg_flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
-        dom = byk[0]
+        dom_k = max((0, 6), key=lambda k: byk[k]["ms"])           # the tiled NT kernel or its one-window form
+        dom = byk[dom_k]
         n_launch = max(dom["launches"], 1)
         achieved = dom["tflops"]
-        traffic, src = pmc_traffic()
-        roof = {"bound": "mfma", "kernel": "k_gemm_nt_bf16", "achieved": round(achieved, 2), "peak": 2500.0,
+        traffic, src = pmc_traffic(KNAME[dom_k])
+        roof = {"bound": "mfma", "kernel": KNAME[dom_k], "achieved": round(achieved, 2), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": traffic,
                 "launches_per_step": n_launch, "avg_launch_ms": round(dom["ms"] / n_launch, 5),
                 "alg_flops_per_launch": dom["alg_flops"] / n_launch,
@@ -399,7 +458,7 @@ def main():
         # the same launches against the HBM roofline: measured bytes per launch (PMC) / measured time per launch.  At
         # K = 256..1024 with 3-4 activation tensors in and out the stack's intensity (~240 FLOP/B) is below the ridge
         # (2500 / 8 = 312), see profiles/r01_op_roofline.txt
-        roof["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2)" if src else None
+        roof["traffic_source"] = src
         if roof["traffic"]:
             tbps = roof["traffic"] / (nt_ms / n_launch * 1e-3) / 1e12
             roof["hbm_view"] = {"achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
@@ -438,7 +497,7 @@ def main():
             "host_fed": {"ms_per_step": 1e3 * dt_host / args.steps, "value": samples / dt_host, "unit": "samples/s",
                          "path": "pinned host batch -> DevicePrefetcher (H2D on a copy stream, jitter generated on the device) -> the "
                                  "same step: PCIe-inclusive, reported beside `value`, never as it"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "data_parallel": dp_info,
             "kernel_ms_by_tag": {str(k): round(v, 4) for k, v in sorted(kern.items())},
         }
         print(json.dumps(out))

@@ -50,6 +50,8 @@ with open(O + "/pmc_mfma_util.csv", "w", newline="") as fh:
         cw.writerow([k, n, f"{mf:.0f}", f"{ga:.0f}", f"{mf / (1024.0 * ga):.4f}" if ga > 0 else "", f"{lc:.4f}"])
 print(open(O + "/bench.json").read()[:600])
 PY
+# ties the PMC table to the kernel sources it was measured on (bench.py only uses a table whose sha matches its build)
+python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $O/pmc_hbm_traffic.sha
 # per-op MFMA / HBM view of the step and the sampler's throughput table
 cd $R
 python tools/op_roofline.py $O/per_op_ms.txt > $O/op_roofline.txt 2>&1
