@@ -50,11 +50,12 @@ class GemmTN(C.Structure):
     _fields_ = [("dtype", i32), ("impl", i32), ("Mc", i32), ("batch", i32), ("N", i32),
                 ("N_pad", i32), ("g", Seg), ("n_segs", i32), ("K_total", i32),
                 ("seg", Seg * MAX_SEGS), ("out", vp), ("out_batch_stride", i64),
-                ("snap_out", vp), ("snap_bs", i64), ("snap_k", i32), ("pad_", i32)]
+                ("snap_out", vp), ("snap_bs", i64), ("snap_k", i32), ("pad_", i32), ("colsum_out", vp),
+                ("grp_splits", i32), ("grp_rows", i32)]
 
 
 class GemmTNGroup(C.Structure):
-    _fields_ = [("descs", vp), ("tile_map", vp), ("n_descs", i32), ("n_blocks", i32)]
+    _fields_ = [("descs", vp), ("tile_map", vp), ("n_descs", i32), ("n_blocks", i32), ("tile", i32), ("pad_", i32)]
 
 
 class CopyRec(C.Structure):

@@ -516,8 +516,9 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
     }
 }
 
-// ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved);
-// the production instantiations (ABL = false) contain none of that code.
+// ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved).  It is instantiated
+// in the tools library only (hipcc -DAEW_FN_ABLATE=1 -o lib/libaewavenet_hip_abl.so); the product library has the
+// ABL = false instantiations, which contain none of that code and ignore g.reserved.
 template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM>
 __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
     typedef NtCfg<MT, NB, BMV> Cfg;
@@ -1594,6 +1595,13 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
     const int srel = SNAP ? g.snap_k - tt.koff : -1;
     const bool snap_here = SNAP && g.snap_out && srel >= 0 && srel < TN_BT;
     int c_in_b = 0, bdone = b_lo;
+    // column sums of G (grouped form, first k tile, the two waves of k half 0): one more MFMA per n tile and stage with
+    // an all-ones A operand - every row of the result is sum_m G[m][n]
+    const bool do_cs = SNAP && g.colsum_out != nullptr && kt == 0 && wk == 0;
+    f32x4_t cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (s16x8_t){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
     for (int t = 0; t < total; ++t) {
         if (t + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 loads per stage per wave
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1613,6 +1621,10 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+        if (do_cs) {                                   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[j], cs[j], 0, 0, 0);
+        }
         if (SNAP && ++c_in_b == nst) {                 // wave-uniform, once per batch element
             c_in_b = 0;
             if (snap_here && wk == (srel >> 6) && (lane >> 4) == ((srel >> 2) & 3)) {
@@ -1641,6 +1653,7 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
             *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
+        if (do_cs && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
     }
 }
 
@@ -1672,8 +1685,15 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp(const aew_ge
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int rec = __builtin_amdgcn_readfirstlane(tile_map[blockIdx.x]);
     if (rec < 0) return;
-    const aew_gemm_tn_t& g = descs[rec >> 16];
-    const int tile = rec & 0xffff, nkt = g.K_total / TN_BT;
+    const aew_gemm_tn_t& g = descs[rec >> 22];
+    const int tile = rec & 0xfff, chunk = (rec >> 12) & 0x3ff, nkt = g.K_total / TN_BT;
+    if (g.grp_splits > 0) {                            // split like a stand-alone op: (batch element, row chunk) -> slab
+        const int bz = chunk / g.grp_splits, sp = chunk - bz * g.grp_splits;
+        const int r_lo = sp * g.grp_rows;
+        tn_bf16_tile<0, false>(g, smem, tile % nkt, tile / nkt, bz, bz + 1, r_lo, min(g.Mc, r_lo + g.grp_rows),
+                               g.out + (int64_t)chunk * g.out_batch_stride);
+        return;
+    }
     tn_bf16_tile<0, true>(g, smem, tile % nkt, tile / nkt, 0, g.batch, 0, g.Mc, g.out);
 }
 
@@ -1739,24 +1759,14 @@ __device__ __forceinline__ void tnb_issue(uint32_t lds_region, int r_end, int wa
     }
 }
 
-__global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big(const aew_gemm_tn_t g, int splits, int rows_per_split,
-                                                                     int fold_batch) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// tnb_tile: one 256 x 256 output tile (kt, nt) contracted over rows [r_lo, r_hi) of the batch elements [b_lo, b_hi), in
+// that order, result to `out` ([N_pad][K_total] fp32).  SNAP as in tn_bf16_tile.
+template <bool SNAP>
+__device__ __forceinline__ void tnb_tile(const aew_gemm_tn_t& g, char* smem, int kt, int nt, int b_lo, int b_hi,
+                                         int r_lo, int r_hi, float* out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 1, wn = wave >> 1;                  // k half, 64-column n slab (n half = wn >> 1)
     const int nk128 = g.K_total / 128, nn128 = g.N_pad / 128;
-    const int nkt = (nk128 + 1) / 2, nnt = (nn128 + 1) / 2;
-    const int n_tiles = nkt * nnt;
-    const int n_chunks = splits * (fold_batch ? 1 : g.batch);
-    // XCD-aware order (see k_gemm_tn_bf16): the tiles that contract over one (batch, row chunk) sit on one XCD
-    const int L = blockIdx.x, seq = L >> 3;
-    const int chunk = (seq / n_tiles) * 8 + (L & 7);
-    if (chunk >= n_chunks) return;
-    const int tile = seq % n_tiles;
-    const int kt = tile % nkt, nt = tile / nkt;
-    const int sp = chunk % splits, bz = chunk / splits;
-    const int b_lo = fold_batch ? 0 : bz, b_hi = fold_batch ? g.batch : bz + 1;
-    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
     const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
     const int total = nst * (b_hi - b_lo);
     // ---- what this wave stages: region = wave >> 1: 0,1 = G halves, 2,3 = A halves
@@ -1798,6 +1808,16 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big(const aew_g
     for (int q = 0; q < TNB_STAGES - 1; ++q)
         if (q < total) issue_next();
     int stage = 0;
+    // SNAP: column snap_k lies in this wave's 128-column k half at offset srel (or not at all)
+    const int srel = (SNAP && comp_valid) ? g.snap_k - ctt.koff : -1;
+    const bool snap_here = SNAP && g.snap_out && srel >= 0 && srel < 128;
+    int c_in_b = 0, bdone = b_lo;
+    // column sums of G (see tn_bf16_tile): the waves of k half 0 of the first k tile
+    const bool do_cs = SNAP && g.colsum_out != nullptr && kt == 0 && wk == 0 && comp_valid;
+    f32x4_t cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (s16x8_t){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
     for (int t = 0; t < total; ++t) {
         // stage t has landed once at most the stages issued after it are outstanding (4 pieces per wave and stage)
         const int ahead = min(total - 1 - t, TNB_STAGES - 2);
@@ -1822,11 +1842,30 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big(const aew_g
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+            if (do_cs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[j], cs[j], 0, 0, 0);
+            }
+        }
+        if (SNAP && ++c_in_b == nst) {                         // wave-uniform, once per batch element
+            c_in_b = 0;
+            if (snap_here && (lane >> 4) == ((srel >> 2) & 3)) {
+                const int si = srel >> 4, sr = srel & 3;
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n128 * 128 + (wn & 1) * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v = (i == si && r == sr) ? acc[i][j][r] : v;
+                    so[j * 16] = v;
+                }
+            }
+            ++bdone;
         }
     }
     if (!comp_valid) return;
-    const int slab = fold_batch ? sp : (bz * splits + sp);
-    float* out = g.out + (int64_t)slab * g.out_batch_stride;
     const int q = lane & 15, gq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1837,7 +1876,37 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big(const aew_g
             *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
+        if (do_cs && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
     }
+}
+
+__global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big(const aew_gemm_tn_t g, int splits, int rows_per_split,
+                                                                     int fold_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkt = (g.K_total / 128 + 1) / 2, nnt = (g.N_pad / 128 + 1) / 2;
+    const int n_tiles = nkt * nnt;
+    const int n_chunks = splits * (fold_batch ? 1 : g.batch);
+    // XCD-aware order (see k_gemm_tn_bf16): the tiles that contract over one (batch, row chunk) sit on one XCD
+    const int L = blockIdx.x, seq = L >> 3;
+    const int chunk = (seq / n_tiles) * 8 + (L & 7);
+    if (chunk >= n_chunks) return;
+    const int tile = seq % n_tiles;
+    const int sp = chunk % splits, bz = chunk / splits;
+    const int r_lo = sp * rows_per_split, r_hi = min(g.Mc, r_lo + rows_per_split);
+    const int slab = fold_batch ? sp : (bz * splits + sp);
+    tnb_tile<false>(g, smem, tile % nkt, tile / nkt, fold_batch ? 0 : bz, fold_batch ? g.batch : bz + 1, r_lo, r_hi,
+                    g.out + (int64_t)slab * g.out_batch_stride);
+}
+
+// Grouped form on the big tiles (aew_gemm_tn_group_t.tile = 256): tile = nt * ((K_total / 128 + 1) / 2) + kt.
+__global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big_grp(const aew_gemm_tn_t* __restrict__ descs,
+                                                                         const int32_t* __restrict__ tile_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rec = __builtin_amdgcn_readfirstlane(tile_map[blockIdx.x]);
+    if (rec < 0) return;
+    const aew_gemm_tn_t& g = descs[rec >> 22];
+    const int tile = rec & 0xfff, nkt = (g.K_total / 128 + 1) / 2;
+    tnb_tile<true>(g, smem, tile % nkt, tile / nkt, 0, g.batch, 0, g.Mc, g.out);
 }
 
 // =============================================================================================
@@ -1993,9 +2062,11 @@ static int ensure_big_lds() {
     AEW_SET_NT(AEW_EPI_GATED)
     AEW_SET_NT(AEW_EPI_RES_SKIP)
     AEW_SET_NT(AEW_EPI_DFG)
+#if AEW_FN_ABLATE       /* tools library only: the ablation variants (ABL = true) do not exist in the product build */
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8>), NT_LDS_BYTES)
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8, 2>), (NtCfg<8, 2>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
+#endif
 #undef AEW_SET_NT
     AEW_SET_LDS((k_gemm_nt_f32<1, 7, 0>), (NfCfg<1, 7>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_f32<1, 14, 0>), (NfCfg<1, 14>::LDS_BYTES))
@@ -2007,6 +2078,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_grp, TN_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16_big_grp, TNB_LDS_BYTES)
 #undef AEW_SET_LDS
     done = 1;
     return 0;
@@ -2151,8 +2223,10 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         switch (g.epi) {
             case AEW_EPI_STORE: AEW_NT_GO(AEW_EPI_STORE, false); break;
             case AEW_EPI_GATED:
-                if (g.reserved) AEW_NT_GO(AEW_EPI_GATED, true);
-                else AEW_NT_GO(AEW_EPI_GATED, false);
+#if AEW_FN_ABLATE
+                if (g.reserved) { AEW_NT_GO(AEW_EPI_GATED, true); break; }
+#endif
+                AEW_NT_GO(AEW_EPI_GATED, false);
                 break;
             case AEW_EPI_RES_SKIP: AEW_NT_GO(AEW_EPI_RES_SKIP, false); break;
             case AEW_EPI_DFG: AEW_NT_GO(AEW_EPI_DFG, false); break;
@@ -2259,8 +2333,12 @@ extern "C" int aew_tn_group_check(const aew_gemm_tn_t* g) {
     aew_seg_t gg = g->g; gg.k_len = TN_BT;
     const int rc = check_seg(gg, 2, TN_BT);
     if (rc) return rc;
-    if (ksum != g->K_total || g->N_pad % TN_BT || (g->N_pad / TN_BT) * (g->K_total / TN_BT) > 0xffff) return AEW_E_ARG;
+    if (ksum != g->K_total || g->N_pad % TN_BT || (g->N_pad / TN_BT) * (g->K_total / TN_BT) > 0xfff) return AEW_E_ARG;
     if (g->snap_out && (g->snap_k < 0 || g->snap_k >= g->K_total)) return AEW_E_ARG;
+    if (g->grp_splits < 0 || g->grp_splits * g->batch > 0x3ff) return AEW_E_ARG;
+    if (g->grp_splits > 0 && (g->grp_rows <= 0 || g->grp_rows % TN_RC || (int64_t)g->grp_splits * g->grp_rows < g->Mc ||
+                              g->snap_out || g->colsum_out))
+        return AEW_E_ARG;
     return 0;
 }
 
@@ -2268,7 +2346,12 @@ static int launch_gemm_tn_group(const aew_gemm_tn_group_t& p, hipStream_t st) {
     if (!p.descs || !p.tile_map || p.n_descs <= 0 || p.n_blocks <= 0) return AEW_E_ARG;
     const int rc = ensure_big_lds();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gemm_tn_bf16_grp, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
+    if (p.tile == 256)
+        hipLaunchKernelGGL(k_gemm_tn_bf16_big_grp, dim3(p.n_blocks), dim3(TNB_THREADS), TNB_LDS_BYTES, st, p.descs, p.tile_map);
+    else if (p.tile == 128)
+        hipLaunchKernelGGL(k_gemm_tn_bf16_grp, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
+    else
+        return AEW_E_ARG;
     return (int)hipGetLastError();
 }
 

@@ -210,6 +210,10 @@ class DecoderPlan:
                               # kernels lose the LDS those blocks hold: 8.63 / 9.68 ms per step with groups of 8 / 4
                               # against 7.68 with one launch and 7.75 with one split-K op per matrix).  0: one TN op per
                               # matrix (round 2's form)
+    wgrad_tile = 128          # output tile of the grouped wgrad launch: 128 (three 4-wave blocks per CU) | 256 (one 8-wave
+                              # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
+                              # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
+                              # independent blocks per CU reach 43 GB/s together
     wgrad_split_layers = 0    # with grouped wgrads: the TOP this-many layers keep one split-K TN op per matrix (they run
                               # under the dgrad chain and fill its tile-wave tails), the rest go to the grouped launch
     split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
@@ -636,38 +640,42 @@ class DecoderPlan:
         def group_add(name, t, tag):
             nonlocal grp
             if grp is None:
-                grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}")
+                grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
             t.out, t.out_batch_stride = ptr, stride
             grp.add(t, "wgrad." + name)
             self.gbuf[name] = (ptr, stride, 1)
             return ptr, stride, 1
 
-        def wgrad_late(name, dtype, Mc, N, N_pad, gseg, segs, tag):
+        def wgrad_late(name, dtype, Mc, N, N_pad, gseg, segs, tag, bias_grad=0):
             """A weight gradient whose operands exist early but whose result is only needed at the end: grouped mode
-            defers it into the last group (one result, unpacked by the late table)."""
+            defers it into the last group (one result, unpacked by the late table).  bias_grad: address of the layer's
+            bias gradient = column sums of the G operand, a by-product of the grouped launch (0: none)."""
             if not grouped:
                 return self._wgrad(plan, name, dtype, Mc, N, N_pad, gseg, segs, tag) + (pk.unpack_tbl,)
             t = make_tn(dtype, Mc, B, N, N_pad, gseg, segs)
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
             t.out, t.out_batch_stride = ptr, stride
+            t.colsum_out = bias_grad or None
             tail_descs.append((name, t))
             self.gbuf[name] = (ptr, stride, 1)
             return ptr, stride, 1, late_tbl
 
         # ---- post network
-        if ps.has(p + "post2.bias"):
+        if ps.has(p + "post2.bias") and not grouped:
             self._colsum(plan, self.dlogits, w, Q, ps.ptr(p + "post2.bias", True), label="db.post2")
-        gp, gs, gn, tbl = wgrad_late("p2", BF, w, Q, Qp, self.dlogits.seg(Qp), [self.h1.seg(Pp)], TAG_POST)
+        gp, gs, gn, tbl = wgrad_late("p2", BF, w, Q, Qp, self.dlogits.seg(Qp), [self.h1.seg(Pp)], TAG_POST,
+                                     bias_grad=ps.ptr(p + "post2.bias", True) if ps.has(p + "post2.bias") else 0)
         keep_tbl, pk.unpack_tbl = pk.unpack_tbl, tbl
         pk.rec(p + "post2.weight", 0, [P, 1], [Q, P], None, 0, [Pp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
         pk.unpack_tbl = keep_tbl
         plan.add(L.OP_GEMM_NT, make_nt(BF, w, Pp, Pp, B, [self.dlogits.seg(Qp)], self.Wp2T.ptr,
                                        flags=L.EF_MUL_POS1, out0=self.dh1.view(), aux1=self.h1.view(),
                                        impl=impl), "d.post2", TAG_POST)
-        if ps.has(p + "post1.bias"):
+        if ps.has(p + "post1.bias") and not grouped:
             self._colsum(plan, self.dh1, w, P, ps.ptr(p + "post1.bias", True), label="db.post1")
-        gp, gs, gn, tbl = wgrad_late("p1", BF, w, P, Pp, self.dh1.seg(Pp), [self.h0.seg(Sp)], TAG_POST)
+        gp, gs, gn, tbl = wgrad_late("p1", BF, w, P, Pp, self.dh1.seg(Pp), [self.h0.seg(Sp)], TAG_POST,
+                                     bias_grad=ps.ptr(p + "post1.bias", True) if ps.has(p + "post1.bias") else 0)
         keep_tbl, pk.unpack_tbl = pk.unpack_tbl, tbl
         pk.rec(p + "post1.weight", 0, [S, 1], [P, S], None, 0, [Sp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
         pk.unpack_tbl = keep_tbl
@@ -761,12 +769,23 @@ class DecoderPlan:
         # ---- skip weights of all layers: ONE wgrad with NL segments (mirror of the deferred skip GEMM):
         # dW_skp[s][l*Dp + k] = sum_t dskp[t][s] * z_l[t + skip_lead_l][k].  640 tiles x batch fill the
         # chip without row splits, so it writes B slabs instead of ~128 per layer.
+        # ---- base layer (wavenet.py:351)
+        # (as a TN GEMM over a materialised one-hot matrix: 0.044 ms + 29 MB written by base_gather.  The scatter-add form
+        # - rows of dx0 added into LDS images per 64 channels, AEW-internal experiment of round 2 - took 0.58 ms: the
+        # rows have to be fetched one dependent (wav[t] -> dx0[t]) load pair at a time and the partial images merged
+        # with ~10 M global atomics; the GEMM streams the same bytes at full rate)
+        has_bb = ps.has(p + "base_layer.bias")
+        if has_bb and not grouped:
+            self._colsum(plan, dx0, T, R, ps.ptr(p + "base_layer.bias", True), label="db.base")
+        gp_b, gs_b, gn_b, _tbl = wgrad_late("base", BF, T, R, Rp, dx0.seg(Rp), [self.onehot.seg(Qp)], TAG_MISC,
+                                            bias_grad=ps.ptr(p + "base_layer.bias", True) if has_bb else 0)
+        pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], None, 0, [Qp, 1], g_ptr=gp_b, slabs=gn_b, slab_stride=gs_b)
         gp, gs, gn, _tbl = wgrad_late("skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
                                       [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
         if grouped:
             for name, t in tail_descs:
                 if grp is None:
-                    grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}")
+                    grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
                 grp.add(t, "wgrad." + name)
             with plan.side(self._next_lane("tng")):
                 grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)", TAG_WG_FG)
@@ -778,15 +797,6 @@ class DecoderPlan:
         for l in range(NL):
             pk.rec(p + f"conv_layers.{l}.dil_skp.weight", 0, [D, 1], [S, D], None, 0, [NL * Dp, 1],
                    g_ptr=gp, slabs=gn, slab_stride=gs, g_off=l * Dp)
-        # ---- base layer (wavenet.py:351)
-        if ps.has(p + "base_layer.bias"):
-            self._colsum(plan, dx0, T, R, ps.ptr(p + "base_layer.bias", True), label="db.base")
-        # (as a TN GEMM over a materialised one-hot matrix: 0.044 ms + 29 MB written by base_gather.  The scatter-add form
-        # - rows of dx0 added into LDS images per 64 channels, AEW-internal experiment of round 2 - took 0.58 ms: the
-        # rows have to be fetched one dependent (wav[t] -> dx0[t]) load pair at a time and the partial images merged
-        # with ~10 M global atomics; the GEMM streams the same bytes at full rate)
-        gp, gs, gn = self._wgrad(plan, "base", BF, T, R, Rp, dx0.seg(Rp), [self.onehot.seg(Qp)], TAG_MISC)
-        pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], None, 0, [Qp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
         # ---- conditioning gradient over all layers' dfg (wavenet.py:100-101 cond terms).  With split_multiseg the
         # layers [n_lo, NL) were summed on a side lane mid-chain (dcond_part); this GEMM adds them.
         lo = self.n_lo
@@ -809,6 +819,26 @@ class DecoderPlan:
             plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)
         # ---- upsamplers, last stage first (wavenet.py:154)
         n_ups = len(hps.lc_upsample_strides)
+        ugrp = TnGroupBuilder(self.ws, p + "tng_ups", 128) if grouped else None     # upsampler + LC-conv wgrads: one launch
+
+        def wgrad_ups(name, Mc, N, N_pad, gseg, segs, bias_grad=0):
+            """One or a few output tiles with up to 8 x 1780 rows to contract: cut into chunks of ~512 rows (one block
+            and one slab each) unless the whole contraction is that short (then the column-sum by-product is available)."""
+            if ugrp is None:
+                return self._wgrad(plan, name, BF, Mc, N, N_pad, gseg, segs, TAG_UPS)
+            t = make_tn(BF, Mc, B, N, N_pad, gseg, segs)
+            split = Mc * B > 1024
+            if not split:
+                t.colsum_out = bias_grad or None
+            elif bias_grad:
+                raise NotImplementedError("bias gradient of a split grouped descriptor")
+            slabs = ugrp.set_split(t, 512) if split else 1
+            ptr, stride = self._gslab(name, t.N_pad, t.K_total, slabs)
+            t.out, t.out_batch_stride = ptr, stride
+            ugrp.add(t, "wgrad." + name)
+            self.gbuf[name] = (ptr, stride, slabs)
+            return ptr, stride, slabs
+
         for i in range(n_ups - 1, -1, -1):
             f, s = hps.lc_upsample_filt_sizes[i], hps.lc_upsample_strides[i]
             pad = f - s
@@ -819,18 +849,22 @@ class DecoderPlan:
             self._colsum(plan, dY, dY.rows, Clc, ps.ptr(p + f"lc_upsample.{i}.tconv.bias", True),
                          label=f"db.up{i}")
             segs = [dY.seg(Cp, row_step=s, row_off=k - pad - trim0) for k in range(f)]
-            gp, gs, gn = self._wgrad(plan, f"up{i}", BF, X.rows, Clc, Cp, X.seg(Cp), segs, TAG_UPS)
+            gp, gs, gn = wgrad_ups(f"up{i}", X.rows, Clc, Cp, X.seg(Cp), segs)
             pk.rec(p + f"lc_upsample.{i}.tconv.weight", 0, [Clc * f, f, 1], [Clc, Clc, f], None, 0,
                    [f * Cp, 1, Cp], g_ptr=gp, slabs=gn, slab_stride=gs)
             plan.add(L.OP_GEMM_NT, make_nt(BF, X.rows, Cp, Cp, B, segs, self.WupT[i].ptr, out0=dX.view(),
                                            impl=impl), f"d.ups{i}", TAG_UPS)
         # ---- LC conv (wavenet.py:337)
         dlc1, lc1 = self.dups[0], self.ups_in[0]
-        if ps.has(p + "lc_conv.bias"):
+        has_lb = ps.has(p + "lc_conv.bias")
+        if has_lb and ugrp is None:
             self._colsum(plan, dlc1, lc1.rows, Clc, ps.ptr(p + "lc_conv.bias", True), label="db.lc")
         nin = self.n_lc_in
-        gp, gs, gn = self._wgrad(plan, "lc", BF, lc1.rows, Clc, Cp, dlc1.seg(Cp),
-                                 [self.lcj.seg(Lp, row_off=t) for t in range(3)], TAG_UPS)
+        gp, gs, gn = wgrad_ups("lc", lc1.rows, Clc, Cp, dlc1.seg(Cp), [self.lcj.seg(Lp, row_off=t) for t in range(3)],
+                               bias_grad=ps.ptr(p + "lc_conv.bias", True) if has_lb else 0)
+        if ugrp is not None:
+            with plan.side(self._next_lane("tng")):
+                ugrp.emit(plan, "wgrad.group (upsamplers, lc conv)", TAG_UPS)
         pk.rec(p + "lc_conv.weight", 0, [nin * 3, 3, 1], [Clc, nin, 3], None, 0, [3 * Lp, 1, Lp],
                g_ptr=gp, slabs=gn, slab_stride=gs)
         plan.add(L.OP_GEMM_NT, make_nt(BF, self.Ne, ru(nin, 8), Lp, B,
@@ -928,25 +962,34 @@ class EncoderPlan:
     def build_backward(self, plan: Plan, need_input_grad: bool = True):
         """Expects dy[9] and dpre[9] already written (by the bottleneck backward)."""
         B, impl, E, Eb, ps, pk = self.B, self.impl, self.E, self.Eb, self.ps, self.pk
+        # grouped mode (DecoderPlan.wgrad_group): the nine weight gradients as ONE launch after the dgrad chain (each
+        # contracts over 8 x 29..70 rows: nine launches of a few microseconds of work each otherwise), the bias
+        # gradients as its column-sum by-product
+        grp = TnGroupBuilder(self.ws, "enc.tng", 128) if (DecoderPlan.wgrad_group > 0 and impl == 0) else None
         for i in range(8, -1, -1):
             f, s, res = G.ENCODER_FILTERS[i], G.ENCODER_STRIDES[i], G.ENCODER_RESIDUAL[i]
             X = self.yb[i]
             cin, cinb = (self.n_mel, self.Mb) if i == 0 else (E, Eb)
             dpre, dyo = self.dpre[i + 1], self.dy[i + 1]
             Lo = dpre.rows
-            cs = L.Colsum()
-            cs.x = dpre.seg(128)
-            cs.dtype, cs.M, cs.N, cs.batch = BF, Lo, E, B
-            cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 1
-            with plan.side(1 + (2 * i) % DecoderPlan.n_side_lanes):
-                plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
             t = make_tn(BF, Lo, B, E, Eb, dpre.seg(Eb), [X.seg(cinb, row_step=s, row_off=k) for k in range(f)],
                         impl=impl)
-            slabs = L.tn_slabs(t)
+            if grp is None:
+                cs = L.Colsum()
+                cs.x = dpre.seg(128)
+                cs.dtype, cs.M, cs.N, cs.batch = BF, Lo, E, B
+                cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 1
+                with plan.side(1 + (2 * i) % DecoderPlan.n_side_lanes):
+                    plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
+            slabs = L.tn_slabs(t) if grp is None else 1
             gt = self.ws.alloc(f"enc.wg.{i}", slabs * Eb * t.K_total, torch.float32)
             t.out, t.out_batch_stride = gt.data_ptr(), Eb * t.K_total
-            with plan.side(1 + (2 * i + 1) % DecoderPlan.n_side_lanes):
-                plan.add(L.OP_GEMM_TN, t, f"wgrad.enc{i}", TAG_ENC)
+            if grp is None:
+                with plan.side(1 + (2 * i + 1) % DecoderPlan.n_side_lanes):
+                    plan.add(L.OP_GEMM_TN, t, f"wgrad.enc{i}", TAG_ENC)
+            else:
+                t.colsum_out = ps.ptr(f"encoder.net.{i}.conv.bias", True)
+                grp.add(t, f"wgrad.enc{i}")
             pk.rec(f"encoder.net.{i}.conv.weight", 0, [cin * f, f, 1], [E, cin, f], None, 0,
                    [f * cinb, 1, cinb], g_ptr=gt.data_ptr(), slabs=slabs, slab_stride=Eb * t.K_total)
             if i == 0 and not need_input_grad:
@@ -968,3 +1011,6 @@ class EncoderPlan:
                     aux0=dyo.view(row_step=s, row_off=ph - lw) if res else null_view(),
                     aux1=self.r[i].view(row_step=s, row_off=ph) if i > 0 else null_view(), impl=impl),
                     f"d.enc{i}.ph{ph}", TAG_ENC)
+        if grp is not None:
+            with plan.side(1):
+                grp.emit(plan, "wgrad.group (encoder)", TAG_ENC)

@@ -250,10 +250,26 @@ class TnGroupBuilder:
 
     N_XCD = 8
 
-    def __init__(self, ws: Workspace, name: str):
-        self.ws, self.name = ws, name
+    def __init__(self, ws: Workspace, name: str, tile: int = 128):
+        assert tile in (128, 256)
+        self.ws, self.name, self.tile = ws, name, tile
         self.descs: List[L.GemmTN] = []
         self.labels: List[str] = []
+
+    def _grid(self, t: L.GemmTN) -> Tuple[int, int]:
+        """(k tiles, n tiles) of a descriptor's output in this builder's tile size."""
+        k128, n128 = t.K_total // 128, t.N_pad // 128
+        return (k128, n128) if self.tile == 128 else ((k128 + 1) // 2, (n128 + 1) // 2)
+
+    def set_split(self, t: L.GemmTN, chunk_rows: int) -> int:
+        """Split the descriptor's contraction into chunks of about `chunk_rows` rows per batch element, one block and one
+        partial-sum slab each (matrices with few output tiles and many rows; 128-tile groups only).  Returns the number
+        of slabs `out` must hold (out_batch_stride apart)."""
+        if chunk_rows > 0 and self.tile == 128:
+            sp = max(1, -(-t.Mc // chunk_rows))
+            rows = ru(-(-t.Mc // sp), 32)
+            t.grp_splits, t.grp_rows = -(-t.Mc // rows), rows
+        return t.grp_splits * t.batch if t.grp_splits > 0 else 1
 
     def add(self, t: L.GemmTN, label: str):
         L.check(L.load().aew_tn_group_check(C.byref(t)), f"grouped TN descriptor '{label}'")
@@ -261,21 +277,24 @@ class TnGroupBuilder:
         self.labels.append(label)
 
     def tile_map(self) -> List[int]:
-        """blockIdx -> desc << 16 | tile.  Workgroup p runs on XCD p % 8: the tiles of one descriptor (they share
+        """blockIdx -> desc << 22 | chunk << 12 | tile.  Workgroup p runs on XCD p % 8: the tiles of one descriptor (they share
         the G rows along k tiles and the A rows along n tiles) go to one XCD where there are enough descriptors,
         otherwise a descriptor is cut by n tile; longest-first onto the least loaded XCD."""
-        units = []                                           # (tiles, desc, [tile ids])
+        units = []                                           # (tiles, desc, [records])
         for d, t in enumerate(self.descs):
-            nkt, nnt = t.K_total // 128, t.N_pad // 128
-            if len(self.descs) >= self.N_XCD:
-                units.append((nkt * nnt, d, list(range(nkt * nnt))))
+            nkt, nnt = self._grid(t)
+            if t.grp_splits > 0:                             # split descriptor: the tiles of one (batch, chunk) together
+                for c in range(t.grp_splits * t.batch):
+                    units.append((nkt * nnt, d, [(d << 22) | (c << 12) | tl for tl in range(nkt * nnt)]))
+            elif len(self.descs) >= self.N_XCD:
+                units.append((nkt * nnt, d, [(d << 22) | tl for tl in range(nkt * nnt)]))
             else:
                 for nt in range(nnt):
-                    units.append((nkt, d, [nt * nkt + kt for kt in range(nkt)]))
+                    units.append((nkt, d, [(d << 22) | (nt * nkt + kt) for kt in range(nkt)]))
         lists = [[] for _ in range(self.N_XCD)]
-        for n, d, tiles in sorted(units, key=lambda u: (-u[0], u[1], u[2][0])):
+        for n, d, recs in sorted(units, key=lambda u: (-u[0], u[1], u[2][0])):
             x = min(range(self.N_XCD), key=lambda i: (len(lists[i]), i))
-            lists[x].extend((d << 16) | tl for tl in tiles)
+            lists[x].extend(recs)
         depth = max(len(l) for l in lists)
         out = []
         for i in range(depth):
@@ -294,6 +313,7 @@ class TnGroupBuilder:
         mt[:len(tm)].copy_(torch.tensor(tm, dtype=torch.int32))
         gp = L.GemmTNGroup()
         gp.descs, gp.tile_map, gp.n_descs, gp.n_blocks = dt.data_ptr(), mt.data_ptr(), len(self.descs), len(tm)
+        gp.tile = self.tile
         return plan.add(L.OP_GEMM_TN_GROUP, gp, label, tag, join=join)
 
 

@@ -14,6 +14,10 @@
  *   - activations are CHANNELS-LAST: tensor[b][t][c], c fastest.  bf16 is stored as uint16
  *   - "row" means a time index t; a buffer is addressed as
  *         ptr + b*batch_stride + row*row_pitch + c            (element units)
+ *   - descriptors carry everything an op computes WITH; the only process-wide state are the aew_set_* switches
+ *     (kernel shape / schedule choices for A-B measurements and bisecting; results are the same under every setting
+ *     unless a switch says otherwise).  They default to the production choice, are not thread-safe, and take effect
+ *     for launches / graph captures made afterwards; a caller that never touches them gets a stateless library
  *
  * The hot path is a static LAUNCH PLAN: an array of aew_op_t records executed in order by
  * aew_run_plan().  Almost every record is one of two GEMM forms over *row-affine segments*:
@@ -157,6 +161,17 @@ typedef struct {
     int64_t snap_bs;
     int32_t snap_k;              /* column of the concatenated K axis; < 0: none                */
     int32_t pad_;
+    /* Grouped form only.  colsum_out != NULL: colsum_out[n] = sum_b sum_m G[b][m][n] for n < N - the bias gradient of
+     * the layer whose weight gradient this is (its G operand is the gradient of the layer's pre-activation) - written
+     * by the blocks of the first k tile from an extra all-ones MFMA operand: no separate column-sum launch, one
+     * summation order (deterministic, no atomics).                                                                  */
+    float* colsum_out;
+    /* Grouped form only.  grp_splits > 0: the contraction is cut like a stand-alone TN op's - one block per (output
+     * tile, batch element, chunk of grp_rows rows), grp_splits chunks per batch element, partial sums to slab
+     * b * grp_splits + chunk of `out` (out_batch_stride apart; the unpack sums them).  For matrices with few output
+     * tiles and a long contraction (the upsampler weights), where one block per tile would be a lone latency-bound
+     * chain.  snap_out / colsum_out need grp_splits = 0 (one block sees every row).                              */
+    int32_t grp_splits, grp_rows;
 } aew_gemm_tn_t;
 
 /* ---------------------------------------------------------------------------------------
@@ -164,14 +179,19 @@ typedef struct {
  * the WHOLE time axis and all batch elements (k ascending, b ascending) in one block.  One fp32 result per
  * descriptor (desc.out[N_pad][K_total], no split-K slabs to write and sum), and enough tiles to fill the chip
  * without splitting (20 layers x (4 x 7 + 3 x 2) tiles in the decoder).  Descriptors and the tile map live in
- * DEVICE memory (built once per plan).  tile_map[p] = desc << 16 | tile (tile = nt * (K_total / 128) + kt), or -1:
- * block p idles.  Workgroup p runs on XCD p % 8, so the builder places tiles that share operands on one XCD.
+ * DEVICE memory (built once per plan).  tile_map[p] = desc << 22 | chunk << 12 | tile (tile = nt * (K_total / 128) + kt;
+ * chunk = 0 unless the descriptor is split, see aew_gemm_tn_t.grp_splits), or -1: block p idles.  Workgroup p runs on XCD p % 8, so the builder places tiles that share operands on one XCD.
  * bf16 only.  Same products as aew_gemm_tn_t ops; the summation order differs (one chain instead of slabs).
  * ------------------------------------------------------------------------------------- */
 typedef struct {
     const aew_gemm_tn_t* descs;  /* device                                                      */
     const int32_t* tile_map;     /* device                                                      */
     int32_t n_descs, n_blocks;
+    int32_t tile;                /* 128: 128 x 128 output tiles, 4 waves, three blocks per CU
+                                    256: 256 x 256 tiles (half the operand bytes staged per FLOP), 8 waves, one block
+                                         per CU; tile = nt * ((K_total / 128 + 1) / 2) + kt in 256-column units, halves
+                                         beyond N_pad / K_total are skipped                                  */
+    int32_t pad_;
 } aew_gemm_tn_group_t;
 
 /* ---------------------------------------------------------------------------------------

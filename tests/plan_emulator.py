@@ -179,13 +179,23 @@ class Emu:
         covered = {}
         for rec in tm:
             if rec >= 0:
-                covered.setdefault(int(rec) >> 16, set()).add(int(rec) & 0xffff)
+                covered.setdefault(int(rec) >> 22, []).append(((int(rec) >> 12) & 0x3ff, int(rec) & 0xfff))
         for d, t in enumerate(descs):
-            # the tile map must name every output tile of every descriptor exactly once
-            n_tiles = (t.N_pad // 128) * (t.K_total // 128)
-            assert covered.get(d, set()) == set(range(n_tiles)), f"tile map of descriptor {d}"
-            assert sum(1 for rec in tm if rec >= 0 and (int(rec) >> 16) == d) == n_tiles
+            # the tile map must name every (chunk, output tile) of every descriptor exactly once
+            k128, n128 = t.K_total // 128, t.N_pad // 128
+            n_tiles = k128 * n128 if p.tile == 128 else ((k128 + 1) // 2) * ((n128 + 1) // 2)
+            n_chunks = t.grp_splits * t.batch if t.grp_splits > 0 else 1
+            assert sorted(covered.get(d, [])) == [(c, tl) for c in range(n_chunks) for tl in range(n_tiles)], f"tile map of descriptor {d}"
             out, ooff = self.flat(t.out)
+            if t.grp_splits > 0:                               # partial sums per (batch element, row chunk)
+                for b in range(t.batch):
+                    Gm = self.seg_matrix(self._with_k(t.g, t.N_pad), b, t.Mc, t.dtype)
+                    A = torch.cat([self.seg_matrix(t.seg[s], b, t.Mc, t.dtype) for s in range(t.n_segs)], dim=1)
+                    for sp in range(t.grp_splits):
+                        r0, r1 = sp * t.grp_rows, min(t.Mc, (sp + 1) * t.grp_rows)
+                        o = ooff + (b * t.grp_splits + sp) * t.out_batch_stride
+                        out[o:o + t.N_pad * t.K_total] = (Gm[r0:r1].t() @ A[r0:r1]).reshape(-1)
+                continue
             dW = torch.zeros(t.N_pad, t.K_total)
             for b in range(t.batch):
                 Gm = self.seg_matrix(self._with_k(t.g, t.N_pad), b, t.Mc, t.dtype)
@@ -194,6 +204,11 @@ class Emu:
                 if t.snap_out:
                     self.wr(t.snap_out, b * t.snap_bs + torch.arange(t.N_pad), dW[:, t.snap_k])
             out[ooff:ooff + t.N_pad * t.K_total] = dW.reshape(-1)
+            if t.colsum_out:
+                cs = torch.zeros(t.N_pad)
+                for b in range(t.batch):
+                    cs += self.seg_matrix(self._with_k(t.g, t.N_pad), b, t.Mc, t.dtype).sum(0)
+                self.wr(t.colsum_out, torch.arange(t.N), cs[:t.N])
 
     @staticmethod
     def _with_k(seg, k):

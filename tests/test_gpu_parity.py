@@ -318,7 +318,8 @@ def test_gemm_tn(dtype, safe, Mc):
         assert err <= (2e-3 if dtype == BF else 2e-5) * scale, ("impl", impl, "safe", safe, err, scale)
 
 
-def test_gemm_tn_group():
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_tn_group(tile):
     """AEW_OP_GEMM_TN_GROUP: several weight-gradient descriptors in one launch, each output tile contracted over all
     rows of all batch elements in one block (one result, no slabs), plus the running per-batch snapshots of the
     ones-channel column.  Against the CPU interpreter and against the per-matrix TN ops + slab sum."""
@@ -336,13 +337,19 @@ def test_gemm_tn_group():
         t = make_tn(BF, 690, B, 256, 256, G1.seg(256), [A1.seg(384), A1.seg(384, row_off=9), A2.seg(128, row_off=31)])
         t.out, t.out_batch_stride = ws.get("o1").data_ptr(), 256 * 896
         t.snap_out, t.snap_bs, t.snap_k = ws.get("snap").data_ptr(), 256, 368
+        t.colsum_out = ws.get("cs1").data_ptr()
         descs.append(t)
         t = make_tn(BF, 650, B, 368, 384, G2.seg(384, hi=640), [Z.seg(256)])
         t.out, t.out_batch_stride = ws.get("o2").data_ptr(), 384 * 256
+        t.colsum_out = ws.get("cs2").data_ptr()          # 368 real columns: entries 368.. must stay untouched
         descs.append(t)
         t = make_tn(BF, 33, B, 256, 256, G1.seg(256, row_off=5), [Z.seg(256, row_off=-2)])    # shorter than one stage pair
         t.out, t.out_batch_stride = ws.get("o3").data_ptr(), 256 * 256
         descs.append(t)
+        if tile == 128:                                  # a split descriptor: partial sums per (batch element, row chunk)
+            t = make_tn(BF, 650, B, 128, 128, G2.seg(128, row_off=3), [Z.seg(256, row_off=1), Z.seg(256)])
+            t.out, t.out_batch_stride = ws.get("o4").data_ptr(), 128 * 512
+            descs.append(t)
         return descs
 
     ws_c = Workspace("cpu")
@@ -353,21 +360,32 @@ def test_gemm_tn_group():
     for n, sz in (("o1", 256 * 896), ("o2", 384 * 256), ("o3", 256 * 256), ("snap", B * 256)):
         ws_c.alloc(n, sz, torch.float32)
         ws_c.alloc(n + ".ref", 8 * sz, torch.float32)
+    ws_c.alloc("o4", 9 * 128 * 512, torch.float32)       # 3 batch elements x 3 chunks of 224 rows
+    ws_c.alloc("cs1", 256, torch.float32)
+    ws_c.alloc("cs2", 384, torch.float32)
+    ws_c.get("cs2")[368:384] = -7.0                    # guard: columns beyond N belong to the next gradient
     ws_g = _mirror(ws_c, DEV)
     for ws in (ws_c, ws_g):
-        gb = TnGroupBuilder(ws, "tng")
+        gb = TnGroupBuilder(ws, "tng", tile)
         for i, t in enumerate(build(ws)):
+            if i == 3:
+                assert gb.set_split(t, 220) == 9 and (t.grp_splits, t.grp_rows) == (3, 224)
             gb.add(t, f"d{i}")
         p = Plan("g")
         gb.emit(p, "group")
         if ws is ws_g:
             tm = gb.tile_map()
-            assert sorted(r for r in tm if r >= 0) == sorted((d << 16) | tl for d, n in enumerate((14, 6, 4)) for tl in range(n))
+            counts = (14, 6, 4) if tile == 128 else (4, 2, 1)
+            want = [(d << 22) | tl for d, n in enumerate(counts) for tl in range(n)]
+            if tile == 128:
+                want += [(3 << 22) | (c << 12) | tl for c in range(9) for tl in range(4)]
+            assert sorted(r for r in tm if r >= 0) == sorted(want)
             p.run(stream())
             torch.cuda.synchronize()
         else:
             Emu(ws).run(p)
-    for n in ("o1", "o2", "o3", "snap"):
+    assert torch.all(ws_g.get("cs2")[368:384].cpu() == -7.0)
+    for n in ("o1", "o2", "o3", "snap", "cs1", "cs2") + (("o4",) if tile == 128 else ()):
         ref, got = ws_c.get(n).float(), ws_g.get(n).float().cpu()
         err = (got - ref).abs().max().item()
         assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (n, err)

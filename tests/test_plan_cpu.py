@@ -183,8 +183,8 @@ def test_unfolded_wgrad_and_ones_channel_colsum(golden_dir, monkeypatch):
         lib.aew_set_tn_fold_rows(4096)
 
 
-@pytest.mark.parametrize("group,split", [(64, 0), (8, 0), (3, 0), (1, 0), (64, 3)])
-def test_grouped_wgrad_plan(golden_dir, monkeypatch, group, split):
+@pytest.mark.parametrize("group,split,tile", [(64, 0, 256), (64, 0, 128), (8, 0, 256), (3, 0, 128), (1, 0, 256), (64, 3, 256)])
+def test_grouped_wgrad_plan(golden_dir, monkeypatch, group, split, tile):
     """The default backward: the gated stack's weight gradients as grouped launches (AEW_OP_GEMM_TN_GROUP, one
     result per matrix, every tile named once in the tile map: the interpreter checks that) and the per-batch
     bias / speaker sums from the running ones-channel snapshots, for several group sizes."""
@@ -193,11 +193,15 @@ def test_grouped_wgrad_plan(golden_dir, monkeypatch, group, split):
     from ae_wavenet_amd import engine as E
     monkeypatch.setattr(E.DecoderPlan, "wgrad_group", group)
     monkeypatch.setattr(E.DecoderPlan, "wgrad_split_layers", split)   # top layers as one split-K op per matrix
+    monkeypatch.setattr(E.DecoderPlan, "wgrad_tile", tile)
     z = load(golden_dir, "mi_tiny_jitter.npz")
     hps, eng = make_engine(z, "mfcc_inverter", 7)
     NL = len(eng.geom.layers)
     kinds = [op.kind for op in eng.bwd.ops]
-    assert kinds.count(L.OP_GEMM_TN_GROUP) == max(1, -(-(NL - split) // group))
+    # the stack's groups + the upsampler / lc-conv group (the MFCC inverter has no encoder group)
+    assert kinds.count(L.OP_GEMM_TN_GROUP) == max(1, -(-(NL - split) // group)) + 1
+    assert not any(lab.startswith(("db.post", "db.base", "db.lc", "wgrad.base", "wgrad.up", "wgrad.lc", "wgrad.p"))
+                   for lab in eng.bwd.labels)
     assert sum(lab.startswith("wgrad.fg") for lab in eng.bwd.labels) == split
     spk = [op.u.spkb for op in eng.bwd.ops if op.kind == L.OP_SPK_BWD]
     assert len(spk) == 1 and spk[0].colsum_running == NL - split
