@@ -128,7 +128,7 @@ class SoftmaxNll(C.Structure):
     _fields_ = [("logits", vp), ("bs", i64), ("pitch", i32), ("wav", vp), ("wav_pitch", i32),
                 ("tgt_off", i32), ("B", i32), ("w", i32), ("Q", i32), ("Q_pad", i32),
                 ("nll", vp), ("ptgt", vp), ("dlogits", vp), ("dl_bs", i64), ("dl_pitch", i32),
-                ("scale", f32), ("backward", i32), ("gmul", vp)]
+                ("scale", f32), ("backward", i32), ("gmul", vp), ("peak", vp), ("amax", vp)]
 
 
 class Colsum(C.Structure):
@@ -172,7 +172,7 @@ class Jitter(C.Structure):
 class VqDiag(C.Structure):
     _fields_ = [("ze", vp), ("Q", i32), ("d", i32), ("d_pitch", i32), ("emb", vp), ("K", i32), ("hist", vp),
                 ("n_sum", vp), ("logits", vp), ("bs", i64), ("pitch", i32), ("B", i32), ("w", i32),
-                ("n_quant", i32), ("scratch", vp), ("out", vp)]
+                ("n_quant", i32), ("scratch", vp), ("out", vp), ("peak", vp), ("amax", vp)]
 
 
 class Mfcc(C.Structure):

@@ -476,12 +476,16 @@ __global__ void k_spk_bias(const aew_spk_bias_t p) {
     p.bias[((int64_t)b * p.L + l) * 2 * p.D_pad + n] = v;
 }
 
+#define AEW_SPK_MAXB 16
 __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
-    // grid (L, 2): one block per (layer, filt|gate); thread = output channel co
+    // grid (L, 2): one block per (layer, filt|gate); thread = output channel co.  Everything a thread needs from global
+    // memory is fetched before the (batch x G) loops (they used to re-load the column sums and gc inside: 160 dependent
+    // loads per thread behind LDS atomics the compiler cannot move loads across, 58 us for 40 blocks).
     const int l = blockIdx.x, half = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
-    extern __shared__ float sh[];                    // [B][G] d(gc) of this (layer, half)
-    for (int i = tid; i < p.B * p.G; i += blockDim.x) sh[i] = 0.f;
+    extern __shared__ float sh[];                    // [B][G] d(gc) of this (layer, half), then [B][G] gc
+    float* gcs = sh + p.B * p.G;
+    for (int i = tid; i < p.B * p.G; i += blockDim.x) { sh[i] = 0.f; gcs[i] = p.gc[i]; }
     __syncthreads();
     const int64_t ob = half ? p.off_bias_gate[l] : p.off_bias_sig[l];
     const int64_t ov0 = half ? p.off_proj_gate[l] : p.off_proj_sig[l];
@@ -490,23 +494,29 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
         const bool ok = co < p.D;
         const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
         const int64_t ov = ov0 + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
-        float bsum = 0.f;
-        // per-batch column sum of dfg (layers below colsum_running: the buffer holds the sums over batch elements 0..b)
-        auto cs_of = [&](int b) -> float {
-            if (!ok) return 0.f;
-            const float v = p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n];
-            return (l < p.colsum_running && b > 0) ? v - p.colsum[((int64_t)(b - 1) * p.L + l) * 2 * p.D_pad + n] : v;
-        };
-        for (int b = 0; b < p.B; ++b) bsum += cs_of(b);
+        // per-batch column sums of dfg (layers below colsum_running: the buffer holds the sums over batch elements 0..b)
+        float csv[AEW_SPK_MAXB];
+        float bsum = 0.f, prev = 0.f;
+#pragma unroll
+        for (int b = 0; b < AEW_SPK_MAXB; ++b) {
+            float v = (ok && b < p.B) ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+            const float raw = v;
+            if (l < p.colsum_running && b > 0) v -= prev;
+            prev = raw;
+            csv[b] = (b < p.B) ? v : 0.f;
+            bsum += csv[b];
+        }
         if (ok && ob >= 0) p.grads[ob + co] = bsum;
         for (int j = 0; j < p.G; ++j) {
             const float vj = ok ? p.params[ov + j] : 0.f;
             float gv = 0.f;
-            for (int b = 0; b < p.B; ++b) {
-                const float cs = cs_of(b);
-                gv += cs * p.gc[b * p.G + j];
-                const float part = wave_sum(cs * vj);
-                if (lane == 0) atomicAdd(&sh[b * p.G + j], part);
+#pragma unroll
+            for (int b = 0; b < AEW_SPK_MAXB; ++b) {
+                if (b < p.B) {
+                    gv += csv[b] * gcs[b * p.G + j];
+                    const float part = wave_sum(csv[b] * vj);
+                    if (lane == 0) atomicAdd(&sh[b * p.G + j], part);
+                }
             }
             if (ok) p.grads[ov + j] = gv;
         }
@@ -548,31 +558,53 @@ __global__ void k_base_gather(const aew_base_gather_t p) {
 
 // fast form: one wave per row, 8 channels per lane, the row of the transposed table Wt[q][:] is one
 // contiguous read (the [R][Q] layout costs R loads 1 KiB apart per row: 107 us -> ~25 us at B=8, T=7046)
+// A wave takes AEW_BG_ROWS rows: the dependent pair (class of the row -> its table row) is issued for all of them before
+// the first store, so a wave has four rows' loads in flight instead of one (54 -> ~30 us for 56 k rows at B = 8).
+#define AEW_BG_ROWS 4
 __global__ __launch_bounds__(256) void k_base_gather_t(const aew_base_gather_t p) {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
-    if (t >= p.T) return;
-    const int q = (int)p.wav[(int64_t)b * p.wav_pitch + p.wav_off + t];
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * AEW_BG_ROWS, b = blockIdx.y;
+    if (t0 >= p.T) return;
     const int c8 = lane * 8;
-    if (c8 < p.R_pad) {
-        const float* wr = p.Wt + (int64_t)q * p.R_pad + c8;
-        const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
-        float v[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    int q[AEW_BG_ROWS];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int c = c8 + r;
-            v[r] = c < p.R ? v[r] + (p.bias ? p.bias[c] : 0.f) : ((p.ones_channel && c == p.R) ? 1.0f : 0.f);
+    for (int i = 0; i < AEW_BG_ROWS; ++i)
+        q[i] = (int)p.wav[(int64_t)b * p.wav_pitch + p.wav_off + min(t0 + i, p.T - 1)];
+    float bias8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bias8[r] = (p.bias && c8 + r < p.R) ? p.bias[c8 + r] : 0.f;
+    if (c8 < p.R_pad) {
+        float4 w0[AEW_BG_ROWS], w1[AEW_BG_ROWS];
+#pragma unroll
+        for (int i = 0; i < AEW_BG_ROWS; ++i) {
+            const float* wr = p.Wt + (int64_t)q[i] * p.R_pad + c8;
+            w0[i] = *reinterpret_cast<const float4*>(wr);
+            w1[i] = *reinterpret_cast<const float4*>(wr + 4);
         }
-        *reinterpret_cast<uint4*>(p.x + (int64_t)b * p.x_bs + (int64_t)t * p.x_pitch + c8) =
-            make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+#pragma unroll
+        for (int i = 0; i < AEW_BG_ROWS; ++i) {
+            if (t0 + i >= p.T) break;
+            float v[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = c8 + r;
+                v[r] = c < p.R ? v[r] + bias8[r] : ((p.ones_channel && c == p.R) ? 1.0f : 0.f);
+            }
+            *reinterpret_cast<uint4*>(p.x + (int64_t)b * p.x_bs + (int64_t)(t0 + i) * p.x_pitch + c8) =
+                make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+        }
     }
     if (p.onehot && c8 < p.Q_pad) {
-        uint32_t w[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)                                   // bf16 1.0 = 0x3f80
-            w[r] = (c8 + 2 * r == q ? 0x3f80u : 0u) | (c8 + 2 * r + 1 == q ? 0x3f800000u : 0u);
-        *reinterpret_cast<uint4*>(p.onehot + (int64_t)b * p.oh_bs + (int64_t)t * p.oh_pitch + c8) =
-            make_uint4(w[0], w[1], w[2], w[3]);
+        for (int i = 0; i < AEW_BG_ROWS; ++i) {
+            if (t0 + i >= p.T) break;
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                               // bf16 1.0 = 0x3f80
+                w[r] = (c8 + 2 * r == q[i] ? 0x3f80u : 0u) | (c8 + 2 * r + 1 == q[i] ? 0x3f800000u : 0u);
+            *reinterpret_cast<uint4*>(p.onehot + (int64_t)b * p.oh_bs + (int64_t)(t0 + i) * p.oh_pitch + c8) =
+                make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
 }
 
@@ -605,6 +637,18 @@ __global__ __launch_bounds__(256) void k_softmax_nll(const aew_softmax_nll_t p) 
                 const float lp = (r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3]) - lse4;
                 p.nll[pos] = live ? -lp : 0.f;
                 if (p.ptgt) p.ptgt[pos] = live ? __expf(lp) : 0.f;
+            }
+            if (p.peak) {
+                // peak log-probability = max - logsumexp; its class = the lowest one holding the maximum: the first
+                // lane (classes ascend with the lane) that has it reports
+                const float m01 = fmaxf(v[0], v[1]), m23 = fmaxf(v[2], v[3]);
+                const bool has = fmaxf(m01, m23) == mx4;
+                const unsigned long long mask = __ballot(has);
+                if (lane == __builtin_ctzll(mask)) {
+                    const int r = v[0] == mx4 ? 0 : (v[1] == mx4 ? 1 : (v[2] == mx4 ? 2 : 3));
+                    p.peak[pos] = -__logf(se4);
+                    p.amax[pos] = 4 * lane + r;
+                }
             }
         } else {
             uint16_t* dl4 = p.dlogits + (int64_t)b * p.dl_bs + (int64_t)u * p.dl_pitch;
@@ -1035,7 +1079,26 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
         for (int k = tid; k < p.K; k += 1024) c += p.n_sum[k] > 0.f ? 1.0 : 0.0;
         o[5] = (float)block_sum(c, shd);
     }
-    if (p.logits) {
+    if (p.peak && p.amax) {                                   // per-position arrays written by the softmax kernel
+        __shared__ int seen[256];
+        if (tid < 256) seen[tid] = 0;
+        __syncthreads();
+        double s1 = 0.0, s2 = 0.0;
+        const int64_t n_all = (int64_t)p.B * p.w;
+        for (int64_t i = tid; i < n_all; i += 1024) {
+            if ((int)(i % p.w) == p.w - 1) continue;
+            const double pk = (double)p.peak[i];
+            s1 += pk; s2 += pk * pk;
+            seen[p.amax[i] & 255] = 1;
+        }
+        const double t1 = block_sum(s1, shd), t2 = block_sum(s2, shd);
+        const double n = (double)p.B * (p.w - 1);
+        const double mean = t1 / n;
+        o[6] = (float)mean;
+        o[7] = n > 1.0 ? (float)sqrt(fmax((t2 - n * mean * mean) / (n - 1.0), 0.0)) : 0.f;   // torch.std: unbiased
+        __syncthreads();
+        o[8] = (float)block_sum(tid < 256 && seen[tid] ? 1.0 : 0.0, shd);
+    } else if (p.logits) {
         const double* acc = reinterpret_cast<const double*>(p.scratch);
         const float* gb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scratch) + 16);
         const double n = (double)p.B * (p.w - 1);
@@ -1207,14 +1270,15 @@ static int launch_spk_bias(const aew_spk_bias_t& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
-    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2), dim3(256), p.B * p.G * sizeof(float), st, p);
+    if (p.B > AEW_SPK_MAXB) return AEW_E_UNSUP;
+    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2), dim3(256), 2 * p.B * p.G * sizeof(float), st, p);
     return (int)hipGetLastError();
 }
 static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {
     const int cmax = p.onehot && p.Q_pad > p.R_pad ? p.Q_pad : p.R_pad;
     if (p.Wt && cmax <= 512 && p.R_pad % 8 == 0 && (!p.onehot || p.Q_pad % 8 == 0) && (p.x_pitch % 8) == 0 &&
         (!p.onehot || p.oh_pitch % 8 == 0)) {
-        hipLaunchKernelGGL(k_base_gather_t, dim3(cdiv64(p.T, 4), p.B), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_base_gather_t, dim3(cdiv64(p.T, 4 * AEW_BG_ROWS), p.B), dim3(256), 0, st, p);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_base_gather, dim3(cdiv64(cmax / 4, 64), p.T, p.B), dim3(64), 0, st, p);
@@ -1222,7 +1286,8 @@ static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {
 }
 static int launch_vq_diag(const aew_vq_diag_t& p, hipStream_t st) {
     if (!p.out || (p.logits && (!p.scratch || p.n_quant < 1 || p.n_quant > 256 || p.w < 2))) return AEW_E_ARG;
-    if (p.logits) {
+    if ((p.peak != nullptr) != (p.amax != nullptr) || (p.peak && p.w < 2)) return AEW_E_ARG;
+    if (p.logits && !p.peak) {
         hipError_t e = hipMemsetAsync(p.scratch, 0, 16 + 256 * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
         const int64_t n_pos = (int64_t)p.B * (p.w - 1);

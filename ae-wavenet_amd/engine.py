@@ -581,6 +581,8 @@ class DecoderPlan:
         sm.nll, sm.ptgt = self.nll.data_ptr(), self.ptgt.data_ptr()
         sm.dlogits, sm.dl_bs, sm.dl_pitch = self.dlogits.ptr, self.dlogits.bs, self.dlogits.pitch
         sm.scale, sm.backward = scale, int(backward)
+        if not backward and getattr(self, "peak_ptrs", None):
+            sm.peak, sm.amax = self.peak_ptrs
         if backward and self.gmul_ptr:
             sm.gmul = self.gmul_ptr
         return sm

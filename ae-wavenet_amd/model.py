@@ -251,15 +251,32 @@ class TrainEngine:
             with fb.side(1):
                 fb.add(L.OP_VQ_DIAG, dv, "diagnostics (codebook)", TAG_LOSS)
 
-        def after_logits(plan):
+        # peak statistics of the predicted distribution (vqema_bn.py:261-263).  With the reference's 256 classes the
+        # softmax kernel has each row in registers and writes the per-position peak log-probability / arg-max next to the
+        # nll; the diagnostics op then reduces 2 x 160 KB instead of reading the 41 MB of logits a second time
+        fused_peak = hps.n_quant == 256 and self.dec.Qp == 256
+        if fused_peak:
+            self.peak_buf = ws.alloc("diag.peak_pos", B * w, torch.float32)
+            self.amax_buf = ws.alloc("diag.amax_pos", B * w, torch.int32)
+            self.dec.peak_ptrs = (self.peak_buf.data_ptr(), self.amax_buf.data_ptr())
+
+        def peak_diag(plan):
             dg = L.VqDiag()
             lgm = self.dec.logits
             dg.logits, dg.bs, dg.pitch, dg.B, dg.w, dg.n_quant = lgm.ptr, lgm.bs, lgm.pitch, B, w, hps.n_quant
             dg.scratch, dg.out = self.diag_scratch.data_ptr(), self.diag_pk.data_ptr()
+            if fused_peak:
+                dg.peak, dg.amax = self.dec.peak_ptrs
             with plan.side(1):
                 plan.add(L.OP_VQ_DIAG, dg, "diagnostics (peak)", TAG_LOSS)
 
+        def after_logits(plan):
+            if not fused_peak:
+                peak_diag(plan)
+
         def after_nll(plan):
+            if fused_peak:
+                peak_diag(plan)
             met = L.Reduce()
             mterms = [(self.dec.nll.data_ptr(), B * w, 1.0 / n_pos_m), (self.dec.ptgt.data_ptr(), B * w, 1.0 / n_pos_m)]
             if bn in ("vqvae-ema", "vqvae"):

@@ -330,6 +330,9 @@ typedef struct {                 /* fused log-softmax + NLL (+ gradient)  wavene
     float scale;                 /* bwd: d(loss)/d(nll term)                                  */
     int32_t backward;
     const float* gmul;           /* optional device scalar: upstream d(L)/d(loss), multiplies scale at run time */
+    float* peak; int32_t* amax;  /* fwd, optional: [B][w] peak log-probability max_c log p(c) and its (lowest) class per
+                                    position - what aew_vq_diag_t reduces (vqema_bn.py:261-263) without reading the
+                                    logits again                                               */
 } aew_softmax_nll_t;
 
 typedef struct {                 /* MFCC + delta + delta-delta front-end on the device (mfcc.py:39-76: librosa.feature.mfcc
@@ -363,6 +366,8 @@ typedef struct {                 /* per-step diagnostics of the reference's loss
     int32_t B, w, n_quant;       /* n_quant <= 256                                             */
     void* scratch;               /* >= 2 KiB, cleared by the op                                */
     float* out;                  /* [12]                                                       */
+    const float* peak; const int32_t* amax;   /* instead of `logits`: the per-position arrays aew_softmax_nll_t wrote
+                                                 ([B][w], u = w-1 dropped); out[6..8] come from them               */
 } aew_vq_diag_t;
 
 typedef struct {                 /* first two moments of a channels-last view: the gradient statistics run() reports

@@ -422,6 +422,10 @@ class Emu:
             self.wr(p.nll, torch.arange(p.B * p.w), (-lp * live).reshape(-1))
             if p.ptgt:
                 self.wr(p.ptgt, torch.arange(p.B * p.w), (lp.exp() * live).reshape(-1))
+            if p.peak:
+                pk, am = lsm.max(-1)
+                self.wr(p.peak, torch.arange(p.B * p.w), pk.reshape(-1))
+                self.wr(p.amax, torch.arange(p.B * p.w), am.reshape(-1).int())
         else:
             g = (lsm.exp() - torch.nn.functional.one_hot(tgt, p.Q).float()) * (p.scale * self._gmul(p)) * live[:, :, None]
             out = torch.zeros(p.B, p.w, p.Q_pad)
@@ -520,7 +524,11 @@ class Emu:
             o[4] = -(n * torch.where(n == 0, torch.zeros_like(n), torch.log2(n))).sum()
         if p.n_sum:
             o[5] = (self.rd(p.n_sum, torch.arange(p.K)) > 0).sum()
-        if p.logits:
+        if p.peak:
+            pk = self.rd(p.peak, torch.arange(p.B * p.w)).view(p.B, p.w)[:, :p.w - 1].double()
+            am = self.rd(p.amax, torch.arange(p.B * p.w)).view(p.B, p.w)[:, :p.w - 1]
+            o[6], o[7], o[8] = pk.mean(), pk.std(), am.unique().numel()
+        elif p.logits:
             idx = (torch.arange(p.B)[:, None, None] * p.bs + torch.arange(p.w - 1)[None, :, None] * p.pitch
                    + torch.arange(p.n_quant)[None, None, :])
             pk, am = torch.log_softmax(self.rd(p.logits, idx).double(), -1).max(-1)

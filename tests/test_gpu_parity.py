@@ -553,7 +553,11 @@ def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.", "scratch.")):
             continue                     # wgrad slabs / search scratch: implementation detail; tables hold pointers
         tg = eg.ws.get(n).cpu()
         if tc.dtype in (torch.int64, torch.int32):
-            if not torch.equal(tc, tg):
+            if n == "diag.amax_pos":
+                # arg-max class per position: the two forwards differ by bf16 rounding noise, near-ties may flip
+                if (tc != tg).float().mean().item() > 0.02:
+                    bad.append((n, "arg-max classes differ in more than 2 % of the positions"))
+            elif not torch.equal(tc, tg):
                 bad.append((n, "int mismatch"))
             continue
         a, b = tc.float(), tg.float()
