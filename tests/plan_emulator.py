@@ -102,7 +102,7 @@ class Emu:
                     W2 = W2t[w2off:w2off + g.N2_pad * K2].float().view(g.N2_pad, K2)
                     zs = torch.zeros(g.M, K2)
                     zs[:, :g.N] = self.vload(g.out0, b, m, 0, g.N)
-                    res = zs @ W2.t()[:, :g.N2]
+                    res = (zs @ W2.t())[:, :g.N2]             # (the product shape of the two-op form: same BLAS blocking)
                     if g.aux0.ptr:
                         res = res + self.vload(g.aux0, b, m, 0, g.N2)
                     self.vstore(g.out3, b, m, 0, res)
