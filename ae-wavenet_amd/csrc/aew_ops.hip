@@ -29,12 +29,18 @@ __global__ void k_copy_table(const aew_copy_table_t t) {
     const int per_thread = (vec || vecf || vecd) ? 1 : 4;
     const int64_t base = (int64_t)(blockIdx.x - r.first_block) * (256 * per_thread);
     for (int u = 0; u < per_thread; ++u) {
-        int64_t e = base + u * 256 + threadIdx.x;
-        if (e >= total) return;
-        const int i3 = (int)(e % d3) * ((vec || vecf) ? 4 : (vecd ? 8 : 1)); e /= d3;
-        const int i2 = (int)(e % r.dims[2]); e /= r.dims[2];
-        const int i1 = (int)(e % r.dims[1]); e /= r.dims[1];
-        const int i0 = (int)e;
+        const int64_t e64 = base + u * 256 + threadIdx.x;
+        if (e64 >= total) return;
+        // (32-bit index arithmetic: a record never has 2^32 items, and three 64-bit divisions per item were most of
+        // what a pack / unpack thread executed)
+        unsigned e = (unsigned)e64;
+        const unsigned q3 = e / (unsigned)d3;
+        const int i3 = (int)(e - q3 * (unsigned)d3) * ((vec || vecf) ? 4 : (vecd ? 8 : 1)); e = q3;
+        const unsigned q2 = e / (unsigned)r.dims[2];
+        const int i2 = (int)(e - q2 * (unsigned)r.dims[2]); e = q2;
+        const unsigned q1 = e / (unsigned)r.dims[1];
+        const int i1 = (int)(e - q1 * (unsigned)r.dims[1]);
+        const int i0 = (int)q1;
         const int64_t so = i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3];
         const int64_t dof = i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
         if (vecf) {
