@@ -210,6 +210,7 @@ class DecoderPlan:
                               # kernels lose the LDS those blocks hold: 8.63 / 9.68 ms per step with groups of 8 / 4
                               # against 7.68 with one launch and 7.75 with one split-K op per matrix).  0: one TN op per
                               # matrix (round 2's form)
+    side_inputs_first = True  # forward: spk_bias / base_gather at the head of the plan's side lane (False: after the upsamplers)
     wgrad_tile = 128          # output tile of the grouped wgrad launch: 128 (three 4-wave blocks per CU) | 256 (one 8-wave
                               # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
                               # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
@@ -421,6 +422,30 @@ class DecoderPlan:
         B, g, hps, p = self.B, self.g, self.hps, self.pre
         Rp, Dp, Sp, Pp, Qp, Cp, Lp = self.Rp, self.Dp, self.Sp, self.Pp, self.Qp, self.Cp, self.Lp
         impl = self.impl
+        # 4./5. (emitted FIRST when side_inputs_first: they depend on nothing in this plan, so the side lane runs them
+        # under the conditioning path instead of starting after its last op)
+        def side_inputs():
+            # 4. speaker-conditioned gated bias (wavenet.py:127-140 folded)
+            sb = L.SpkBias()
+            self._fill_spk(sb)
+            sb.bias, sb.gc = self.bias_bl.data_ptr(), self.gc.data_ptr()
+            with plan.side():                                      # independent of the conditioning path
+                plan.add(L.OP_SPK_BIAS, sb, "spk_bias", TAG_MISC)
+            # 5. base layer = column gather (wavenet.py:348-351)
+            bg = L.BaseGather()
+            bg.wav, bg.wav_pitch, bg.wav_off = self.wav.data_ptr(), self.wav.shape[1], g.trim_dec_in[0]
+            bg.W = self.ps.ptr(p + "base_layer.weight")
+            bg.Wt = self.Wbase_t.ptr
+            bg.bias = self.ps.ptr(p + "base_layer.bias") if self.ps.has(p + "base_layer.bias") else None
+            bg.B, bg.T, bg.R, bg.R_pad, bg.Q = B, self.T, self.R, Rp, self.Q
+            bg.x, bg.x_bs, bg.x_pitch = self.x[0].ptr, self.x[0].bs, self.x[0].pitch
+            if need_onehot:
+                bg.onehot, bg.oh_bs, bg.oh_pitch, bg.Q_pad = self.onehot.ptr, self.onehot.bs, self.onehot.pitch, Qp
+            bg.ones_channel = int(self.R < Rp)
+            with plan.side():
+                plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
+        if self.side_inputs_first:
+            side_inputs()
         # 1. jitter gather (wavenet.py:330-336)
         lg_ = L.LcGather()
         lg_.src, lg_.src_bs, lg_.src_pitch = self.lc_src.ptr, self.lc_src.bs, self.lc_src.pitch
@@ -470,27 +495,12 @@ class DecoderPlan:
                     BF, Mq, Cp, Cp, B, segs, self.Wup[i][ph].ptr, flags=L.EF_BIAS,
                     out0=Y.view(row_off=o0 - trim0, row_step=s), bias_ptr=self.bias_vec[f"up{i}"],
                     impl=impl), f"ups{i}.ph{ph}", TAG_UPS)
-        # 4. speaker-conditioned gated bias (wavenet.py:127-140 folded)
-        sb = L.SpkBias()
-        self._fill_spk(sb)
-        sb.bias, sb.gc = self.bias_bl.data_ptr(), self.gc.data_ptr()
-        with plan.side():                                      # independent of the conditioning path
-            plan.add(L.OP_SPK_BIAS, sb, "spk_bias", TAG_MISC)
-        # 5. base layer = column gather (wavenet.py:348-351)
-        bg = L.BaseGather()
-        bg.wav, bg.wav_pitch, bg.wav_off = self.wav.data_ptr(), self.wav.shape[1], g.trim_dec_in[0]
-        bg.W = self.ps.ptr(p + "base_layer.weight")
-        bg.Wt = self.Wbase_t.ptr
-        bg.bias = self.ps.ptr(p + "base_layer.bias") if self.ps.has(p + "base_layer.bias") else None
-        bg.B, bg.T, bg.R, bg.R_pad, bg.Q = B, self.T, self.R, Rp, self.Q
-        bg.x, bg.x_bs, bg.x_pitch = self.x[0].ptr, self.x[0].bs, self.x[0].pitch
-        if need_onehot:
-            bg.onehot, bg.oh_bs, bg.oh_pitch, bg.Q_pad = self.onehot.ptr, self.onehot.bs, self.onehot.pitch, Qp
-        bg.ones_channel = int(self.R < Rp)
-        with plan.side():
-            plan.add(L.OP_BASE_GATHER, bg, "base_gather", TAG_MISC)
+        if not self.side_inputs_first:
+            side_inputs()
         # 6. gated dilated stack (wavenet.py:91-111, 355-357)
         NL = self.NL
+        # layer 0 waits for lane 1 only (x[0], gated biases), not for the other lanes' work that only later steps read
+        g1_join = ("lane", 1) if self.side_inputs_first else True
         # Optionally (split_chains) the gated stack runs as two independent half-batch chains, chain 0 on the
         # main lane and chain 1 on the side lane, so that each fills the other's tile-wave tails (a full-batch
         # layer GEMM is 1.1-1.5 waves of tiles and nothing else is runnable in the forward).
@@ -514,12 +524,12 @@ class DecoderPlan:
                     plan.add(L.OP_GEMM_NT, make_nt(
                         BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, impl=2, W2_ptr=self.Wrs[l].ptr, N2=Rp, N2_pad=Rp,
                         out3=self.x[l + 1].view(b0=b0), aux0=x.view(row_off=lg.dil, b0=b0), **gkw),
-                        f"G1.{l}" + sfx, TAG_G1, join=(l == 0 and c == 0))
+                        f"G1.{l}" + sfx, TAG_G1, join=g1_join if (l == 0 and c == 0) else False)
                     continue
                 plan.add(L.OP_GEMM_NT, make_nt(
                     BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, impl=self._impl("G1"), **gkw),
                     f"G1.{l}" + sfx, TAG_G1,
-                    join=(l == 0 and c == 0))                 # x[0] and the gated biases come from the side lane
+                    join=g1_join if (l == 0 and c == 0) else False)   # x[0] and the gated biases come from the side lane
                 if not last:
                     # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
                     plan.add(L.OP_GEMM_NT, make_nt(

@@ -34,6 +34,7 @@ class TrainEngine:
     update_codebook_every_step: refresh emb from the EMA statistics each step (standard
     VQ-VAE-EMA); the reference only refreshes at global_step == 10000 (chassis.py:175-176).
     """
+    DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
     PACK_LANE = 2             # side lane of the forward-layout weight pack (layers 1.. of the encoder, biases, bottleneck)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
                               # forward plan; A/B: 8.02 -> 7.99 ms per step)
@@ -248,7 +249,7 @@ class TrainEngine:
                 dv.hist, dv.n_sum = self.ind_hist.data_ptr(), self.n_sum_diag.data_ptr()
             dv.B, dv.w, dv.n_quant = B, w, hps.n_quant
             dv.scratch, dv.out = self.diag_scratch.data_ptr(), self.diag.data_ptr()
-            with fb.side(1):
+            with fb.side(self.DIAG_LANE):                       # not lane 1: decoder layer 0 waits for that one
                 fb.add(L.OP_VQ_DIAG, dv, "diagnostics (codebook)", TAG_LOSS)
 
         # peak statistics of the predicted distribution (vqema_bn.py:261-263).  With the reference's 256 classes the
