@@ -101,5 +101,7 @@ class FusedAdam(torch.optim.Optimizer):
             eng.step_count = step
 
     def zero_grad(self, set_to_none=True):
-        # gradients are rewritten (not accumulated) by every backward; nothing to do
+        # the backward plan rewrites the flat gradient buffer: "cleared" is a flag the next backward reads (no memset;
+        # without it the next backward adds to the existing .grad like any torch module, surface._grads_carried)
+        self.model._grads_cleared = True
         return None

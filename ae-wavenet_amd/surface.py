@@ -38,11 +38,14 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, g):
         # g = d(L)/d(loss) from autograd ((loss * k).backward(), loss scaling, ...).  It is copied device-side into
         # the engine's `gmul` scalar, which the ops where the loss gradient enters the backward plan multiply in, so
-        # every .grad carries it.  .grad is OVERWRITTEN by each backward (the reference harness zeroes it every
-        # step, chassis.py:157-160); accumulation over several backward() calls is not supported.
+        # every .grad carries it.  The backward plan WRITES the flat gradient buffer; nn.Module semantics (a second
+        # backward() without zero_grad() adds to .grad) are kept by carrying the previous values over explicitly - a
+        # path the reference harness never takes (it zeroes every step, chassis.py:157-160; FusedAdam.zero_grad() /
+        # zero_grad(set_to_none=True) cost nothing here).
         owner = ctx.owner
         owner._engine.set_upstream_grad(g)
         dp = owner._dp
+        prev = owner._grads_carried()
         if dp is not None and dp.sharded and dp.world > 1:
             dp.backward_exchange(owner._engine, dp.bf16_grads)   # reduce-scatter issued under the encoder backward
         else:
@@ -50,6 +53,9 @@ class _StepFn(torch.autograd.Function):
                 dp.allreduce_kl(owner._engine)               # VAE: the clamp's gate sees the global KL
             owner._engine.backward()
         owner._after_backward(g)
+        if prev is not None:
+            eng = owner._engine
+            eng.ps.grads[:eng.ps.numel].add_(prev)
         return torch.zeros_like(owner._anchor), None
 
 
@@ -106,6 +112,7 @@ class HipModelBase(nn.Module):
         self._engine: Optional[TrainEngine] = None
         self._engines: Dict[int, TrainEngine] = {}      # engines by batch size (train B, sampling B = 1, ...)
         self._opt_carry = None                           # (step, exp_avg flat, exp_avg_sq flat) while no engine holds them
+        self._grads_cleared = True                       # no backward yet / FusedAdam.zero_grad() since the last one
         self._opt_carry_partial = False                  # carry saved from a sharded DP engine without a moment gather
         self._weights_epoch = 0                          # bumped whenever parameter values change behind torch's back
         self._device = torch.device("cpu")
@@ -338,6 +345,7 @@ class HipModelBase(nn.Module):
                 view.copy_(p.data.to(self._device))
                 p.data = view
                 p.grad = eng.ps.view(name, grad=True)
+        self._grads_cleared = True                               # gradients do not move between engines
         self._engine = eng
         self._weights_epoch += 1
         self._push_buffers_to_engine()
@@ -415,6 +423,31 @@ class HipModelBase(nn.Module):
             out, _ = smp.generate(cond.expand(n16, -1, -1).contiguous(), bias.expand(n16, -1, -1).contiguous(),
                                   forced.contiguous(), seed=seed)
             return torch.cat([given, out[:R]], 0).float()
+
+    def _grads_carried(self):
+        """What the coming backward has to ADD to the gradients it writes: None when the gradients were cleared
+        (FusedAdam.zero_grad(), or every .grad is None as zero_grad(set_to_none=True) leaves them), else a copy of the
+        current values (zeros where a single .grad is None) - torch's accumulate-into-.grad rule."""
+        eng = self._engine
+        cleared, self._grads_cleared = self._grads_cleared, False
+        if cleared:
+            return None
+        grads = [(name, self._parameters[pname].grad) for name, pname in self._pnames]
+        if all(gr is None for _, gr in grads):
+            return None
+        if self._dp is not None and self._dp.sharded and self._dp.world > 1:
+            raise L.AewError("backward() onto existing gradients (no zero_grad() since the last backward) is not supported "
+                             "under the sharded data-parallel schedule: each rank holds the reduced gradient of its own "
+                             "shards only")
+        prev = eng.ps.grads[:eng.ps.numel].clone()
+        for name, gr in grads:
+            view = eng.ps.view(name, grad=True)
+            o = (view.data_ptr() - eng.ps.grads.data_ptr()) // 4
+            if gr is None:
+                prev[o:o + view.numel()].zero_()
+            elif gr.data_ptr() != view.data_ptr():               # somebody assigned their own tensor
+                prev[o:o + view.numel()].copy_(gr.detach().reshape(-1).to(prev))
+        return prev
 
     def _after_backward(self, g):
         eng = self._engine

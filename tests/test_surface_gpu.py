@@ -57,6 +57,7 @@ def test_unclipped_jitter_is_clamped():
     got = pred.clone(), m._engine.ps.grads[:m._engine.ps.numel].clone(), m._engine.dec.dlc_src.tensor().clone()
     assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all()
     clipped = torch.from_numpy(np.clip(raw[:, :Ne], 0, Ne - 1)).to(DEV)
+    m.zero_grad()
     pred2, _, loss2 = m.run(wav, mel, voice, clipped)
     loss2.backward()
     torch.cuda.synchronize()
@@ -79,15 +80,30 @@ def test_upstream_gradient_reaches_every_grad(bn):
     n = m._engine.ps.numel
     g1 = m._engine.ps.grads[:n].clone()
     assert float(g1.abs().max()) > 0
+    m.zero_grad()
     _, _, loss = m.run(*batch, eps=eps)
     (loss * 4.0).backward()                                    # a power of two: bf16 / fp32 roundings scale exactly
     torch.cuda.synchronize()
     g4 = m._engine.ps.grads[:n].clone()
     assert torch.allclose(g4, 4.0 * g1, rtol=2e-4, atol=1e-7 * float(g1.abs().max()))
+    m.zero_grad()
     _, _, loss = m.run(*batch, eps=eps)
     loss.backward()                                            # and back: the scalar is per call, not sticky
     torch.cuda.synchronize()
     assert torch.allclose(m._engine.ps.grads[:n], g1, rtol=2e-4, atol=1e-7 * float(g1.abs().max()))
+    # no zero_grad(): a further backward ADDS to .grad (nn.Module semantics); a parameter whose .grad was set to None
+    # alone starts from zero
+    first = next(iter(m.parameters()))
+    first.grad = None
+    _, _, loss = m.run(*batch, eps=eps)
+    (loss * 2.0).backward()
+    torch.cuda.synchronize()
+    g3 = m._engine.ps.grads[:n]
+    k = first.numel()
+    o = (m._engine.ps.view(m._pnames[0][0], grad=True).data_ptr() - m._engine.ps.grads.data_ptr()) // 4
+    want = 3.0 * g1
+    want[o:o + k] = 2.0 * g1[o:o + k]
+    assert first.grad is not None and torch.allclose(g3, want, rtol=3e-4, atol=2e-7 * float(g1.abs().max()))
 
 
 @pytest.mark.parametrize("kind", ["vqvae-ema", "vae", "mfcc"])
@@ -142,6 +158,7 @@ def test_adam_state_survives_engine_rebuilds():
     opt = optim.FusedAdam(m, lr=1e-3)
     batch = _batch(m, 2)
     for _ in range(2):
+        opt.zero_grad()
         _, _, loss = m.run(*batch)
         loss.backward()
         opt.step()
