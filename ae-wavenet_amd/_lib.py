@@ -61,7 +61,7 @@ class GemmTNGroup(C.Structure):
 class CopyRec(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("dims", i32 * 4), ("ss", i64 * 4), ("ds", i64 * 4),
                 ("src_dtype", i32), ("dst_dtype", i32), ("red_n", i32), ("accumulate", i32),
-                ("red_stride", i64), ("scale", f32), ("first_block", i32)]
+                ("red_stride", i64), ("scale", f32), ("first_block", i32), ("tr_a", i32), ("tr_b", i32)]
 
 
 class CopyTable(C.Structure):
@@ -276,7 +276,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 14:
+    if lib.aew_abi_version() != 15:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

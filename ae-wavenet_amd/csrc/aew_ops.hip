@@ -7,6 +7,56 @@
 __global__ void k_copy_table(const aew_copy_table_t t) {
     const int rec_i = t.block_rec[blockIdx.x];
     const aew_copy_rec_t r = t.recs[rec_i];
+    if (r.tr_a > 0) {
+        // tiled form: one tr_a x tr_b tile of the (dims[2], dims[3]) plane through LDS - loads run along dims[3] (the
+        // source's contiguous dim), stores along dims[2] (the destination's).  The element-wise forms touch one cache
+        // line per element on one of the two sides of a transposing record (the encoder's dgrad-layout pack ran at
+        // 0.9 TB/s).
+        __shared__ float tile[1600];
+        const int TA = r.tr_a, TB = r.tr_b, pitch = TA | 1;
+        const unsigned na = (unsigned)((r.dims[3] + TA - 1) / TA), nb = (unsigned)((r.dims[2] + TB - 1) / TB);
+        unsigned q = blockIdx.x - (unsigned)r.first_block;
+        const int a0 = (int)(q % na) * TA; q /= na;
+        const int b0 = (int)(q % nb) * TB; q /= nb;
+        const int i1 = (int)(q % (unsigned)r.dims[1]), i0 = (int)(q / (unsigned)r.dims[1]);
+        const float* sp = reinterpret_cast<const float*>(r.src) + i0 * r.ss[0] + i1 * r.ss[1];
+        const int64_t dbase = i0 * r.ds[0] + i1 * r.ds[1];
+        const int n = TA * TB;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int bl = e / TA, al = e - bl * TA;
+            const int a = a0 + al, b = b0 + bl;
+            tile[bl * pitch + al] = (a < r.dims[3] && b < r.dims[2]) ? sp[b * r.ss[2] + a * r.ss[3]] * r.scale : 0.f;
+        }
+        __syncthreads();
+        if (r.dst_dtype == AEW_BF16) {
+            uint16_t* dp = reinterpret_cast<uint16_t*>(r.dst) + dbase;
+            // two consecutive dims[2] positions per thread (one 4-byte store) when every pair is aligned
+            const bool pair = !((TB | r.dims[2]) & 1) && !((r.ds[3] | dbase) & 1) && !((uintptr_t)r.dst & 3);
+            if (pair) {
+                const int hb = TB >> 1;
+                for (int e = threadIdx.x; e < TA * hb; e += 256) {
+                    const int al = e / hb, bl = (e - al * hb) * 2;
+                    const int a = a0 + al, b = b0 + bl;
+                    if (a < r.dims[3] && b < r.dims[2])
+                        *reinterpret_cast<uint32_t*>(dp + b + a * r.ds[3]) = pack2_bf16(tile[bl * pitch + al], tile[(bl + 1) * pitch + al]);
+                }
+            } else {
+                for (int e = threadIdx.x; e < n; e += 256) {
+                    const int al = e / TB, bl = e - al * TB;
+                    const int a = a0 + al, b = b0 + bl;
+                    if (a < r.dims[3] && b < r.dims[2]) dp[b + a * r.ds[3]] = f2bf(tile[bl * pitch + al]);
+                }
+            }
+        } else {
+            float* dp = reinterpret_cast<float*>(r.dst) + dbase;
+            for (int e = threadIdx.x; e < n; e += 256) {
+                const int al = e / TB, bl = e - al * TB;
+                const int a = a0 + al, b = b0 + bl;
+                if (a < r.dims[3] && b < r.dims[2]) dp[b + a * r.ds[3]] = tile[bl * pitch + al];
+            }
+        }
+        return;
+    }
     // vector form: 4 consecutive elements of the last dim per thread when the fp32 source is
     // contiguous there (the gradient-unpack records: float4 loads over every slab)
     // destination-vector form: fp32 -> bf16 pack records whose LAST dim is contiguous in the destination:
@@ -483,56 +533,73 @@ __global__ void k_spk_bias(const aew_spk_bias_t p) {
 }
 
 #define AEW_SPK_MAXB 16
+#define AEW_SPK_MAXG 16
 __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
-    // grid (L, 2): one block per (layer, filt|gate); thread = output channel co.  Everything a thread needs from global
-    // memory is fetched before the (batch x G) loops (they used to re-load the column sums and gc inside: 160 dependent
-    // loads per thread behind LDS atomics the compiler cannot move loads across, 58 us for 40 blocks).
+    // grid (L, 2): one block per (layer, filt|gate); thread = output channel co.
+    //   phase 1: everything a thread needs from global memory is fetched up front (column sums of dfg per batch
+    //            element, its row of the speaker projection); it writes its bias / projection gradients and leaves
+    //            both vectors in LDS;
+    //   phase 2: thread (b, j) sums cs[b][co] * V[co][j] over the channels in ascending order.
+    // (Until round 3 phase 2 was B x G cross-lane reductions per wave with LDS atomics - 80 dependent ds_bpermute
+    // chains, ~45 us for 40 blocks - and its order depended on the atomics.)
     const int l = blockIdx.x, half = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63;
-    extern __shared__ float sh[];                    // [B][G] d(gc) of this (layer, half), then [B][G] gc
-    float* gcs = sh + p.B * p.G;
-    for (int i = tid; i < p.B * p.G; i += blockDim.x) { sh[i] = 0.f; gcs[i] = p.gc[i]; }
-    __syncthreads();
+    const int tid = threadIdx.x;
+    extern __shared__ float sh[];                    // gc [B][G] | cs [B][257] | vs [G][257]
+    float* gcs = sh;
+    float* cs = sh + p.B * p.G;
+    float* vs = cs + p.B * 257;
+    for (int i = tid; i < p.B * p.G; i += blockDim.x) gcs[i] = p.gc[i];
     const int64_t ob = half ? p.off_bias_gate[l] : p.off_bias_sig[l];
     const int64_t ov0 = half ? p.off_proj_gate[l] : p.off_proj_sig[l];
-    for (int co0 = 0; co0 < p.D; co0 += blockDim.x) {
+    const int pb = p.G > 0 ? tid / p.G : p.B, pj = tid - pb * p.G;   // phase 2: this thread's (batch element, embedding column)
+    float dgc = 0.f;
+    __syncthreads();
+    for (int co0 = 0; co0 < p.D; co0 += 256) {
         const int co = co0 + tid;
         const bool ok = co < p.D;
         const int n = (co >> 4) * 32 + (co & 15) + 16 * half;
         const int64_t ov = ov0 + (int64_t)co * (p.C_lc + p.G) + p.C_lc;
         // per-batch column sums of dfg (layers below colsum_running: the buffer holds the sums over batch elements 0..b)
-        float csv[AEW_SPK_MAXB];
+        float csv[AEW_SPK_MAXB], vrow[AEW_SPK_MAXG];
+#pragma unroll
+        for (int b = 0; b < AEW_SPK_MAXB; ++b)
+            csv[b] = (ok && b < p.B) ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < AEW_SPK_MAXG; ++j) vrow[j] = (ok && j < p.G) ? p.params[ov + j] : 0.f;
         float bsum = 0.f, prev = 0.f;
 #pragma unroll
         for (int b = 0; b < AEW_SPK_MAXB; ++b) {
-            float v = (ok && b < p.B) ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
-            const float raw = v;
-            if (l < p.colsum_running && b > 0) v -= prev;
+            const float raw = csv[b];
+            if (l < p.colsum_running && b > 0 && b < p.B) csv[b] -= prev;
             prev = raw;
-            csv[b] = (b < p.B) ? v : 0.f;
             bsum += csv[b];
+            if (b < p.B) cs[b * 257 + tid] = csv[b];
         }
         if (ok && ob >= 0) p.grads[ob + co] = bsum;
-        for (int j = 0; j < p.G; ++j) {
-            const float vj = ok ? p.params[ov + j] : 0.f;
-            float gv = 0.f;
 #pragma unroll
-            for (int b = 0; b < AEW_SPK_MAXB; ++b) {
-                if (b < p.B) {
-                    gv += csv[b] * gcs[b * p.G + j];
-                    const float part = wave_sum(csv[b] * vj);
-                    if (lane == 0) atomicAdd(&sh[b * p.G + j], part);
-                }
+        for (int j = 0; j < AEW_SPK_MAXG; ++j) {
+            if (j < p.G) {
+                vs[j * 257 + tid] = vrow[j];
+                float gv = 0.f;
+#pragma unroll
+                for (int b = 0; b < AEW_SPK_MAXB; ++b)
+                    if (b < p.B) gv += csv[b] * gcs[b * p.G + j];
+                if (ok) p.grads[ov + j] = gv;
             }
-            if (ok) p.grads[ov + j] = gv;
         }
+        __syncthreads();
+        if (pb < p.B) {
+            const float* c = cs + pb * 257;
+            const float* v = vs + pj * 257;
+            const int nco = min(256, p.D - co0);
+            for (int k = 0; k < nco; ++k) dgc += c[k] * v[k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // speaker embedding grads accumulate over layers -> global atomics (caller zeroes them)
-    for (int i = tid; i < p.B * p.G; i += blockDim.x) {
-        const int b = i / p.G, j = i % p.G;
-        atomicAdd(p.grads + p.off_spk_w + (int64_t)j * p.n_speakers + p.voice[b], sh[i]);
-        if (p.off_spk_b >= 0) atomicAdd(p.grads + p.off_spk_b + j, sh[i]);
+    if (pb < p.B) {
+        atomicAdd(p.grads + p.off_spk_w + (int64_t)pj * p.n_speakers + p.voice[pb], dgc);
+        if (p.off_spk_b >= 0) atomicAdd(p.grads + p.off_spk_b + pj, dgc);
     }
 }
 
@@ -790,9 +857,17 @@ __global__ __launch_bounds__(1024) void k_moments(const aew_moments_t p) {
     __shared__ double sh[2][1024];
     const int64_t per_b = (int64_t)p.rows * p.cols, n = per_b * p.batch;
     double s = 0.0, q = 0.0;
-    for (int64_t e = threadIdx.x; e < n; e += 1024) {
-        const int b = (int)(e / per_b);
-        const int r = (int)((e - b * per_b) / p.cols), c = (int)(e - b * per_b - (int64_t)r * p.cols);
+    const bool small = n < ((int64_t)1 << 31);               // 32-bit index arithmetic (two 64-bit divisions per element
+    for (int64_t e = threadIdx.x; e < n; e += 1024) {        // were most of what this single block executed)
+        int b, r, c;
+        if (small) {
+            const unsigned e32 = (unsigned)e, pb = (unsigned)per_b, cols = (unsigned)p.cols;
+            const unsigned bq = e32 / pb, rem = e32 - bq * pb, rq = rem / cols;
+            b = (int)bq; r = (int)rq; c = (int)(rem - rq * cols);
+        } else {
+            b = (int)(e / per_b);
+            r = (int)((e - b * per_b) / p.cols); c = (int)(e - b * per_b - (int64_t)r * p.cols);
+        }
         const int row = r * p.x.row_step + p.x.row_off;
         if (row < p.x.row_lo || row >= p.x.row_hi) continue;                    // rows outside the view read as zero
         const int64_t off = b * p.x.batch_stride + (int64_t)row * p.x.row_pitch + c;
@@ -1041,6 +1116,30 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
     auto norms = [&](const float* base, int rows, int pitch, float& lo, float& hi) {
         lo = INFINITY; hi = -INFINITY;
         const int part = tid & 7;
+        if (p.d == 64 && (pitch & 3) == 0) {
+            // the codebook's shape: NR rows per thread and pass, their 2 NR loads in flight together (one row per pass
+            // left this single block waiting for a memory round trip 32 times for 4096 codes)
+            constexpr int NR = 8;
+            for (int r0 = 0; r0 < rows; r0 += 128 * NR) {
+                float4 v[NR][2];
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int r = r0 + u * 128 + (tid >> 3);
+                    const float* x = base + (int64_t)min(r, rows - 1) * pitch + part * 4;
+                    v[u][0] = *reinterpret_cast<const float4*>(x);
+                    v[u][1] = *reinterpret_cast<const float4*>(x + 32);
+                }
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int r = r0 + u * 128 + (tid >> 3);
+                    float ss = v[u][0].x * v[u][0].x + v[u][0].y * v[u][0].y + v[u][0].z * v[u][0].z + v[u][0].w * v[u][0].w;
+                    ss += v[u][1].x * v[u][1].x + v[u][1].y * v[u][1].y + v[u][1].z * v[u][1].z + v[u][1].w * v[u][1].w;
+                    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                    if (r < rows) { const float nr = sqrtf(ss); lo = fminf(lo, nr); hi = fmaxf(hi, nr); }
+                }
+            }
+            return;
+        }
         for (int r0 = 0; r0 < rows; r0 += 128) {
             const int r = r0 + (tid >> 3);
             float ss = 0.f;
@@ -1059,6 +1158,18 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
             if (r < rows) { const float nr = sqrtf(ss); lo = fminf(lo, nr); hi = fmaxf(hi, nr); }
         }
     };
+    // code counts: in registers before anything else (<= 4 per thread), so that their memory round trips run under the
+    // norm passes instead of after them
+    const bool pre = p.K <= 4096;
+    float hv[4] = {0.f, 0.f, 0.f, 0.f}, nv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = tid + 1024 * u;
+            if (p.hist && k < p.K) hv[u] = p.hist[k];
+            if (p.n_sum && k < p.K) nv[u] = p.n_sum[k];
+        }
+    }
     if (p.ze) {
         float lo, hi;
         norms(p.ze, p.Q, p.d_pitch, lo, hi);
@@ -1071,18 +1182,27 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
     }
     if (p.hist) {                                             // -sum n log2 n, n = hist / sum(hist); 0 log 0 = 0
         double s = 0.0;
-        for (int k = tid; k < p.K; k += 1024) s += (double)p.hist[k];
+        if (pre) { for (int u = 0; u < 4; ++u) s += (double)hv[u]; }          // k = tid, tid + 1024, ...: the same order
+        else for (int k = tid; k < p.K; k += 1024) s += (double)p.hist[k];
         const double tot = block_sum(s, shd);
         double e = 0.0;
-        for (int k = tid; k < p.K; k += 1024) {
-            const float n = (float)((double)p.hist[k] / tot);
-            if (n > 0.f) e -= (double)(n * log2f(n));
+        if (pre) {
+            for (int u = 0; u < 4; ++u) {
+                const float n = (float)((double)hv[u] / tot);
+                if (n > 0.f) e -= (double)(n * log2f(n));
+            }
+        } else {
+            for (int k = tid; k < p.K; k += 1024) {
+                const float n = (float)((double)p.hist[k] / tot);
+                if (n > 0.f) e -= (double)(n * log2f(n));
+            }
         }
         o[4] = (float)block_sum(e, shd);
     }
     if (p.n_sum) {
         double c = 0.0;
-        for (int k = tid; k < p.K; k += 1024) c += p.n_sum[k] > 0.f ? 1.0 : 0.0;
+        if (pre) { for (int u = 0; u < 4; ++u) c += nv[u] > 0.f ? 1.0 : 0.0; }
+        else for (int k = tid; k < p.K; k += 1024) c += p.n_sum[k] > 0.f ? 1.0 : 0.0;
         o[5] = (float)block_sum(c, shd);
     }
     if (p.peak && p.amax) {                                   // per-position arrays written by the softmax kernel
@@ -1091,11 +1211,34 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
         __syncthreads();
         double s1 = 0.0, s2 = 0.0;
         const int64_t n_all = (int64_t)p.B * p.w;
-        for (int64_t i = tid; i < n_all; i += 1024) {
-            if ((int)(i % p.w) == p.w - 1) continue;
-            const double pk = (double)p.peak[i];
-            s1 += pk; s2 += pk * pk;
-            seen[p.amax[i] & 255] = 1;
+        if (n_all < (int64_t)1 << 31) {
+            // four positions per thread and pass (loads first), 32-bit index arithmetic; thread t still adds positions
+            // t, t + 1024, ... in that order
+            const unsigned n32 = (unsigned)n_all, w32 = (unsigned)p.w;
+            for (unsigned i0 = tid; i0 < n32; i0 += 4096) {
+                float pk[4];
+                int am[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned i = min(i0 + 1024u * u, n32 - 1);
+                    pk[u] = p.peak[i]; am[u] = p.amax[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned i = i0 + 1024u * u;
+                    if (i >= n32 || i % w32 == w32 - 1) continue;
+                    const double v = (double)pk[u];
+                    s1 += v; s2 += v * v;
+                    seen[am[u] & 255] = 1;
+                }
+            }
+        } else {
+            for (int64_t i = tid; i < n_all; i += 1024) {
+                if ((int)(i % p.w) == p.w - 1) continue;
+                const double pk = (double)p.peak[i];
+                s1 += pk; s2 += pk * pk;
+                seen[p.amax[i] & 255] = 1;
+            }
         }
         const double t1 = block_sum(s1, shd), t2 = block_sum(s2, shd);
         const double n = (double)p.B * (p.w - 1);
@@ -1276,8 +1419,8 @@ static int launch_spk_bias(const aew_spk_bias_t& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
-    if (p.B > AEW_SPK_MAXB) return AEW_E_UNSUP;
-    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2), dim3(256), 2 * p.B * p.G * sizeof(float), st, p);
+    if (p.B > AEW_SPK_MAXB || p.G > AEW_SPK_MAXG) return AEW_E_UNSUP;
+    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2), dim3(256), (p.B * p.G + (p.B + p.G) * 257) * sizeof(float), st, p);
     return (int)hipGetLastError();
 }
 static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {

@@ -330,6 +330,17 @@ class CopyTableBuilder:
         dims, ss, ds = list(dims), list(ss), list(ds)
         while len(dims) < 4:
             dims.insert(0, 1); ss.insert(0, 0); ds.insert(0, 0)
+        tiled = self._tiled_form(dims, ss, ds, src_dtype, dst_dtype, red_n, accumulate) if self.tiled else None
+        if tiled is not None:
+            dims, ss, ds, tr_a, tr_b = tiled
+            r = L.CopyRec()
+            r.src, r.dst = src_ptr, dst_ptr
+            for i in range(4):
+                r.dims[i], r.ss[i], r.ds[i] = dims[i], ss[i], ds[i]
+            r.src_dtype, r.dst_dtype, r.red_n, r.red_stride = src_dtype, dst_dtype, 1, 0
+            r.accumulate, r.scale, r.tr_a, r.tr_b = 0, scale, tr_a, tr_b
+            self.recs.append(r)
+            return
         # thread index runs fastest over the LAST dim: order dims so that it is the one with the
         # smallest source stride (coalesced reads; the read side carries the slab reduction)
         order = sorted(range(4), key=lambda i: (0, 0) if dims[i] == 1 else (1, -abs(ss[i])))
@@ -354,6 +365,60 @@ class CopyTableBuilder:
         r.accumulate, r.scale = int(accumulate), scale
         self.recs.append(r)
 
+    tiled = True              # transposing records go through LDS tiles (False: element-wise forms only; A/B)
+
+    @staticmethod
+    def _tiled_form(dims, ss, ds, src_dtype, dst_dtype, red_n, accumulate):
+        """A record that is contiguous along one dim in the source and along ANOTHER in the destination (transposing
+        weight packs, tap <-> channel permutations) -> (dims, ss, ds, tr_a, tr_b) with dims[3] the source-side and
+        dims[2] the destination-side dim and the tile the kernel moves through LDS, or None when the element-wise
+        forms already run along both (k_copy_table)."""
+        if src_dtype != L.F32 or dst_dtype not in (L.F32, L.BF16) or red_n != 1 or accumulate:
+            return None
+        dims, ss, ds = list(dims), list(ss), list(ds)
+        # merge dims that are nested the same way on both sides ((c, tap) of a conv weight is one run of c * k elements)
+        merged = True
+        while merged:
+            merged = False
+            for i in range(4):
+                for j in range(4):
+                    if i != j and dims[i] > 1 and dims[j] > 1 and ss[i] == ss[j] * dims[j] and ds[i] == ds[j] * dims[j]:
+                        dims[j] *= dims[i]
+                        dims[i], ss[i], ds[i] = 1, 0, 0
+                        merged = True
+        live = [i for i in range(4) if dims[i] > 1]
+        bs = [i for i in live if ds[i] == 1]
+        if not bs:
+            return None
+        b = bs[0]
+        rest = [i for i in live if i != b]
+        if not rest:
+            return None
+        a = min(rest, key=lambda i: abs(ss[i]))
+        # the element-wise forms run along ONE side (8 loads at stride ss[b] per 16-byte store, or one 16-byte load per 4
+        # stores at stride ds[a]); a short stride on either side is as good as sequential there
+        if not (0 < ss[a] <= 2) or ss[b] <= 8 or ds[a] <= 8:
+            return None
+        A, B = dims[a], dims[b]
+        ta = A if A <= 8 else (16 if A <= 16 else 32)
+        cap = 1 << ((1024 // ta).bit_length() - 1)                 # power of two <= 1024 / ta
+        if B < 32:
+            return None                                            # (16-wide runs: measured slower than the 16-byte-store form)
+        else:
+            best = None
+            for tb_c in (cap, cap // 2, cap // 4):
+                if tb_c < 16:
+                    continue
+                util = B / (-(-B // tb_c) * tb_c)
+                if best is None or util > best[0] + 0.05:         # smaller tiles only for a real gain in coverage
+                    best = (util, tb_c)
+            tb = best[1]
+        assert ta * tb <= 1024 and tb * (ta | 1) <= 1600
+        outer = [i for i in range(4) if i not in (a, b)]
+        outer.sort(key=lambda i: dims[i] > 1)                      # size-1 dims first
+        order = outer + [b, a]
+        return [dims[i] for i in order], [ss[i] for i in order], [ds[i] for i in order], ta, tb
+
     def emit(self, plan: Plan, label: str, join: bool = False):
         if not self.recs:
             return
@@ -361,6 +426,9 @@ class CopyTableBuilder:
         for i, r in enumerate(self.recs):
             n = r.dims[0] * r.dims[1] * r.dims[2] * r.dims[3]
             r.first_block = len(block_rec)
+            if r.tr_a > 0:
+                block_rec.extend([i] * (r.dims[0] * r.dims[1] * (-(-r.dims[2] // r.tr_b)) * (-(-r.dims[3] // r.tr_a))))
+                continue
             block_rec.extend([i] * ((n + 1023) // 1024))
         raw = bytes((L.CopyRec * len(self.recs))(*self.recs))
         rec_t = self.ws.alloc(f"{self.name}.recs", (len(raw) + 7) // 8, torch.int64, zero=True)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 14
+#define AEW_ABI_VERSION 15
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -197,6 +197,10 @@ typedef struct {
 /* ---------------------------------------------------------------------------------------
  * table-driven strided copy / convert / reduce (weight pack, gradient unpack, NCL<->NLC)
  *   dst[sum_d i_d*ds_d] = cvt( sum_{r<red_n} src[sum_d i_d*ss_d + r*red_stride] )
+ * Tiled form (tr_a > 0; red_n = 1, no accumulate, f32 source): dims[3] is the dim the SOURCE is (nearly) contiguous in,
+ * dims[2] the one the DESTINATION is contiguous in (ds[2] = 1); a block moves one tr_a x tr_b tile of that plane through
+ * LDS, reading along dims[3] and writing along dims[2] (transposing weight packs: both sides coalesced).  Same result
+ * as the element-wise forms.  Blocks per record: dims[0] * dims[1] * ceil(dims[2] / tr_b) * ceil(dims[3] / tr_a).
  * ------------------------------------------------------------------------------------- */
 typedef struct {
     const void* src;
@@ -208,7 +212,10 @@ typedef struct {
     int32_t accumulate;          /* dst += (f32 dst only) */
     int64_t red_stride;
     float scale;
-    int32_t first_block;         /* filled by the host: first 1024-element block of this record */
+    int32_t first_block;         /* filled by the host: first block of this record (1024 elements per block, or one
+                                    tile in the tiled form)                                                       */
+    int32_t tr_a, tr_b;          /* tiled form: tile extents along dims[3] / dims[2]; tr_a * tr_b <= 1024,
+                                    tr_b * (tr_a | 1) <= 1600; 0 = element-wise forms                             */
 } aew_copy_rec_t;
 
 typedef struct {
@@ -291,7 +298,8 @@ typedef struct {                 /* per-(batch,layer) gated bias incl. speaker t
     float* gc;                   /* [B][G] saved for backward                                 */
 } aew_spk_bias_t;
 
-typedef struct {                 /* backward of the above from per-batch column sums of dfg   */
+typedef struct {                 /* backward of the above from per-batch column sums of dfg; B <= 16, G <= 16
+                                    (AEW_E_UNSUP beyond: the kernel holds both in registers)  */
     const float* params; const int64_t* voice;
     const int64_t* off_bias_sig; const int64_t* off_bias_gate;
     const int64_t* off_proj_sig; const int64_t* off_proj_gate;

@@ -451,6 +451,52 @@ def test_gemm_tn_big_tiles(Np, ks):
         assert err <= 2e-3 * scale, (tag, err, scale)
 
 
+@pytest.mark.parametrize("tiled", [True, False])
+def test_copy_table_transposing_records(tiled):
+    """AEW_OP_COPY_TABLE on the record shapes of the weight packs (conv weight [o][c][k] -> dgrad layout [(c, k)][o],
+    gate-permuted groups, a k = 1 transpose into a wider matrix, ragged extents, fp32 and bf16 destinations, a scale),
+    tiled through LDS and element-wise: both bit-identical to the interpreter's definition of the op."""
+    gen = torch.Generator().manual_seed(11)
+    ws_c = Workspace("cpu")
+    ws_c.alloc("src", 768 * 2304 + 64, torch.float32); _fill(ws_c, "src", gen)
+    for n, sz, dt in (("d_bf", 2304 * 768 + 64, torch.bfloat16), ("d_f", 2304 * 768 + 64, torch.float32), ("d_g", 16 * 1024 * 40, torch.bfloat16),
+                      ("d_r", 117 * 768 + 64, torch.bfloat16), ("d_o", 130 * 77 + 64, torch.bfloat16), ("d_w", 368 * 640 + 64, torch.bfloat16),
+                      ("d_e", 64 * 2304, torch.float32)):
+        ws_c.alloc(n, sz, dt)
+    cases = [  # name, dims, source strides, destination strides, destination type, scale, expected to be tiled
+        ("d_bf", (768, 768, 3), (2304, 3, 1), (1, 2304, 768), BF, 1.0, True),        # encoder conv -> [c][k][o]
+        ("d_f", (768, 768, 3), (2304, 3, 1), (1, 2304, 768), F3, 0.5, True),
+        ("d_g", (16, 368, 2, 16), (11776, 2, 1, 736), (32, 1024, 512, 1), BF, 1.0, False),  # gate-permuted: 16-wide runs, element-wise
+        ("d_r", (768, 39, 3), (117, 3, 1), (1, 2304, 768), BF, 1.0, True),           # 117 = 3.66 tiles of 32
+        ("d_o", (77, 130), (130, 1), (1, 77), BF, 1.0, True),                        # odd extents: 2-byte stores
+        ("d_w", (368, 256), (256, 1), (1, 640), BF, 1.0, True),                      # k = 1 transpose into a wider matrix
+        ("d_e", (64, 768, 3), (2304, 3, 1), (2304, 1, 768), F3, 1.0, False)]         # tap <-> channel: element-wise form
+
+    def build(ws):
+        keep, PL.CopyTableBuilder.tiled = PL.CopyTableBuilder.tiled, tiled
+        try:
+            tb = PL.CopyTableBuilder(ws, "t.tbl")
+            for name, dims, ss, ds, dt, scale, _ in cases:
+                tb.add(ws.get("src").data_ptr() + 4 * 8, ws.get(name).data_ptr(), dims, ss, ds, F3, dt, scale=scale)
+        finally:
+            PL.CopyTableBuilder.tiled = keep
+        assert [r.tr_a > 0 for r in tb.recs] == [c[-1] and tiled for c in cases]
+        p = Plan("t")
+        tb.emit(p, "copy")
+        return p
+    ws_g = _mirror(ws_c, DEV)
+    build(ws_g).run(stream())
+    torch.cuda.synchronize()
+    ws_e = Workspace("cpu")
+    for n, t in ws_c.bufs.items():
+        ws_e.bufs[n] = t.clone()
+    Emu(ws_e).run(build(ws_e))
+    for name in ("d_bf", "d_g", "d_r", "d_o", "d_w"):
+        assert torch.equal(ws_g.get(name).cpu().view(torch.int16), ws_e.get(name).view(torch.int16)), name
+    for name in ("d_f", "d_e"):
+        assert torch.equal(ws_g.get(name).cpu(), ws_e.get(name)), name
+
+
 @pytest.mark.parametrize("dtype", [BF, F3])
 def test_moments_and_vq_stats_ops(dtype):
     """The two small reductions added in round 2 against the plan interpreter: AEW_OP_MOMENTS over a strided view with

@@ -264,3 +264,33 @@ def test_adam_plan(mode):
         a.lr, a.bc1, a.bc2 = 3e-4, 1 - 0.9 ** eng.step_count, 1 - 0.999 ** eng.step_count
         Emu(eng.ws).run(eng.opt)
         np.testing.assert_allclose(eng.ps.params[:n].numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_copy_table_tiled_form_addresses_the_same_elements():
+    """CopyTableBuilder._tiled_form reorders / merges the dims of a transposing record; the (source, destination) offset
+    pairs it describes must be exactly those of the record as given, the tile must fit the kernel's LDS buffer, and the
+    records the element-wise forms already handle sequentially must be left alone."""
+    import itertools
+    from ae_wavenet_amd import _lib as L
+    from ae_wavenet_amd.plan import CopyTableBuilder
+
+    def pairs(dims, ss, ds):
+        out = set()
+        for idx in itertools.product(*[range(d) for d in dims]):
+            out.add((sum(i * s for i, s in zip(idx, ss)), sum(i * s for i, s in zip(idx, ds))))
+        return out
+    cases = [((1, 48, 40, 3), (0, 120, 3, 1), (0, 1, 144, 48)),          # [o][c][k] -> [(c, k)][o]
+             ((1, 1, 37, 50), (0, 0, 50, 1), (0, 0, 1, 37)),              # ragged transpose
+             ((1, 1, 48, 32), (0, 0, 64, 2), (0, 0, 1, 48))]              # source stride 2 (every other tap)
+    for dims, ss, ds in cases:
+        got = CopyTableBuilder._tiled_form(list(dims), list(ss), list(ds), L.F32, L.BF16, 1, False)
+        assert got is not None, (dims, ss, ds)
+        d2, s2, t2, ta, tb = got
+        assert pairs(d2, s2, t2) == pairs(dims, ss, ds)
+        assert t2[2] == 1 and 0 < s2[3] <= 2 and ta * tb <= 1024 and tb * (ta | 1) <= 1600
+    for dims, ss, ds in [((1, 8, 40, 3), (0, 120, 3, 1), (0, 120, 1, 40)),   # tap <-> channel inside a row
+                         ((1, 8, 3, 40), (0, 120, 40, 1), (0, 120, 1, 3)),   # ... and back
+                         ((4, 23, 2, 16), (736, 2, 1, 46), (32, 128, 64, 1)),   # gate-permuted groups: 16-wide runs stay element-wise
+                         ((1, 1, 16, 64), (0, 0, 64, 1), (0, 0, 64, 1))]:    # plain copy
+        assert CopyTableBuilder._tiled_form(list(dims), list(ss), list(ds), L.F32, L.F32, 1, False) is None
+    assert CopyTableBuilder._tiled_form([1, 1, 64, 64], [0, 0, 64, 1], [0, 0, 1, 64], L.F32, L.F32, 4, False) is None   # slab sums

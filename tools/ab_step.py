@@ -52,11 +52,15 @@ def main():
 
     engines = {}
 
+    def owner(k):                                  # E.tiled: the copy-table builder's switch; everything else DecoderPlan's
+        from ae_wavenet_amd import plan as PLN
+        return PLN.CopyTableBuilder if k == "tiled" else E.DecoderPlan
+
     def engine_for(ekey):
         if ekey not in engines:
             for k, v in ekey:
-                e_defaults.setdefault(k, getattr(E.DecoderPlan, k))
-                setattr(E.DecoderPlan, k, v)
+                e_defaults.setdefault(k, getattr(owner(k), k))
+                setattr(owner(k), k, v)
             torch.manual_seed(2507)
             model = ae.AutoEncoder(hps, n_mel=39).to(dev)
             eng = model._ensure_engine(args.batch)
