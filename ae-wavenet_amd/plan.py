@@ -395,24 +395,34 @@ class CopyTableBuilder:
         if not rest:
             return None
         a = min(rest, key=lambda i: abs(ss[i]))
-        # the element-wise forms run along ONE side (8 loads at stride ss[b] per 16-byte store, or one 16-byte load per 4
-        # stores at stride ds[a]); a short stride on either side is as good as sequential there
-        if not (0 < ss[a] <= 2) or ss[b] <= 8 or ds[a] <= 8:
-            return None
         A, B = dims[a], dims[b]
-        ta = A if A <= 8 else (16 if A <= 16 else 32)
-        cap = 1 << ((1024 // ta).bit_length() - 1)                 # power of two <= 1024 / ta
-        if B < 32:
-            return None                                            # (16-wide runs: measured slower than the 16-byte-store form)
-        else:
+        if not (0 < ss[a] <= 2):
+            return None
+
+        def fit(extent, cap):
+            """Tile extent (a power of two <= cap, >= 16) along a dim: the largest unless a smaller one covers the dim
+            with >= 5 % less padding."""
             best = None
-            for tb_c in (cap, cap // 2, cap // 4):
-                if tb_c < 16:
+            for t in (cap, cap // 2, cap // 4):
+                if t < 16:
                     continue
-                util = B / (-(-B // tb_c) * tb_c)
-                if best is None or util > best[0] + 0.05:         # smaller tiles only for a real gain in coverage
-                    best = (util, tb_c)
-            tb = best[1]
+                util = extent / (-(-extent // t) * t)
+                if best is None or util > best[0] + 0.05:
+                    best = (util, t)
+            return best[1]
+
+        def pow2_le(n):
+            return 1 << (n.bit_length() - 1)
+        if ss[b] > 8 and ds[a] > 8 and B >= 32:
+            # a transpose proper: the element-wise forms run along ONE side (8 loads at stride ss[b] per 16-byte store, or
+            # one 16-byte load per 4 stores at stride ds[a]) and touch a cache line per element on the other.  Measured
+            # slower tiled and left element-wise: B < 32 (the gate-permuted 16-wide runs: decoder pack 52 -> 67 us) and
+            # the tap <-> channel (de)interleaves inside a row, whose short strides the element-wise forms already
+            # cover (k x 256 tiles: decoder pack / unpack 59 -> 85 / 49 -> 76 us).
+            ta = A if A <= 8 else (16 if A <= 16 else 32)
+            tb = fit(B, pow2_le(1024 // ta))
+        else:
+            return None
         assert ta * tb <= 1024 and tb * (ta | 1) <= 1600
         outer = [i for i in range(4) if i not in (a, b)]
         outer.sort(key=lambda i: dims[i] > 1)                      # size-1 dims first

@@ -461,7 +461,8 @@ def test_copy_table_transposing_records(tiled):
     ws_c.alloc("src", 768 * 2304 + 64, torch.float32); _fill(ws_c, "src", gen)
     for n, sz, dt in (("d_bf", 2304 * 768 + 64, torch.bfloat16), ("d_f", 2304 * 768 + 64, torch.float32), ("d_g", 16 * 1024 * 40, torch.bfloat16),
                       ("d_r", 117 * 768 + 64, torch.bfloat16), ("d_o", 130 * 77 + 64, torch.bfloat16), ("d_w", 368 * 640 + 64, torch.bfloat16),
-                      ("d_e", 64 * 2304, torch.float32)):
+                      ("d_e", 64 * 2304, torch.float32), ("d_i", 64 * 2304, torch.float32), ("d_t", 16 * 736, torch.float32),
+                      ("d_s", 64 * 120, torch.float32)):
         ws_c.alloc(n, sz, dt)
     cases = [  # name, dims, source strides, destination strides, destination type, scale, expected to be tiled
         ("d_bf", (768, 768, 3), (2304, 3, 1), (1, 2304, 768), BF, 1.0, True),        # encoder conv -> [c][k][o]
@@ -470,7 +471,10 @@ def test_copy_table_transposing_records(tiled):
         ("d_r", (768, 39, 3), (117, 3, 1), (1, 2304, 768), BF, 1.0, True),           # 117 = 3.66 tiles of 32
         ("d_o", (77, 130), (130, 1), (1, 77), BF, 1.0, True),                        # odd extents: 2-byte stores
         ("d_w", (368, 256), (256, 1), (1, 640), BF, 1.0, True),                      # k = 1 transpose into a wider matrix
-        ("d_e", (64, 768, 3), (2304, 3, 1), (2304, 1, 768), F3, 1.0, False)]         # tap <-> channel: element-wise form
+        ("d_e", (64, 768, 3), (2304, 3, 1), (2304, 1, 768), F3, 1.0, False),         # [c][k] -> [k][c] inside a row: element-wise
+        ("d_i", (64, 3, 768), (2304, 768, 1), (2304, 1, 3), F3, 1.0, False),         # ... and back (gradient unpack)
+        ("d_t", (16, 2, 368), (896, 384, 1), (736, 1, 2), F3, 1.0, False),           # two taps
+        ("d_s", (64, 40, 3), (120, 3, 1), (120, 1, 40), F3, 1.0, False)]             # short rows: element-wise form
 
     def build(ws):
         keep, PL.CopyTableBuilder.tiled = PL.CopyTableBuilder.tiled, tiled
@@ -493,7 +497,7 @@ def test_copy_table_transposing_records(tiled):
     Emu(ws_e).run(build(ws_e))
     for name in ("d_bf", "d_g", "d_r", "d_o", "d_w"):
         assert torch.equal(ws_g.get(name).cpu().view(torch.int16), ws_e.get(name).view(torch.int16)), name
-    for name in ("d_f", "d_e"):
+    for name in ("d_f", "d_e", "d_i", "d_t", "d_s"):
         assert torch.equal(ws_g.get(name).cpu(), ws_e.get(name)), name
 
 

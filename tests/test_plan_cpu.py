@@ -288,8 +288,8 @@ def test_copy_table_tiled_form_addresses_the_same_elements():
         d2, s2, t2, ta, tb = got
         assert pairs(d2, s2, t2) == pairs(dims, ss, ds)
         assert t2[2] == 1 and 0 < s2[3] <= 2 and ta * tb <= 1024 and tb * (ta | 1) <= 1600
-    for dims, ss, ds in [((1, 8, 40, 3), (0, 120, 3, 1), (0, 120, 1, 40)),   # tap <-> channel inside a row
-                         ((1, 8, 3, 40), (0, 120, 40, 1), (0, 120, 1, 3)),   # ... and back
+    for dims, ss, ds in [((1, 8, 100, 3), (0, 300, 3, 1), (0, 300, 1, 100)),   # tap <-> channel inside a row
+                         ((1, 8, 3, 100), (0, 300, 100, 1), (0, 300, 1, 3)),   # ... and back
                          ((4, 23, 2, 16), (736, 2, 1, 46), (32, 128, 64, 1)),   # gate-permuted groups: 16-wide runs stay element-wise
                          ((1, 1, 16, 64), (0, 0, 64, 1), (0, 0, 64, 1))]:    # plain copy
         assert CopyTableBuilder._tiled_form(list(dims), list(ss), list(ds), L.F32, L.F32, 1, False) is None
