@@ -32,10 +32,12 @@
 #define FN_NLOAD 4
 #define FN_THREADS ((FN_NCONS + FN_NLOAD) * 64)
 
-template <int NTW>
+template <int NTW, int MTCAP = 0>
 struct FnCfg {
     static constexpr int BN = 128 * NTW;                       // 8 consumer waves x NTW MFMA tiles x 16 channels
-    static constexpr int MTMAX = NTW >= 4 ? 6 : (NTW == 3 ? 8 : (NTW == 2 ? 12 : 16));   // 96 accumulator VGPRs
+    static constexpr int MTFULL = NTW >= 4 ? 6 : (NTW == 3 ? 8 : (NTW == 2 ? 12 : 16));   // 96 accumulator VGPRs
+    static constexpr int MTMAX = MTCAP > 0 ? MTCAP : MTFULL;   // (MTCAP: shorter tiles so that a three-stage ring fits)
+    static_assert(MTMAX <= MTFULL, "accumulator budget");
     static constexpr int RMAX = 16 * MTMAX;
     static constexpr int XOFF = 0, WOFF = RMAX * 128;
     static constexpr int STAGE = (RMAX + BN) * 128;            // bytes: X rows, then W rows (128 B each)
@@ -109,9 +111,9 @@ __device__ __forceinline__ void fn_barrier() {
 // ---------------------------------------------------------------------------------------------------------------
 // loader side
 // ---------------------------------------------------------------------------------------------------------------
-template <int NTW>
+template <int NTW, int MTCAP = 0>
 struct FnLoader {
-    typedef FnCfg<NTW> Cfg;
+    typedef FnCfg<NTW, MTCAP> Cfg;
     const char* xp[Cfg::XPL];      // per-lane source of this loader's X pieces (piece q = ld + 4*jj), current segment
     uint32_t voff_perm, voff_plain;
     int ld, lane;
@@ -137,8 +139,10 @@ struct FnLoader {
         tile = t; seg = 0; kin = 0; kt = 0;
         setup_x(g);
     }
-    // issue K tile `kt` of `tile` into the stage at byte offset `stage`
-    template <int EPI>
+    // issue K tile `kt` of `tile` into the stage at byte offset `stage`.  ALLX: every X piece goes out (pieces beyond
+    // the tile's rows stream zeros into rows nobody reads), so that a loader issues the same number of DMA
+    // instructions per K tile whatever the tile - what a counted vmcnt wait needs.
+    template <int EPI, bool ALLX = false>
     __device__ __forceinline__ void issue(const aew_gemm_nt_t& g, uint32_t stage) {
         if (FN_ABL(g, 2)) {                                    // (ablation: no operand traffic)
             ++kt; kin += 64;
@@ -148,7 +152,7 @@ struct FnLoader {
 #pragma unroll
         for (int jj = 0; jj < Cfg::XPL; ++jj) {
             const int q = ld + FN_NLOAD * jj;
-            if (q < 2 * tile.mt) fn_dma_v(xp[jj], lds0 + stage + Cfg::XOFF + q * 1024);
+            if (ALLX || q < 2 * tile.mt) fn_dma_v(xp[jj], lds0 + stage + Cfg::XOFF + q * 1024);
             xp[jj] += 128;
         }
         const uint64_t wk = reinterpret_cast<uint64_t>(g.W) + (uint64_t)kt * 128;
@@ -460,16 +464,16 @@ struct FnFuse {                                                // LDS overlay of
     static_assert(NTW2 == 0 || W2S <= Cfg::STAGE, "W2 stage A must fit inside operand stage 0");
 };
 
-template <int NTW, int EPI, int NTW2>
+template <int NTW, int EPI, int NTW2, int NST = 2, int MTCAP = 0>
 constexpr int fn_lds_bytes() {
     return (NTW2 > 0 && FnFuse<NTW, NTW2 ? NTW2 : 1>::BYTES > 2 * FnCfg<NTW>::STAGE) ? FnFuse<NTW, NTW2 ? NTW2 : 1>::BYTES
-                                                                                        : 2 * FnCfg<NTW>::STAGE;
+                                                                                        : NST * FnCfg<NTW, MTCAP>::STAGE;
 }
 
-template <int NTW, int MT, int EPI, int NTW2>
+template <int NTW, int MT, int EPI, int NTW2, int NST = 2, int MTCAP = 0>
 __device__ __forceinline__ void fn_consumer_tile(const aew_gemm_nt_t& g, char* smem, const FnTile& t, int wn, int lane,
                                                  int nkt, int& ktg) {
-    typedef FnCfg<NTW> Cfg;
+    typedef FnCfg<NTW, MTCAP> Cfg;
     const int fi = lane & 15, fg = lane >> 4;
     const int xo = fi * 128 + ((fg ^ ((fi >> 1) & 7)) << 4);
     f32x4_t acc[NTW][MT];
@@ -479,11 +483,12 @@ __device__ __forceinline__ void fn_consumer_tile(const aew_gemm_nt_t& g, char* s
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < nkt; ++k) {
         fn_barrier();                                          // A_k: tile k landed; my reads of tile k-1 are consumed
-        const char* st = smem + ((ktg + k) & 1) * Cfg::STAGE;
+        // (NST = 3: ktg is the ring slot of this tile's first K tile, kept in [0, 3))
+        const char* st = smem + (NST == 2 ? ((ktg + k) & 1) : ((ktg + k) % NST)) * Cfg::STAGE;
         if (!FN_ABL(g, 1))                                     // (ablation: barriers only)
             fn_compute<NTW, MT>(st + Cfg::XOFF, st + Cfg::WOFF + wn * NTW * 2048, xo, acc);
     }
-    ktg += nkt;
+    ktg = NST == 2 ? ktg + nkt : (ktg + nkt) % NST;
     if constexpr (NTW2 == 0) {
         if (FN_ABL(g, 4)) return;                              // (ablation: no epilogue)
         if constexpr (EPI == AEW_EPI_GATED) fn_epilogue_gated<NTW, MT, false>(g, acc, t, wn, lane, nullptr, 0);
@@ -510,9 +515,17 @@ __device__ __forceinline__ void fn_consumer_tile(const aew_gemm_nt_t& g, char* s
     }
 }
 
-template <int NTW, int EPI, int NTW2>
+template <int N>
+__device__ __forceinline__ void fn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// NST = 3 (plain GEMMs only, NTW2 = 0): a three-stage operand ring, the loaders TWO K tiles ahead of the consumers with
+// a counted vmcnt wait.  One block per CU fills its LDS at the rate of (bytes in flight) / (DMA latency): with one K tile
+// of 50-56 KB in flight the long-K multi-segment GEMMs (skip sum K = 5120, cond gradient K = 10240: one tile per block,
+// 80-160 K tiles) ran at 27 GB/s per CU.  MTCAP shortens the tiles so that three stages fit in 160 KB.
+template <int NTW, int EPI, int NTW2, int NST = 2, int MTCAP = 0>
 __global__ __launch_bounds__(FN_THREADS, 3) void k_fn(const aew_gemm_nt_t g) {
-    typedef FnCfg<NTW> Cfg;
+    typedef FnCfg<NTW, MTCAP> Cfg;
+    static_assert(NST == 2 || (NST == 3 && NTW2 == 0 && (Cfg::RMAX / 8) % FN_NLOAD == 0), "ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const FnSched sch = fn_sched(g.M, g.batch);
@@ -524,8 +537,38 @@ __global__ __launch_bounds__(FN_THREADS, 3) void k_fn(const aew_gemm_nt_t g) {
     if (wave >= FN_NCONS) {
         // ------------------------------------------------------------------------------ loader
         __builtin_amdgcn_s_setprio(1);
-        FnLoader<NTW> L;
+        FnLoader<NTW, MTCAP> L;
         L.init(wave - FN_NCONS, lane, (uint32_t)(uintptr_t)AEW_LDS_PTR(smem), (uint32_t)g.K_total * 2);
+        if constexpr (NST == 3) {
+            // the K tiles of all of this block's tiles as ONE stream through a ring of three slots
+            constexpr int PER = Cfg::XPL + Cfg::WPL;           // DMA instructions per K tile and loader
+            FnTile cur, nxt;
+            if (!walk.next(cur)) return;
+            bool more = walk.next(nxt);
+            L.begin_tile(g, cur);
+            int in_tile = 0, head = 0, ahead = 0;
+            auto issue_next = [&]() {
+                if (in_tile == nkt) {
+                    if (!more) return;
+                    cur = nxt;
+                    L.begin_tile(g, cur);
+                    in_tile = 0;
+                    more = walk.next(nxt);
+                }
+                L.template issue<EPI, true>(g, (uint32_t)(head * Cfg::STAGE));
+                ++in_tile; ++ahead;
+                head = head == 2 ? 0 : head + 1;
+            };
+            issue_next();
+            issue_next();
+            while (ahead > 0) {
+                if (ahead >= 2) fn_wait_vm<PER>(); else wait_vm0();    // the OLDEST K tile in flight has landed
+                fn_barrier();                                  // A_k (the consumers are done with K tile k - 1: its slot is `head`)
+                --ahead;
+                issue_next();
+            }
+            return;
+        }
         uint32_t voff2_perm = 0, voff2_plain = 0;
         if constexpr (NTW2 > 0) {
             const int lr = lane >> 3, pos = lane & 7;
@@ -582,7 +625,7 @@ __global__ __launch_bounds__(FN_THREADS, 3) void k_fn(const aew_gemm_nt_t g) {
         switch (t.mt) {
 #define FN_CASE(MTV)                                                                                   \
             case MTV:                                                                                   \
-                if constexpr (MTV <= Cfg::MTMAX) fn_consumer_tile<NTW, MTV, EPI, NTW2>(g, smem, t, wn, lane, nkt, ktg); \
+                if constexpr (MTV <= Cfg::MTMAX) fn_consumer_tile<NTW, MTV, EPI, NTW2, NST, MTCAP>(g, smem, t, wn, lane, nkt, ktg); \
                 break;
             FN_CASE(1) FN_CASE(2) FN_CASE(3) FN_CASE(4) FN_CASE(5) FN_CASE(6) FN_CASE(7) FN_CASE(8)
             FN_CASE(9) FN_CASE(10) FN_CASE(11) FN_CASE(12) FN_CASE(13) FN_CASE(14) FN_CASE(15) FN_CASE(16)
@@ -596,22 +639,24 @@ __global__ __launch_bounds__(FN_THREADS, 3) void k_fn(const aew_gemm_nt_t g) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 static int g_fn_enable = 1;
+static int g_fn_ring3 = 16;                                    // K tiles from which plain full-N GEMMs take the 3-stage ring (0: never)
 extern "C" int aew_set_fn(int on) { g_fn_enable = on; return 0; }
+extern "C" int aew_set_fn_ring3(int min_k_tiles) { g_fn_ring3 = min_k_tiles < 0 ? 0 : min_k_tiles; return 0; }
 int g_fn_enable_flag() { return g_fn_enable; }
 
-template <int NTW, int EPI, int NTW2>
+template <int NTW, int EPI, int NTW2, int NST = 2, int MTCAP = 0>
 static int fn_launch(const aew_gemm_nt_t& g, hipStream_t st) {
     static int attr_done = 0;
-    constexpr int lds = fn_lds_bytes<NTW, EPI, NTW2>();
+    constexpr int lds = fn_lds_bytes<NTW, EPI, NTW2, NST, MTCAP>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fn<NTW, EPI, NTW2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fn<NTW, EPI, NTW2, NST, MTCAP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_done = 1;
     }
     const FnSched s = fn_sched(g.M, g.batch);
-    hipLaunchKernelGGL((k_fn<NTW, EPI, NTW2>), dim3(s.n_chunks), dim3(FN_THREADS), lds, st, g);
+    hipLaunchKernelGGL((k_fn<NTW, EPI, NTW2, NST, MTCAP>), dim3(s.n_chunks), dim3(FN_THREADS), lds, st, g);
     return (int)hipGetLastError();
 }
 
@@ -650,6 +695,11 @@ static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st) {
             if (a == 2) return fn_launch<2, AEW_EPI_DFG, 0>(g, st);
             return fn_launch<3, AEW_EPI_DFG, 0>(g, st);
         default:
+            // long K (the multi-segment skip sum / cond gradient): three-stage ring, see k_fn
+            if (g_fn_ring3 && g.K_total >= 64 * g_fn_ring3) {
+                if (a == 1) return fn_launch<1, AEW_EPI_STORE, 0, 3, 0>(g, st);
+                if (a == 2) return fn_launch<2, AEW_EPI_STORE, 0, 3, 10>(g, st);
+            }
             if (a == 1) return fn_launch<1, AEW_EPI_STORE, 0>(g, st);
             if (a == 2) return fn_launch<2, AEW_EPI_STORE, 0>(g, st);
             if (a == 3) return fn_launch<3, AEW_EPI_STORE, 0>(g, st);

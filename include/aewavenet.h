@@ -521,6 +521,8 @@ int aew_set_nt_pipe(int on);
 /* impl = 2 descriptors (full-N kernels, aew_fn.hip): 1 (default) use them where the shape is covered, 0 run every
  * impl = 2 descriptor on the tiled kernels instead (A/B and bisecting aid; same results). */
 int aew_set_fn(int on);
+int aew_set_fn_ring3(int min_k_tiles);   /* plain full-N GEMMs of >= this many 64-channel K tiles take the three-stage
+                                            operand ring (default 16; 0 = never).  Same results either way.       */
 /* Which kernel a GEMM_NT descriptor dispatches to under the current settings: 0 k_gemm_nt_bf16 (256- / 192-row tiles),
  * 1 k_gemm_nt_bf16_p64 (64-row tiles, small launches), 2 k_fn, 3 k_gemm_nt_f32, 4 the scalar check kernel, 5 an A/B
  * shape.  Measurement aid: lets a caller group per-op times by kernel the way a rocprofv3 kernel trace does. */

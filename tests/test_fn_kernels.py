@@ -129,6 +129,12 @@ CASES = [
     # full-size shapes of the bench workload: chunks of 14 units = tiles of 5 + 5 + 4 row groups, batch 8
     Case("fused_4_3_fullsize", 8, 7030, 256, 512, [384, 384, 128], "fused", N2=368, N2_pad=384, d=16),
     Case("store384_fullsize", 8, 7046, 368, 384, [512, 512], "add", d=512),
+    # >= 16 K tiles, N <= 256: the three-stage operand ring (loaders two K tiles ahead, counted vmcnt).  One tile per
+    # block, two tiles per block (the K-tile stream crosses a tile boundary), five segments with row offsets
+    Case("store256_ring3_fullsize", 8, 7046, 256, 256, [256] * 5, "add", d=3),
+    Case("store128_ring3_multiseg", 2, 3000, 128, 128, [512, 512, 256], "bias_relu"),
+    Case("store128_ring3_two_tiles", 1, 70000, 104, 128, [512, 512], "plain"),
+    Case("store256_ring3_mask", 3, 1000, 200, 256, [1024], "mask"),
 ]
 
 
