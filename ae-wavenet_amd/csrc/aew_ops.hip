@@ -772,7 +772,12 @@ template <int W>
 __global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_per_chunk) {
     __shared__ float sh[4][64 * W];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = blockIdx.x * (64 * W) + lane * W;
+    // narrow matrices (N <= 32 W): `lpr` lanes cover a row and a wave takes G = 64 / lpr rows per load (128 bf16
+    // columns left 48 of 64 lanes idle: the upsampler bias gradients ran at 0.5 TB/s)
+    int lpr = 64;
+    if (gridDim.x == 1) { while (lpr > 1 && (lpr >> 1) * W >= p.N) lpr >>= 1; }
+    const int G = 64 / lpr, cl = lane & (lpr - 1), rg = lane / lpr;
+    const int col = blockIdx.x * (64 * W) + cl * W;
     const int b = blockIdx.y;
     const int r0 = blockIdx.z * rows_per_chunk, r1 = min(p.M, r0 + rows_per_chunk);
     float s[W];
@@ -796,17 +801,21 @@ __global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_p
         }
     };
     if (col < p.N && p.x.row_hi > p.x.row_lo)
-        for (int m = r0 + wv; m < r1; m += 16) {
+        for (int m = r0 + wv * G + rg; m < r1; m += 16 * G) {
             float v[4][W];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load(m + 4 * u, v[u]);
+            for (int u = 0; u < 4; ++u) load(m + 4 * G * u, v[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int r = 0; r < W; ++r) s[r] += v[u][r];
         }
+    for (int o = lpr; o < 64; o <<= 1) {                       // add the G row groups of the wave
 #pragma unroll
-    for (int r = 0; r < W; ++r) sh[wv][lane * W + r] = s[r];
+        for (int r = 0; r < W; ++r) s[r] += __shfl_xor(s[r], o);
+    }
+#pragma unroll
+    for (int r = 0; r < W; ++r) sh[wv][lane * W + r] = (lane < lpr) ? s[r] : 0.f;
     __syncthreads();
     for (int c = threadIdx.x; c < 64 * W; c += 256) {
         const int cc = blockIdx.x * (64 * W) + c;
@@ -857,24 +866,33 @@ __global__ __launch_bounds__(1024) void k_moments(const aew_moments_t p) {
     __shared__ double sh[2][1024];
     const int64_t per_b = (int64_t)p.rows * p.cols, n = per_b * p.batch;
     double s = 0.0, q = 0.0;
-    const bool small = n < ((int64_t)1 << 31);               // 32-bit index arithmetic (two 64-bit divisions per element
-    for (int64_t e = threadIdx.x; e < n; e += 1024) {        // were most of what this single block executed)
-        int b, r, c;
-        if (small) {
-            const unsigned e32 = (unsigned)e, pb = (unsigned)per_b, cols = (unsigned)p.cols;
-            const unsigned bq = e32 / pb, rem = e32 - bq * pb, rq = rem / cols;
-            b = (int)bq; r = (int)rq; c = (int)(rem - rq * cols);
-        } else {
-            b = (int)(e / per_b);
-            r = (int)((e - b * per_b) / p.cols); c = (int)(e - b * per_b - (int64_t)r * p.cols);
+    // four elements per thread and pass, loads first (thread t still adds elements t, t + 1024, ... in that order);
+    // 32-bit index arithmetic where it fits (two 64-bit divisions per element were most of what this block executed)
+    const bool small = n < ((int64_t)1 << 31);
+    for (int64_t e0 = threadIdx.x; e0 < n; e0 += 4096) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = e0 + 1024 * u;
+            v[u] = 0.f;
+            if (e >= n) continue;
+            int b, r, c;
+            if (small) {
+                const unsigned e32 = (unsigned)e, pb = (unsigned)per_b, cols = (unsigned)p.cols;
+                const unsigned bq = e32 / pb, rem = e32 - bq * pb, rq = rem / cols;
+                b = (int)bq; r = (int)rq; c = (int)(rem - rq * cols);
+            } else {
+                b = (int)(e / per_b);
+                r = (int)((e - b * per_b) / p.cols); c = (int)(e - b * per_b - (int64_t)r * p.cols);
+            }
+            const int row = r * p.x.row_step + p.x.row_off;
+            if (row < p.x.row_lo || row >= p.x.row_hi) continue;                // rows outside the view read as zero
+            const int64_t off = b * p.x.batch_stride + (int64_t)row * p.x.row_pitch + c;
+            v[u] = p.x.dtype == AEW_BF16 ? bf2f(static_cast<const uint16_t*>(p.x.ptr)[off])
+                                         : static_cast<const float*>(p.x.ptr)[off];
         }
-        const int row = r * p.x.row_step + p.x.row_off;
-        if (row < p.x.row_lo || row >= p.x.row_hi) continue;                    // rows outside the view read as zero
-        const int64_t off = b * p.x.batch_stride + (int64_t)row * p.x.row_pitch + c;
-        const float v = p.x.dtype == AEW_BF16 ? bf2f(static_cast<const uint16_t*>(p.x.ptr)[off])
-                                              : static_cast<const float*>(p.x.ptr)[off];
-        s += (double)v;
-        q += (double)v * (double)v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u]; q += (double)v[u] * (double)v[u]; }
     }
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = q;
@@ -1471,7 +1489,13 @@ static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
         }
     }
-    const int rpc = 64;                                      // rows per block: 16 per wave, 4 loads in flight
+    int rpc = 64;                                            // rows per block: 16 per wave, 4 loads in flight
+    {                                                        // narrow matrices: G rows per wave-load (see k_colsum)
+        const int W = p.dtype == AEW_BF16 ? 8 : 4;
+        int lpr = 64;
+        if (p.N <= 64 * W) { while (lpr > 1 && (lpr >> 1) * W >= p.N) lpr >>= 1; }
+        rpc = 64 * (64 / lpr);
+    }
     const int chunks = (p.M + rpc - 1) / rpc;
     if (p.dtype == AEW_BF16) {
         if ((p.x.row_pitch % 8) || ((uintptr_t)p.x.ptr & 15) || (p.x.batch_stride % 8)) return AEW_E_ALIGN;
