@@ -76,7 +76,10 @@ extern "C" int aew_sizeof(int which) {
 // inside a stream capture become graph dependencies (the side stream joins the capture by
 // waiting on an event recorded in the capturing stream).
 // ---------------------------------------------------------------------------------------------
-static int g_lanes = 1;
+// Default OFF (round 3): with the weight gradients in one launch after the chain there is little left to overlap, and in a
+// captured graph every fork / join edge is a cross-branch dependency the replay pays for - measured on one box, one
+// process: graph + lanes 6.96 ms/step, graph serial 6.81, eager serial 6.80, eager + lanes 6.77 (profiles/r03_notes.md).
+static int g_lanes = 0;
 static std::vector<hipEvent_t> g_lane_ev;
 static size_t g_lane_ev_next = 0;
 

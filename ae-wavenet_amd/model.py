@@ -7,6 +7,8 @@ and `mfcc_inverter.MfccInverter` wrap it in the reference's nn.Module surface
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional
 
@@ -46,7 +48,8 @@ class TrainEngine:
         _SERIAL[0] += 1
         self.serial = _SERIAL[0]          # unique per engine (id() can be recycled after garbage collection)
         self.weights_version = 0          # bumped by adam_step(): FusedAdam writes parameters by raw pointer
-        self.use_graphs = use_graphs
+        # AEW_USE_GRAPHS=0: plans run eagerly (stream launches) instead of as captured hipGraphs (A/B aid)
+        self.use_graphs = use_graphs if os.environ.get("AEW_USE_GRAPHS") is None else os.environ["AEW_USE_GRAPHS"] == "1"
         self.kind = hps.global_model
         self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
         self.loss_mode, self.take_compat = loss_mode, take_compat

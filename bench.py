@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--jitter-prob", dest="jitter_prob", type=float, default=0.12, help="par/train.basic.json")
-    ap.add_argument("--lanes", type=int, default=1, help="0: serial plan order (no side-lane overlap)")
+    ap.add_argument("--lanes", type=int, default=0, help="1: side-lane ops on their own streams / graph branches (default 0: serial plan order)")
     ap.add_argument("--nt-wave-rows", dest="nt_wave_rows", type=int, default=64, help="bf16 NT shape (64|128|256)")
     ap.add_argument("--nt-pipe", dest="nt_pipe", type=int, default=1, help="0 plain loop, 1 pipelined, 2 pipelined K=64 tiles")
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")

@@ -550,7 +550,8 @@ int aew_set_nt_rows192(int mode);
  * 256 + d rows per K tile and issue both taps' MFMAs from it (k_gemm_nt_bf16_win).  Default 64 (the largest
  * supported), 0 = never.  Results agree with the two-segment kernel to fp32 accumulation order, not bit for bit. */
 int aew_set_nt_window(int max_dist);
-/* 0: ignore aew_op_t.lane (every op on the caller's stream, plan order).  Default 1. */
+/* 0 (default): ignore aew_op_t.lane - every op on the caller's stream, in plan order.  1: side-lane ops on private
+ * streams (branches of a captured graph).  Same results either way (the atomically accumulated bias sums up to order). */
 int aew_set_lanes(int on);
 
 /* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */

@@ -1140,4 +1140,4 @@ def test_two_lane_schedule_is_bit_identical_to_serial():
             same(*step(), l_ref, g_ref)
     finally:
         eng.use_graphs = True
-        lib.aew_set_lanes(1)
+        lib.aew_set_lanes(0)                        # the library's default

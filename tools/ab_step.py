@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 1, "fn": 1, "fn_ring3": 16}
+DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1}
 
 
 def main():
@@ -83,6 +83,9 @@ def main():
         eng = engine_for(ekey)
         cur[0] = eng
         for k, v in vals.items():
+            if k == "graphs":                      # 0: plans run eagerly (real streams + events) instead of as hipGraphs
+                eng.use_graphs = bool(v)
+                continue
             getattr(lib, "aew_set_" + k)(v)
         for p in (eng.fwd_a, eng.fwd_b, eng.bwd, getattr(eng, "bwd_a", None), getattr(eng, "bwd_b", None),
                   getattr(eng, "cb", None), getattr(eng, "fwd_b_noema", None), getattr(eng, "ema_plan", None)):
