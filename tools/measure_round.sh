@@ -1,6 +1,7 @@
 #!/bin/bash
 # Full measurement pass for profiles/: bench line (+per-op), rocprofv3 kernel stats (serial plan order,
-# --lanes 0, so that per-kernel durations are not inflated by side-lane overlap), PMC HBM traffic.
+# --lanes 0 - the library default since the end of round 3 - so that per-kernel durations are not inflated by
+# side-lane overlap), PMC HBM traffic.
 # Then the per-op roofline table and the sampler bench.
 # usage (on the GPU box): tools/measure_round.sh <tag>
 cd /tmp && export TMPDIR=/tmp
