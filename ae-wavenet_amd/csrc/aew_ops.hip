@@ -4,9 +4,81 @@
 // =============================================================================================
 // table-driven strided copy / convert / reduce   (weight pack, gradient unpack, NCL <-> NLC)
 // =============================================================================================
+// interleave forms of k_copy_table (K = -tr_a taps; conv weight [..][c][k] <-> [..][k][c]): a thread moves W channels
+// of all K taps - K (or 2K) 16-byte loads, K 16-byte stores, both sides consecutive across the wave, the permutation in
+// registers.  (The element-wise forms issue one 4-byte access per element on one of the two sides.)
+//   tr_b = 1  interleave    (gradient unpack):  src[.. + t*ss[2] + c]  ->  dst[.. + c*K + t]        dims[2] = K, W = 4
+//   tr_b = 2  de-interleave (weight pack):      src[.. + c*K + t]      ->  dst[.. + t*ds[3] + c]    dims[3] = K, W = 4 | 8 (bf16)
+template <int K>
+__device__ __forceinline__ void copy_ilv(const aew_copy_rec_t& r, unsigned item) {
+    const bool ilv = r.tr_b == 1;
+    const bool w8 = !ilv && r.dst_dtype == AEW_BF16;
+    const int W = w8 ? 8 : 4;
+    const int nc = (ilv ? r.dims[3] : r.dims[2]) / W;
+    const unsigned total = (unsigned)r.dims[0] * (unsigned)r.dims[1] * (unsigned)nc;
+    if (item >= total) return;
+    const unsigned q = item % (unsigned)nc, o = item / (unsigned)nc;
+    const int i1 = (int)(o % (unsigned)r.dims[1]), i0 = (int)(o / (unsigned)r.dims[1]);
+    const float* sp = reinterpret_cast<const float*>(r.src) + i0 * r.ss[0] + i1 * r.ss[1];
+    const int64_t dbase = i0 * r.ds[0] + i1 * r.ds[1];
+    if (ilv) {
+        float v[K][4];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const float4 x = *reinterpret_cast<const float4*>(sp + t * r.ss[2] + 4 * q);
+            v[t][0] = x.x * r.scale; v[t][1] = x.y * r.scale; v[t][2] = x.z * r.scale; v[t][3] = x.w * r.scale;
+        }
+        float* dp = reinterpret_cast<float*>(r.dst) + dbase + (int64_t)4 * q * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {                           // element e = 4j + u of the run is (channel e / K, tap e % K)
+            float o4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o4[u] = v[(4 * j + u) % K][(4 * j + u) / K];
+            *reinterpret_cast<float4*>(dp + 4 * j) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+        return;
+    }
+    if (w8) {
+        float v[8 * K];
+        const float* s0 = sp + (int64_t)8 * q * K;
+#pragma unroll
+        for (int j = 0; j < 2 * K; ++j) {
+            const float4 x = *reinterpret_cast<const float4*>(s0 + 4 * j);
+            v[4 * j] = x.x * r.scale; v[4 * j + 1] = x.y * r.scale; v[4 * j + 2] = x.z * r.scale; v[4 * j + 3] = x.w * r.scale;
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(r.dst) + dbase + t * r.ds[3] + 8 * q) =
+                make_uint4(pack2_bf16(v[t], v[K + t]), pack2_bf16(v[2 * K + t], v[3 * K + t]),
+                           pack2_bf16(v[4 * K + t], v[5 * K + t]), pack2_bf16(v[6 * K + t], v[7 * K + t]));
+    } else {
+        float v[4 * K];
+        const float* s0 = sp + (int64_t)4 * q * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float4 x = *reinterpret_cast<const float4*>(s0 + 4 * j);
+            v[4 * j] = x.x * r.scale; v[4 * j + 1] = x.y * r.scale; v[4 * j + 2] = x.z * r.scale; v[4 * j + 3] = x.w * r.scale;
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(r.dst) + dbase + t * r.ds[3] + 4 * q) =
+                make_float4(v[t], v[K + t], v[2 * K + t], v[3 * K + t]);
+    }
+}
+
 __global__ void k_copy_table(const aew_copy_table_t t) {
     const int rec_i = t.block_rec[blockIdx.x];
     const aew_copy_rec_t r = t.recs[rec_i];
+    if (r.tr_a < 0) {                                           // interleave forms (copy_ilv)
+        const unsigned item = (blockIdx.x - (unsigned)r.first_block) * 256u + threadIdx.x;
+        switch (-r.tr_a) {
+            case 2: copy_ilv<2>(r, item); break;
+            case 3: copy_ilv<3>(r, item); break;
+            case 4: copy_ilv<4>(r, item); break;
+            default: break;
+        }
+        return;
+    }
     if (r.tr_a > 0) {
         // tiled form: one tr_a x tr_b tile of the (dims[2], dims[3]) plane through LDS - loads run along dims[3] (the
         // source's contiguous dim), stores along dims[2] (the destination's).  The element-wise forms touch one cache

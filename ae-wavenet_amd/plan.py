@@ -331,6 +331,8 @@ class CopyTableBuilder:
         while len(dims) < 4:
             dims.insert(0, 1); ss.insert(0, 0); ds.insert(0, 0)
         tiled = self._tiled_form(dims, ss, ds, src_dtype, dst_dtype, red_n, accumulate) if self.tiled else None
+        if tiled is None and self.interleave:
+            tiled = self._interleave_form(dims, ss, ds, src_ptr, dst_ptr, src_dtype, dst_dtype, red_n, accumulate)
         if tiled is not None:
             dims, ss, ds, tr_a, tr_b = tiled
             r = L.CopyRec()
@@ -429,6 +431,39 @@ class CopyTableBuilder:
         order = outer + [b, a]
         return [dims[i] for i in order], [ss[i] for i in order], [ds[i] for i in order], ta, tb
 
+    interleave = True         # tap <-> channel (de)interleaves as register permutations (False: element-wise forms; A/B)
+
+    @staticmethod
+    def _interleave_form(dims, ss, ds, src_ptr, dst_ptr, src_dtype, dst_dtype, red_n, accumulate):
+        """Conv-weight records that swap the tap dim (k = 2..4) with the channel dim inside a row:
+        [..][k][c] -> [..][c][k] (gradient unpack, tr_b = 1) and [..][c][k] -> [..][k][c] (weight pack, tr_b = 2).
+        -> (dims, ss, ds, -k, tr_b) in the kernel's dim order, or None (shape or alignment not covered)."""
+        if src_dtype != L.F32 or dst_dtype not in (L.F32, L.BF16) or red_n != 1 or accumulate:
+            return None
+        dims, ss, ds = list(dims), list(ss), list(ds)
+        live = [i for i in range(4) if dims[i] > 1]
+        a = [i for i in live if ss[i] == 1]
+        b = [i for i in live if ds[i] == 1]
+        if len(a) != 1 or len(b) != 1 or a[0] == b[0]:
+            return None
+        a, b = a[0], b[0]
+        rest = [i for i in range(4) if i not in (a, b)]
+        rest.sort(key=lambda i: dims[i] > 1)
+        if dims[b] in (2, 3, 4) and ds[a] == dims[b] and dst_dtype == L.F32:
+            k, mode = dims[b], 1                                    # interleave: a = channels (source run), b = taps
+            ok = dims[a] % 4 == 0 and ss[b] % 4 == 0 and all(ss[i] % 4 == 0 and ds[i] % 4 == 0 for i in rest if dims[i] > 1)
+            order = rest + [b, a]
+        elif dims[a] in (2, 3, 4) and ss[b] == dims[a]:
+            k, mode = dims[a], 2                                    # de-interleave: a = taps, b = channels (destination run)
+            w = 8 if dst_dtype == L.BF16 else 4
+            ok = dims[b] % w == 0 and ds[a] % w == 0 and all(ss[i] % 4 == 0 and ds[i] % w == 0 for i in rest if dims[i] > 1)
+            order = rest + [b, a]
+        else:
+            return None
+        if not ok or src_ptr % 16 or dst_ptr % 16:
+            return None
+        return [dims[i] for i in order], [ss[i] for i in order], [ds[i] for i in order], -k, mode
+
     def emit(self, plan: Plan, label: str, join: bool = False):
         if not self.recs:
             return
@@ -438,6 +473,11 @@ class CopyTableBuilder:
             r.first_block = len(block_rec)
             if r.tr_a > 0:
                 block_rec.extend([i] * (r.dims[0] * r.dims[1] * (-(-r.dims[2] // r.tr_b)) * (-(-r.dims[3] // r.tr_a))))
+                continue
+            if r.tr_a < 0:                                         # interleave forms: one item per W channels of all taps
+                w = 8 if (r.tr_b == 2 and r.dst_dtype == L.BF16) else 4
+                items = r.dims[0] * r.dims[1] * ((r.dims[3] if r.tr_b == 1 else r.dims[2]) // w)
+                block_rec.extend([i] * ((items + 255) // 256))
                 continue
             block_rec.extend([i] * ((n + 1023) // 1024))
         raw = bytes((L.CopyRec * len(self.recs))(*self.recs))

@@ -201,6 +201,10 @@ typedef struct {
  * dims[2] the one the DESTINATION is contiguous in (ds[2] = 1); a block moves one tr_a x tr_b tile of that plane through
  * LDS, reading along dims[3] and writing along dims[2] (transposing weight packs: both sides coalesced).  Same result
  * as the element-wise forms.  Blocks per record: dims[0] * dims[1] * ceil(dims[2] / tr_b) * ceil(dims[3] / tr_a).
+ * Interleave forms (tr_a = -k, k = 2..4 taps of a conv weight; f32 source, red_n = 1, no accumulate, 16-byte aligned):
+ *   tr_b = 1  [..][k][c] -> [..][c][k]:  dims[2] = k, dims[3] = c (ss[3] = 1, ds[2] = 1, ds[3] = k), f32 destination
+ *   tr_b = 2  [..][c][k] -> [..][k][c]:  dims[2] = c, dims[3] = k (ss[3] = 1, ss[2] = k, ds[2] = 1), f32 or bf16
+ * a thread permutes W = 4 (8 for bf16) channels of all taps in registers; blocks: ceil(dims[0] * dims[1] * c / W / 256).
  * ------------------------------------------------------------------------------------- */
 typedef struct {
     const void* src;
@@ -214,8 +218,8 @@ typedef struct {
     float scale;
     int32_t first_block;         /* filled by the host: first block of this record (1024 elements per block, or one
                                     tile in the tiled form)                                                       */
-    int32_t tr_a, tr_b;          /* tiled form: tile extents along dims[3] / dims[2]; tr_a * tr_b <= 1024,
-                                    tr_b * (tr_a | 1) <= 1600; 0 = element-wise forms                             */
+    int32_t tr_a, tr_b;          /* tr_a > 0: tiled form, tile extents along dims[3] / dims[2] (tr_a * tr_b <= 1024,
+                                    tr_b * (tr_a | 1) <= 1600); tr_a < 0: interleave forms; 0 = element-wise      */
 } aew_copy_rec_t;
 
 typedef struct {

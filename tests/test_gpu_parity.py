@@ -462,7 +462,7 @@ def test_copy_table_transposing_records(tiled):
     for n, sz, dt in (("d_bf", 2304 * 768 + 64, torch.bfloat16), ("d_f", 2304 * 768 + 64, torch.float32), ("d_g", 16 * 1024 * 40, torch.bfloat16),
                       ("d_r", 117 * 768 + 64, torch.bfloat16), ("d_o", 130 * 77 + 64, torch.bfloat16), ("d_w", 368 * 640 + 64, torch.bfloat16),
                       ("d_e", 64 * 2304, torch.float32), ("d_i", 64 * 2304, torch.float32), ("d_t", 16 * 736, torch.float32),
-                      ("d_s", 64 * 120, torch.float32)):
+                      ("d_s", 64 * 120, torch.float32), ("d_p", 16 * 28672 + 64, torch.bfloat16)):
         ws_c.alloc(n, sz, dt)
     cases = [  # name, dims, source strides, destination strides, destination type, scale, expected to be tiled
         ("d_bf", (768, 768, 3), (2304, 3, 1), (1, 2304, 768), BF, 1.0, True),        # encoder conv -> [c][k][o]
@@ -474,17 +474,22 @@ def test_copy_table_transposing_records(tiled):
         ("d_e", (64, 768, 3), (2304, 3, 1), (2304, 1, 768), F3, 1.0, False),         # [c][k] -> [k][c] inside a row: element-wise
         ("d_i", (64, 3, 768), (2304, 768, 1), (2304, 1, 3), F3, 1.0, False),         # ... and back (gradient unpack)
         ("d_t", (16, 2, 368), (896, 384, 1), (736, 1, 2), F3, 1.0, False),           # two taps
-        ("d_s", (64, 40, 3), (120, 3, 1), (120, 1, 40), F3, 1.0, False)]             # short rows: element-wise form
+        ("d_s", (64, 40, 3), (120, 3, 1), (120, 1, 40), F3, 1.0, False),             # 40 channels: interleave form too
+        ("d_p", (16, 16, 368, 2), (11776, 736, 2, 1), (28672, 896, 1, 384), BF, 0.25, False)]   # decoder pack: two taps -> bf16 planes
+
+    ilv = {"d_e": -3, "d_i": -3, "d_t": -2, "d_s": -3, "d_p": -2}                      # the (de)interleaves: register-permutation form, k taps
 
     def build(ws):
-        keep, PL.CopyTableBuilder.tiled = PL.CopyTableBuilder.tiled, tiled
+        keep = PL.CopyTableBuilder.tiled, PL.CopyTableBuilder.interleave
+        PL.CopyTableBuilder.tiled = PL.CopyTableBuilder.interleave = tiled
         try:
             tb = PL.CopyTableBuilder(ws, "t.tbl")
             for name, dims, ss, ds, dt, scale, _ in cases:
                 tb.add(ws.get("src").data_ptr() + 4 * 8, ws.get(name).data_ptr(), dims, ss, ds, F3, dt, scale=scale)
         finally:
-            PL.CopyTableBuilder.tiled = keep
+            PL.CopyTableBuilder.tiled, PL.CopyTableBuilder.interleave = keep
         assert [r.tr_a > 0 for r in tb.recs] == [c[-1] and tiled for c in cases]
+        assert [r.tr_a for r in tb.recs if r.tr_a < 0] == ([ilv[c[0]] for c in cases if c[0] in ilv] if tiled else [])
         p = Plan("t")
         tb.emit(p, "copy")
         return p
@@ -495,7 +500,7 @@ def test_copy_table_transposing_records(tiled):
     for n, t in ws_c.bufs.items():
         ws_e.bufs[n] = t.clone()
     Emu(ws_e).run(build(ws_e))
-    for name in ("d_bf", "d_g", "d_r", "d_o", "d_w"):
+    for name in ("d_bf", "d_g", "d_r", "d_o", "d_w", "d_p"):
         assert torch.equal(ws_g.get(name).cpu().view(torch.int16), ws_e.get(name).view(torch.int16)), name
     for name in ("d_f", "d_e", "d_i", "d_t", "d_s"):
         assert torch.equal(ws_g.get(name).cpu(), ws_e.get(name)), name

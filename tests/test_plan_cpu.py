@@ -294,3 +294,29 @@ def test_copy_table_tiled_form_addresses_the_same_elements():
                          ((1, 1, 16, 64), (0, 0, 64, 1), (0, 0, 64, 1))]:    # plain copy
         assert CopyTableBuilder._tiled_form(list(dims), list(ss), list(ds), L.F32, L.F32, 1, False) is None
     assert CopyTableBuilder._tiled_form([1, 1, 64, 64], [0, 0, 64, 1], [0, 0, 1, 64], L.F32, L.F32, 4, False) is None   # slab sums
+
+
+def test_copy_table_interleave_form_addresses_the_same_elements():
+    """CopyTableBuilder._interleave_form: same (source, destination) offset pairs as the record given, dims in the order
+    the kernel's register-permutation forms expect, nothing selected when shape or alignment is not covered."""
+    import itertools
+    from ae_wavenet_amd import _lib as L
+    from ae_wavenet_amd.plan import CopyTableBuilder
+
+    def pairs(dims, ss, ds):
+        return {(sum(i * s for i, s in zip(idx, ss)), sum(i * s for i, s in zip(idx, ds)))
+                for idx in itertools.product(*[range(d) for d in dims])}
+    got = CopyTableBuilder._interleave_form([1, 6, 3, 40], [0, 120, 40, 1], [0, 120, 1, 3], 0, 0, L.F32, L.F32, 1, False)
+    d, s, t, k, mode = got
+    assert (k, mode) == (-3, 1) and d[2] == 3 and s[3] == 1 and t[2] == 1 and t[3] == 3
+    assert pairs(d, s, t) == pairs([1, 6, 3, 40], [0, 120, 40, 1], [0, 120, 1, 3])
+    got = CopyTableBuilder._interleave_form([2, 6, 48, 2], [1152, 96, 2, 1], [2304, 192, 1, 64], 64, 32, L.F32, L.BF16, 1, False)
+    d, s, t, k, mode = got
+    assert (k, mode) == (-2, 2) and d[3] == 2 and s[2] == 2 and t[2] == 1 and t[3] == 64
+    assert pairs(d, s, t) == pairs([2, 6, 48, 2], [1152, 96, 2, 1], [2304, 192, 1, 64])
+    none = [([1, 6, 3, 42], [0, 126, 42, 1], [0, 126, 1, 3], 0, 0, L.F32, L.F32),        # 42 channels: not a multiple of 4
+            ([1, 6, 3, 40], [0, 120, 40, 1], [0, 120, 1, 3], 4, 0, L.F32, L.F32),        # source not 16-byte aligned
+            ([1, 6, 5, 40], [0, 200, 40, 1], [0, 200, 1, 5], 0, 0, L.F32, L.F32),        # five taps
+            ([1, 6, 44, 2], [0, 88, 2, 1], [0, 176, 1, 44], 0, 0, L.F32, L.BF16)]        # bf16 planes need multiples of 8
+    for dims, ss, ds, sp, dp, a, b in none:
+        assert CopyTableBuilder._interleave_form(dims, ss, ds, sp, dp, a, b, 1, False) is None

@@ -54,7 +54,7 @@ def main():
 
     def owner(k):                                  # E.tiled: the copy-table builder's switch; everything else DecoderPlan's
         from ae_wavenet_amd import plan as PLN
-        return PLN.CopyTableBuilder if k == "tiled" else E.DecoderPlan
+        return PLN.CopyTableBuilder if k in ("tiled", "interleave") else E.DecoderPlan
 
     def engine_for(ekey):
         if ekey not in engines:
