@@ -952,6 +952,10 @@ __device__ __forceinline__ void p64_frags_ready(bf16x8_t (&wf)[4], bf16x8_t (&xf
 //                            blocks.  With 2 waves a K tile is 12 LDS-DMA instructions per wave at 60-185 cycles
 //                            of issue each (MI355X_MICROARCH.md) against 512 cycles of MFMA: the two waves spent
 //                            their time issuing loads (1870 cycles per tile measured).  8 waves issue 3 each.
+//                1 x 4 x 1 =  64 x  64 tile, 4 waves: launches of so few blocks that even the 64 x 128 shape leaves most
+//                            CUs idle (the encoder / upsampler dgrads: 4-54 blocks).  A lone block fills its LDS at
+//                            ~30 GB/s whatever its ring, so its K loop lasts bytes-per-block / 30 GB/s: half the W rows
+//                            per block = 2/3 of the bytes, twice the blocks (aew_set_nt_small_n64)
 //   S = ring depth.  2: tile T+2 is issued one tile time ahead (the long-K shapes are MFMA-bound anyway).  The 64-row
 //   shape runs launches of a few dozen blocks whose K loop is pure DMA latency at depth 2 (36 tiles x ~1 us for the
 //   encoder dgrads against 0.2 us of MFMAs per tile); S = 5 keeps four tiles in flight (counted vmcnt).
@@ -2030,6 +2034,7 @@ static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kern
 static int g_nt_rows192 = 1;      // default shape: 0 never, 1 cost model, 2 always use 192-row tiles
 static int g_nf_loaders = 1;        // fp32 NT: four dedicated loader waves per block (0: the consumer waves stage their own operands)
 static int g_nf_deep = 256;         // fp32 NT: launches of <= this many blocks get one block per CU and a 12-14 stage ring
+static int g_nt_small_n64 = 256;   // ... and as 64 x 64 tiles when the launch has <= this many 64 x 128 blocks (0: never)
 static int g_nt_small_w8 = 1;       // ... with 8 waves (16 rows x 64 channels each) instead of 2: the LDS-DMA issue is shared
 static int g_nt_small_deep = 256;   // 64-row launches of <= this many blocks (one per CU) use the 5-stage ring (120 KiB)
 static int g_nt_small_tiles = 128; // default shape: launches of <= this many 256x128 tiles use 64-row tiles
@@ -2052,6 +2057,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), (P64Cfg<4, 1, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 4, 1, 2, 5>), (5 * P64Cfg<4, 1, 2>::STAGE_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 1, 4, 2, 5>), (5 * P64Cfg<1, 4, 2>::STAGE_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16_p64<EPI, 1, 4, 1, 5>), (5 * P64Cfg<1, 4, 1>::STAGE_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 1>), (NtCfg<8, 1>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
@@ -2190,13 +2196,18 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             const int dwp = win_dwp(g);
             if (dwp) return launch_win(g, dwp, t192, st);
         }
-        const int bm = p64r ? 64 : (p128 ? 128 : (t192 ? 192 : NT_BM)), bn = (p128 || p64r) ? 128 : (wide ? 256 : NT_BN);
+        // 64 x 64 tiles for launches of very few 64 x 128 blocks (see the p64 kernel's table)
+        const bool p64n = p64r && g_nt_small_w8 && g_nt_small_n64 > 0 &&
+                          ((g.M + 63) / 64) * g.batch * (g.N_pad / 128) <= g_nt_small_n64;
+        const int bm = p64r ? 64 : (p128 ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : (wide ? 256 : NT_BN));
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
 #define AEW_NT_GO(EPI, ABL)                                                                                   \
     do {                                                                                                      \
         if (!ABL && t192)                                                                                      \
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), grid, dim3((NtCfg<3, 1, 192>::THREADS)), (NtCfg<3, 1, 192>::LDS_BYTES), st, g); \
+        else if (!ABL && p64n)                                                                                 \
+            hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 1, 4, 1, 5>), grid, dim3(256), (5 * P64Cfg<1, 4, 1>::STAGE_BYTES), st, g); \
         else if (!ABL && p64r && (int)grid.x <= g_nt_small_deep && g_nt_small_w8)                              \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 1, 4, 2, 5>), grid, dim3(512), (5 * P64Cfg<1, 4, 2>::STAGE_BYTES), st, g); \
         else if (!ABL && p64r && (int)grid.x <= g_nt_small_deep)                                               \

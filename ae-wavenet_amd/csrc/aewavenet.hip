@@ -256,6 +256,7 @@ extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n;
 extern "C" int aew_set_nf_loaders(int on) { g_nf_loaders = on ? 1 : 0; return 0; }
 extern "C" int aew_set_nf_deep(int max_blocks) { g_nf_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
 extern "C" int aew_set_nt_small_waves(int waves) { g_nt_small_w8 = waves >= 8 ? 1 : 0; return 0; }
+extern "C" int aew_set_nt_small_n64(int max_blocks) { g_nt_small_n64 = max_blocks < 0 ? 0 : max_blocks; return 0; }
 extern "C" int aew_set_nt_small_deep(int max_blocks) { g_nt_small_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
 extern "C" int aew_set_nt_pipe(int mode) { g_nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_wave_rows(int rows) {

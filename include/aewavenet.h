@@ -535,6 +535,8 @@ int aew_nt_kernel(const aew_gemm_nt_t* g);
 int aew_set_nt_small_tiles(int n);
 /* ... and of those, launches of <= max_blocks blocks (default 256: one block per CU) run a 5-stage operand ring
  * instead of 2 stages: their K loop is DMA latency, not MFMA (0 = never; same results). */
+int aew_set_nt_small_n64(int max_blocks);   /* launches of <= this many 64 x 128 blocks run as 64 x 64 tiles (twice the
+                                               blocks, 2/3 of the operand bytes per block; default 256, 0 = never)  */
 int aew_set_nt_small_deep(int max_blocks);
 /* ... as 8 waves of 16 rows x 64 channels (default) or 2 waves of 64 x 64 per block (A/B; same results). */
 int aew_set_nt_small_waves(int waves);

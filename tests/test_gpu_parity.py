@@ -148,7 +148,8 @@ def test_gemm_nt(dtype, epi):
         # the 64-row shape in its three forms: 8 waves + 5-stage ring (default for small launches), 2 waves + 5 stages,
         # 2 waves + 2 stages; the fp32 kernel with the deep (one block per CU) and the shallow ring, with and without
         # its dedicated loader waves
-        for waves, deep, nf_deep, nf_ld in ((8, 256, 256, 1), (2, 256, 0, 1), (2, 0, 256, 0), (8, 256, 0, 0)):
+        # (... and the 8-wave form as 64 x 64 tiles - the default for launches of few blocks - or as 64 x 128)
+        for waves, deep, nf_deep, nf_ld, n64 in ((8, 256, 256, 1, 128), (8, 256, 256, 1, 0), (2, 256, 0, 1, 128), (2, 0, 256, 0, 0), (8, 256, 0, 0, 0)):
             lib.aew_set_nt_rows192(0)
             lib.aew_set_nt_wave_rows(64)
             lib.aew_set_nt_pipe(1)
@@ -157,13 +158,14 @@ def test_gemm_nt(dtype, epi):
             lib.aew_set_nt_small_deep(deep)
             lib.aew_set_nf_deep(nf_deep)
             lib.aew_set_nf_loaders(nf_ld)
+            lib.aew_set_nt_small_n64(n64)
             ws_g = _mirror(ws_c, DEV)
             p = Plan("nt")
             p.add(L.OP_GEMM_NT, _nt_case(ws_g, dtype, epi, 0), "nt")
             p.run(stream())
             torch.cuda.synchronize()
             for n in ("O0", "O1", "O2"):
-                assert torch.equal(ws_g.get(n).float().cpu(), results[0][n]), (n, "small-launch form", waves, deep, nf_deep, nf_ld)
+                assert torch.equal(ws_g.get(n).float().cpu(), results[0][n]), (n, "small-launch form", waves, deep, nf_deep, nf_ld, n64)
     finally:
         lib.aew_set_nt_wave_rows(64)
         lib.aew_set_nt_pipe(1)
@@ -173,6 +175,7 @@ def test_gemm_nt(dtype, epi):
         lib.aew_set_nt_small_deep(256)
         lib.aew_set_nf_deep(256)
         lib.aew_set_nf_loaders(1)
+        lib.aew_set_nt_small_n64(256)
     ws_e = Workspace("cpu")
     for n, t in ws_c.bufs.items():
         ws_e.bufs[n] = t.clone()
