@@ -1196,7 +1196,102 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     for (int i = 0; i < 16; ++i) r += sh[i];
     return r;
 }
-__global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
+// The bulk of the diagnostics in AEW_DIAG_PARTS blocks: a single block reads the 1 MB codebook (or 2 x 160 KB of
+// per-position values) at the fill rate of one CU (~23 us); the slices leave 16 floats each in `scratch`
+//   [0..3] min / max row norm of the ze slice, of the codebook slice   [4..7] two doubles: sum / sum of squares of the peak
+//   [8..15] 256-bit set of the arg-max classes seen
+// and k_diag_final combines them in slice order (deterministic).
+#define AEW_DIAG_PARTS 16
+__global__ __launch_bounds__(256) void k_diag_part(const aew_vq_diag_t p) {
+    __shared__ float shf[4][2];
+    __shared__ double shd[4][2];
+    __shared__ int seen[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    float* part = reinterpret_cast<float*>(p.scratch) + b * 16;
+    auto norms = [&](const float* base, int rows, int pitch, int slot) {
+        const int per = (rows + AEW_DIAG_PARTS - 1) / AEW_DIAG_PARTS;
+        const int r_lo = b * per, r_hi = min(rows, r_lo + per);
+        float lo = INFINITY, hi = -INFINITY;
+        const int sub = tid & 7;
+        for (int r0 = r_lo; r0 < r_hi; r0 += 256) {           // 8 lanes per row, 8 rows per thread in flight
+            float ss[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u * 32 + (tid >> 3);
+                const float* x = base + (int64_t)min(r, rows - 1) * pitch;
+                float a = 0.f;
+                if ((p.d & 3) == 0 && (pitch & 3) == 0) {
+                    for (int j = sub * 4; j < p.d; j += 32) {
+                        const float4 v = *reinterpret_cast<const float4*>(x + j);
+                        a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    }
+                } else {
+                    for (int j = sub; j < p.d; j += 8) a += x[j] * x[j];
+                }
+                ss[u] = a;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u * 32 + (tid >> 3);
+                float a = ss[u];
+                a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+                if (r < r_hi) { const float nr = sqrtf(a); lo = fminf(lo, nr); hi = fmaxf(hi, nr); }
+            }
+        }
+        lo = -wave_max(-lo); hi = wave_max(hi);
+        __syncthreads();
+        if (lane == 0) { shf[wv][0] = lo; shf[wv][1] = hi; }
+        __syncthreads();
+        if (tid == 0) {
+            part[slot] = fminf(fminf(shf[0][0], shf[1][0]), fminf(shf[2][0], shf[3][0]));
+            part[slot + 1] = fmaxf(fmaxf(shf[0][1], shf[1][1]), fmaxf(shf[2][1], shf[3][1]));
+        }
+    };
+    if (p.ze) norms(p.ze, p.Q, p.d_pitch, 0);
+    if (p.emb) norms(p.emb, p.K, p.d, 2);
+    if (p.peak && p.amax) {
+        seen[tid] = 0;
+        __syncthreads();
+        const int64_t n_all = (int64_t)p.B * p.w;
+        const int64_t per = (n_all + AEW_DIAG_PARTS - 1) / AEW_DIAG_PARTS;
+        const int64_t i_lo = b * per, i_hi = min(n_all, i_lo + per);
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t i0 = i_lo + tid; i0 < i_hi; i0 += 1024) {
+            float pk[4];
+            int am[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = min(i0 + 256 * u, n_all - 1);
+                pk[u] = p.peak[i]; am[u] = p.amax[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + 256 * u;
+                if (i >= i_hi || (int)(i % p.w) == p.w - 1) continue;
+                const double v = (double)pk[u];
+                s1 += v; s2 += v * v;
+                seen[am[u] & 255] = 1;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        __syncthreads();
+        if (lane == 0) { shd[wv][0] = s1; shd[wv][1] = s2; }
+        __syncthreads();
+        const unsigned long long bits = __ballot(seen[tid] != 0);       // wave wv: classes 64 wv .. 64 wv + 63
+        if (lane == 0) {
+            reinterpret_cast<uint32_t*>(part)[8 + 2 * wv] = (uint32_t)bits;
+            reinterpret_cast<uint32_t*>(part)[9 + 2 * wv] = (uint32_t)(bits >> 32);
+        }
+        if (tid == 0) {
+            double* dp = reinterpret_cast<double*>(part + 4);
+            dp[0] = (shd[0][0] + shd[1][0]) + (shd[2][0] + shd[3][0]);
+            dp[1] = (shd[0][1] + shd[1][1]) + (shd[2][1] + shd[3][1]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p, int parts) {
     __shared__ float shf[16];
     __shared__ double shd[16];
     const int tid = threadIdx.x;
@@ -1260,14 +1355,17 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
             if (p.n_sum && k < p.K) nv[u] = p.n_sum[k];
         }
     }
+    const float* part = reinterpret_cast<const float*>(p.scratch);       // parts > 0: the slices' results (k_diag_part)
     if (p.ze) {
-        float lo, hi;
-        norms(p.ze, p.Q, p.d_pitch, lo, hi);
+        float lo = INFINITY, hi = -INFINITY;
+        if (parts) { if (tid < parts) { lo = part[tid * 16]; hi = part[tid * 16 + 1]; } }
+        else norms(p.ze, p.Q, p.d_pitch, lo, hi);
         o[0] = block_red(lo, false, shf); o[1] = block_red(hi, true, shf);
     }
     if (p.emb) {
-        float lo, hi;
-        norms(p.emb, p.K, p.d, lo, hi);
+        float lo = INFINITY, hi = -INFINITY;
+        if (parts) { if (tid < parts) { lo = part[tid * 16 + 2]; hi = part[tid * 16 + 3]; } }
+        else norms(p.emb, p.K, p.d, lo, hi);
         o[2] = block_red(lo, false, shf); o[3] = block_red(hi, true, shf);
     }
     if (p.hist) {                                             // -sum n log2 n, n = hist / sum(hist); 0 log 0 = 0
@@ -1301,7 +1399,18 @@ __global__ __launch_bounds__(1024) void k_diag_final(const aew_vq_diag_t p) {
         __syncthreads();
         double s1 = 0.0, s2 = 0.0;
         const int64_t n_all = (int64_t)p.B * p.w;
-        if (n_all < (int64_t)1 << 31) {
+        if (parts) {                                          // slice sums in slice order (thread 0), class sets OR-ed
+            if (tid == 0)
+                for (int q = 0; q < parts; ++q) {
+                    const double* dp = reinterpret_cast<const double*>(part + q * 16 + 4);
+                    s1 += dp[0]; s2 += dp[1];
+                }
+            if (tid < 256) {
+                uint32_t w = 0;
+                for (int q = 0; q < parts; ++q) w |= reinterpret_cast<const uint32_t*>(part)[q * 16 + 8 + (tid >> 5)];
+                seen[tid] = (w >> (tid & 31)) & 1;
+            }
+        } else if (n_all < (int64_t)1 << 31) {
             // four positions per thread and pass (loads first), 32-bit index arithmetic; thread t still adds positions
             // t, t + 1024, ... in that order
             const unsigned n32 = (unsigned)n_all, w32 = (unsigned)p.w;
@@ -1478,8 +1587,14 @@ static int launch_vq_stats(const aew_vq_stats_t& p, hipStream_t st) {
     if (p.Q > 0 && p.Q <= 1024 && p.d <= 64 && (int64_t)p.K * p.d >= 16 * (int64_t)p.Q) {
         // few queries, many codes: clear the accumulators, then one wave per query (k_vq_stats_few)
         aew_zero_t z1 = {p.z_sum, (int64_t)p.K * p.d * 4}, z2 = {p.n_sum, (int64_t)p.K * 4};
-        int rc = launch_zero(z1, st);
-        if (rc == 0) rc = launch_zero(z2, st);
+        int rc;
+        if (p.n_sum == p.z_sum + (int64_t)p.K * p.d) {         // the engine allocates them back to back: one launch
+            z1.bytes += z2.bytes;
+            rc = launch_zero(z1, st);
+        } else {
+            rc = launch_zero(z1, st);
+            if (rc == 0) rc = launch_zero(z2, st);
+        }
         if (rc) return rc;
         hipLaunchKernelGGL(k_vq_stats_few, dim3((p.Q + 3) / 4), dim3(256), 0, st, p);
         return (int)hipGetLastError();
@@ -1532,7 +1647,10 @@ static int launch_vq_diag(const aew_vq_diag_t& p, hipStream_t st) {
         const int64_t n_pos = (int64_t)p.B * (p.w - 1);
         hipLaunchKernelGGL(k_diag_peak, dim3((unsigned)min((int64_t)512, cdiv64(n_pos, 16))), dim3(256), 0, st, p);
     }
-    hipLaunchKernelGGL(k_diag_final, dim3(1), dim3(1024), 0, st, p);
+    // codebook norms / per-position statistics in slices first (needs the scratch buffer: 16 floats per slice)
+    const int parts = (p.scratch && !(p.logits && !p.peak) && (p.ze || p.emb || p.peak)) ? AEW_DIAG_PARTS : 0;
+    if (parts) hipLaunchKernelGGL(k_diag_part, dim3(parts), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_diag_final, dim3(1), dim3(1024), 0, st, p, parts);
     return (int)hipGetLastError();
 }
 static int launch_mfcc(const aew_mfcc_t& p, hipStream_t st) {

@@ -242,6 +242,7 @@ class TrainEngine:
         self.diag = ws.alloc("diag.out", 16, torch.float32)              # [0..5] (vqema_bn.py:254-260)
         self.diag_pk = ws.alloc("diag.peak", 16, torch.float32)          # [6..8] (vqema_bn.py:261-263)
         self.diag_scratch = ws.alloc("scratch.diag", 512, torch.float32)
+        self.diag_scratch_pk = ws.alloc("scratch.diag_pk", 512, torch.float32)   # (the two diagnostics ops may overlap on lanes)
         self.met_buf = ws.alloc("diag.metrics", 8, torch.float32)        # [1] rec, [2] tprb_m, [3] com
         if bn in ("vqvae-ema", "vqvae"):
             dv = L.VqDiag()
@@ -268,7 +269,7 @@ class TrainEngine:
             dg = L.VqDiag()
             lgm = self.dec.logits
             dg.logits, dg.bs, dg.pitch, dg.B, dg.w, dg.n_quant = lgm.ptr, lgm.bs, lgm.pitch, B, w, hps.n_quant
-            dg.scratch, dg.out = self.diag_scratch.data_ptr(), self.diag_pk.data_ptr()
+            dg.scratch, dg.out = self.diag_scratch_pk.data_ptr(), self.diag_pk.data_ptr()
             if fused_peak:
                 dg.peak, dg.amax = self.dec.peak_ptrs
             with plan.side(1):

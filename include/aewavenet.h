@@ -376,7 +376,8 @@ typedef struct {                 /* per-step diagnostics of the reference's loss
     const float* n_sum;          /* this step's counts [K]                                     */
     const float* logits; int64_t bs; int32_t pitch;         /* fp32 [B][w][>= n_quant]; u = w-1 is dropped */
     int32_t B, w, n_quant;       /* n_quant <= 256                                             */
-    void* scratch;               /* >= 2 KiB, cleared by the op                                */
+    void* scratch;               /* >= 2 KiB, written by the op (per-slice partial results; with `logits` the
+                                    class bins).  NULL (not with `logits`): one block does everything            */
     float* out;                  /* [12]                                                       */
     const float* peak; const int32_t* amax;   /* instead of `logits`: the per-position arrays aew_softmax_nll_t wrote
                                                  ([B][w], u = w-1 dropped); out[6..8] come from them               */
