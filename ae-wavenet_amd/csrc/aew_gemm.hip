@@ -87,6 +87,17 @@ __device__ __forceinline__ void epi_store(const aew_gemm_nt_t& g, const EpiUni& 
     if (fl & AEW_EF_OUT2_COPY) row_store<W>(R.o2, U.dt_o2, n, v);
 }
 
+// one gated unit from its pre-activations (bias included): z = tanh(f) sigmoid(g) and the two local derivatives
+// dz/dfilt, dz/dgate, all from the fp32 factors (the saturated-tanh factor 1 - a^2 would suffer bf16 cancellation if
+// formed in the backward)
+__device__ __forceinline__ void gated_math(float f, float gt, float& z, float& pf, float& pg) {
+    const float a = tanh_f(f);
+    const float s = sigmoid_f(gt);
+    z = a * s;
+    pf = s * (1.0f - a * a);
+    pg = z * (1.0f - s);
+}
+
 // filt / gate values of the same W channels ch..ch+W-1; np_f = packed column of filt channel ch
 // (the W channels lie inside one 16-channel group, so their packed columns are contiguous)
 // fbias / gbias: the W filt / gate biases of channels ch..ch+W-1 (loaded once per wave by the caller)
@@ -100,13 +111,7 @@ __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& 
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * q + r;
             if (ABL && (g.reserved & 512)) { z[e] = f[e] + fbias[e]; pf[e] = gt[e] + gbias[e]; pg[e] = f[e] - gt[e]; continue; }  // ablation
-            const float a = tanh_f(f[e] + fbias[e]);
-            const float s = sigmoid_f(gt[e] + gbias[e]);
-            // z and the two local derivatives dz/dfilt, dz/dgate, all from the fp32 factors (the
-            // saturated-tanh factor 1-a^2 would suffer bf16 cancellation if formed in backward)
-            z[e] = a * s;
-            pf[e] = s * (1.0f - a * a);
-            pg[e] = z[e] * (1.0f - s);
+            gated_math(f[e] + fbias[e], gt[e] + gbias[e], z[e], pf[e], pg[e]);
         }
     }
     if (ABL && (g.reserved & 256)) {                   // ablation: math but no stores
@@ -192,6 +197,9 @@ __device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n,
 #define AEW_NT_COUNTED 0     /* 1: thin shape with asm fragment reads, counted lgkmcnt waits and hand-placed
                                 MFMA / LDS-DMA order.  Bit-identical, measured null (NT 4.84 vs 4.84 ms per
                                 step), so the compiler-scheduled loop stays the default */
+#endif
+#ifndef AEW_EPI_FAST
+#define AEW_EPI_FAST 1       /* 0: every launch on the general (branchy) epilogue - A/B and bisecting aid, same results */
 #endif
 #ifndef AEW_NT_SETPRIO
 #define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
@@ -407,9 +415,165 @@ __device__ __forceinline__ char* epi_view_row(const EpiViewCtx& c, int j) {
     return (c.p && row >= c.lo && row < c.hi) ? c.p + j * c.inc : nullptr;
 }
 
+// ---- straight-line epilogues (round 4).  The epilogue above is correct and slow: its row loop is full of branches
+// (row / channel masks as `if`, one `if` per runtime flag), and at every control-flow join the compiler's wait-count
+// insertion falls back to `s_waitcnt vmcnt(0)` before the next use of a loaded value (bias registers, the prefetched aux
+// rows) - which, vmcnt being one in-order counter for loads AND stores, also waits for the stores of the previous row
+// group to be acknowledged.  The s_memtime phase clock (tools/phase_clock.py) put 39 % (gated), 41 % (dz), 49 % (dx) and
+// 72 % (residual 1x1) of a block's lifetime into "epilogue issue"; the ISA shows one vmcnt(0) per 16-row group.
+// The forms below have NO branch after their entry test: masked rows / channels store to a sink instead of being skipped,
+// flags act through selects, every load is issued unconditionally (masked ones from the zero region) - the compiler then
+// counts its waits exactly and no store is ever waited for.  They cover the hot configurations (gated, dz, STORE with any
+// of BIAS | RELU | ADD_AUX0 | RELU_POST on bf16 views); everything else takes the general path above.  Same arithmetic,
+// same results.
+__device__ __attribute__((aligned(128))) unsigned int aew_sink[16384];   // 64 KiB, write-only: where masked stores land
+#define AEW_RSV_GENERAL_EPI 4096   /* aew_gemm_nt_t.reserved, set by the launcher under aew_set_epi_fast(0): general path everywhere */
+
+__device__ __forceinline__ void st16(char* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ uint4 pack8_bf16(const float v[8]) {
+    return make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+}
+
+template <int EPI, int MT>
+__device__ __forceinline__ bool nt_epilogue_fast(const aew_gemm_nt_t& g, f32x4_t (&acc)[4][MT], int b, int m0, int n0,
+                                                 int wm, int wn, int lane) {
+    const int fi = lane & 15, fg = lane >> 4;
+    const int mbase = m0 + wm * (16 * MT) + fi;
+    const EpiUni U = epi_uni(g);
+    const unsigned fl = U.fl;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const sink = reinterpret_cast<char*>(aew_sink) + ((blockIdx.x * 8 + wave) & 31) * 2048 + lane * 32;
+    const char* const zr = reinterpret_cast<const char*>(aew_zero_region);
+    constexpr int S = 2 * MT;                                    // steps: (row group j, channel octet u), s = 2 j + u
+    if constexpr (EPI == AEW_EPI_GATED) {
+        const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase), c1 = epi_view_ctx(g.out1, b, mbase), c2 = epi_view_ctx(g.out2, b, mbase);
+        const int ch = ((n0 + wn * 64) >> 1) + 8 * fg;           // first of the lane's 8 channels
+        const bool ch_ok = ch < U.N;
+        const int np_f = (ch >> 4) * 32 + (ch & 15);             // packed column of the filt half
+        const float* bp = g.bias + (int64_t)b * g.bias_bs + np_f;
+        // biases go into the accumulators right away (the same fp32 add the row loop would do): no bias registers stay
+        // live across the row groups (the 128-VGPR shape spilled with them, and a scratch reload is a vmcnt(0) again)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 bf = *reinterpret_cast<const float4*>(bp + 4 * q);
+            const float4 bg = *reinterpret_cast<const float4*>(bp + 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                acc[q][j][0] += bf.x; acc[q][j][1] += bf.y; acc[q][j][2] += bf.z; acc[q][j][3] += bf.w;
+                acc[2 + q][j][0] += bg.x; acc[2 + q][j][1] += bg.y; acc[2 + q][j][2] += bg.z; acc[2 + q][j][3] += bg.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const bool ok = ch_ok && (mbase + j * 16 < g.M);
+            char* p0 = epi_view_row(c0, j);
+            char* p1 = epi_view_row(c1, j);
+            char* p2 = epi_view_row(c2, j);
+            p0 = (ok && p0) ? p0 + ch * 2 : sink;
+            p1 = (ok && p1) ? p1 + ch * 2 : sink;
+            p2 = (ok && p2) ? p2 + ch * 2 : sink;
+            const float f[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3],
+                                acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
+            const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
+                                acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
+            float z[8], pf[8], pg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gated_math(f[e], q[e], z[e], pf[e], pg[e]);
+            st16(p0, pack8_bf16(z));
+            st16(p1, pack8_bf16(pf));
+            st16(p2, pack8_bf16(pg));
+        }
+        return true;
+    } else if constexpr (EPI == AEW_EPI_DFG) {
+        if (U.dt_o0 != AEW_BF16) return false;                   // (wave-uniform)
+        const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase), ca0 = epi_view_ctx(g.aux0, b, mbase), ca1 = epi_view_ctx(g.aux1, b, mbase);
+        uint4 r0[S], r1[S];
+        auto load = [&](int s) {
+            const int j = s >> 1, n = n0 + wn * 64 + (s & 1) * 32 + 8 * fg;
+            const char* a = epi_view_row(ca0, j);
+            const char* c = epi_view_row(ca1, j);
+            r0[s] = *reinterpret_cast<const uint4*>((a ? a : zr) + n * 2);
+            r1[s] = *reinterpret_cast<const uint4*>((c ? c : zr) + n * 2);
+        };
+        constexpr int AHEAD = 2;
+#pragma unroll
+        for (int s = 0; s < AHEAD && s < S; ++s) load(s);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + AHEAD < S) load(s + AHEAD);
+            const int j = s >> 1, u = s & 1, n = n0 + wn * 64 + u * 32 + 8 * fg;
+            const float dz[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
+                                 acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
+            float pf[8], pg[8], df[8], dg[8];
+            unpack8_bf16(r0[s], pf);
+            unpack8_bf16(r1[s], pg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { df[e] = dz[e] * pf[e]; dg[e] = dz[e] * pg[e]; }
+            char* p = epi_view_row(c0, j);
+            const bool ok = p && n < U.N && (mbase + j * 16 < g.M);
+            const int np = (n >> 4) * 32 + (n & 15);               // the 8 channels stay inside one 16-group
+            st16(ok ? p + np * 2 : sink, pack8_bf16(df));
+            st16(ok ? p + (np + 16) * 2 : sink + 16, pack8_bf16(dg));
+        }
+        return true;
+    } else if constexpr (EPI == AEW_EPI_STORE) {
+        constexpr unsigned COVERED = AEW_EF_BIAS | AEW_EF_RELU | AEW_EF_ADD_AUX0 | AEW_EF_RELU_POST;
+        if ((fl & ~COVERED) || U.dt_o0 != AEW_BF16 || ((fl & AEW_EF_ADD_AUX0) && U.dt_a0 != AEW_BF16)) return false;   // (wave-uniform)
+        const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase), ca0 = epi_view_ctx(g.aux0, b, mbase);
+        const bool need0 = fl & AEW_EF_ADD_AUX0;
+        const bool relu_pre = fl & AEW_EF_RELU, relu_post = fl & AEW_EF_RELU_POST;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                            // biases into the accumulators (zeros when the flag is off)
+            const int n = n0 + wn * 64 + u * 32 + 8 * fg;
+            const bool bok = (fl & AEW_EF_BIAS) && n < U.N;
+            const float* bp = bok ? g.bias + (int64_t)b * g.bias_bs + n : reinterpret_cast<const float*>(zr);
+            const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                acc[2 * u][j][0] += b0.x; acc[2 * u][j][1] += b0.y; acc[2 * u][j][2] += b0.z; acc[2 * u][j][3] += b0.w;
+                acc[2 * u + 1][j][0] += b1.x; acc[2 * u + 1][j][1] += b1.y; acc[2 * u + 1][j][2] += b1.z; acc[2 * u + 1][j][3] += b1.w;
+            }
+        }
+        uint4 r0[S];
+        auto load = [&](int s) {
+            const int j = s >> 1, n = n0 + wn * 64 + (s & 1) * 32 + 8 * fg;
+            const char* a = epi_view_row(ca0, j);
+            r0[s] = *reinterpret_cast<const uint4*>(((need0 && a) ? a : zr) + n * 2);
+        };
+        constexpr int AHEAD = 3;
+#pragma unroll
+        for (int s = 0; s < AHEAD && s < S; ++s) load(s);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + AHEAD < S) load(s + AHEAD);
+            const int j = s >> 1, u = s & 1, n = n0 + wn * 64 + u * 32 + 8 * fg;
+            float v[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
+                          acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
+            float a[8];
+            unpack8_bf16(r0[s], a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // the general path's order: + bias, relu, + aux, relu (a flag that is off adds 0 / selects nothing)
+                float t = v[e];
+                t = (relu_pre && !(t > 0.f)) ? 0.f : t;
+                t = t + a[e];
+                v[e] = (relu_post && !(t > 0.f)) ? 0.f : t;
+            }
+            char* p = epi_view_row(c0, j);
+            const bool ok = p && n < U.N && (mbase + j * 16 < g.M);
+            st16(ok ? p + n * 2 : sink, pack8_bf16(v));
+        }
+        return true;
+    }
+    return false;
+}
+
 template <int EPI, bool ABL, int MT>
 __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&acc)[4][MT], int b, int m0, int n0,
                                             int wm, int wn, int lane) {
+    if constexpr (!ABL) {
+        if (AEW_EPI_FAST && !(g.reserved & AEW_RSV_GENERAL_EPI) && nt_epilogue_fast<EPI, MT>(g, acc, b, m0, n0, wm, wn, lane)) return;
+    }
     const int fi = lane & 15, fg = lane >> 4;
     const int mbase = m0 + wm * (16 * MT) + fi;
     // views each epilogue touches: GATED o0 o1 o2 | RES_SKIP o0 o1 o2 a0 | DFG o0 a0 a1 | STORE o0 o1 a0 a1
@@ -519,9 +683,16 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
 // ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved).  It is instantiated
 // in the tools library only (hipcc -DAEW_FN_ABLATE=1 -o lib/libaewavenet_hip_abl.so); the product library has the
 // ABL = false instantiations, which contain none of that code and ignore g.reserved.
-template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM>
+// ST = ring depth.  A K step is bound by the latency of the LDS-DMA stream, not by its volume (tools/membound_probe.py,
+// profiles/r04_notes.md): a block advances one K tile per (DMA latency / tiles in flight), so the default 3 stages (two
+// blocks per CU, 2 x 2 tiles in flight) and a deep ring of one block per CU are different points on the same curve.
+template <int N>
+__device__ __forceinline__ void nt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM, int ST = NT_STAGES>
 __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
     typedef NtCfg<MT, NB, BMV> Cfg;
+    static_assert(ST >= 3 && (ST - 2) * (Cfg::XP + Cfg::WP) <= 63 && ST * Cfg::STAGE_BYTES <= 160 * 1024, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % Cfg::WAVES_N, wm = wave / Cfg::WAVES_N;
@@ -569,7 +740,7 @@ __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>:
     auto advance = [&]() {
         --is.left;
         ++is.issued;
-        is.slot = (is.slot + 1 == NT_STAGES) ? 0 : is.slot + 1;
+        is.slot = (is.slot + 1 == ST) ? 0 : is.slot + 1;
         if (is.left == 0 && !(abl & 128)) {            // wave-uniform and rare: scalar loads only here
             if (is.issued >= nkt) {
                 nt_setup_idle<MT, NB, BMV>(P);
@@ -582,10 +753,11 @@ __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>:
         }
     };
     if (abl & 16) return;                              // launch + pointer setup
-    if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem, wave, P);
-    advance();
-    if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + Cfg::STAGE_BYTES, wave, P);
-    advance();
+#pragma unroll
+    for (int q = 0; q < ST - 1; ++q) {                 // tiles 0 .. ST-2 in flight
+        if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + q * Cfg::STAGE_BYTES, wave, P);
+        advance();
+    }
     const int fi = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (constant over the K loop)
     int woff[4], xoff[MT];
@@ -602,16 +774,14 @@ __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>:
     int stage = 0;
     lap(0);
     for (int t = 0; t < nkt; ++t) {
-        // tile t has landed once at most the loads of tile t+1 (XP + WP per wave) are outstanding
-        if (Cfg::XP + Cfg::WP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (Cfg::XP + Cfg::WP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // tile t has landed once at most the loads of tiles t+1 .. t+ST-2 (XP + WP per wave each) are outstanding
+        nt_wait_vm<(ST - 2) * (Cfg::XP + Cfg::WP)>();
         lap(1);
         if (!(abl & 64)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         lap(2);
         const char* st = smem + stage * Cfg::STAGE_BYTES;
-        stage = (stage + 1 == NT_STAGES) ? 0 : stage + 1;
+        stage = (stage + 1 == ST) ? 0 : stage + 1;
         {
             bf16x8_t wf[4], xf[MT];
             constexpr bool COUNTED = AEW_NT_COUNTED && !ABL && MT == 4;
@@ -643,7 +813,7 @@ __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>:
                 for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(xf[j]));
                 lap(3);
             }
-            // tile t+2 goes into the stage that was computed at step t-1 (every wave is past it: barrier)
+            // tile t+ST-1 goes into the stage that was computed at step t-1 (every wave is past it: barrier)
             if (!COUNTED && !(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
             if constexpr (COUNTED) {
                 // hand-placed: wait for what the group needs, 4 MFMAs, one LDS-DMA piece of tile t+2
@@ -2038,6 +2208,10 @@ static int g_nt_small_n64 = 256;   // ... and as 64 x 64 tiles when the launch h
 static int g_nt_small_w8 = 1;       // ... with 8 waves (16 rows x 64 channels each) instead of 2: the LDS-DMA issue is shared
 static int g_nt_small_deep = 256;   // 64-row launches of <= this many blocks (one per CU) use the 5-stage ring (120 KiB)
 static int g_nt_small_tiles = 128; // default shape: launches of <= this many 256x128 tiles use 64-row tiles
+static int g_nt_mem128 = 0;        // memory-bound plain launches (DFG epilogue, or K_total <= 256) as 128-row tiles: 0 off,
+                                   // 1: 128 x 128 K32 tiles, 4 waves, three blocks per CU; 2: 128 x 128 K64 tiles (p64), two per CU
+static int g_nt_deep = 0;          // deep operand rings, one block per CU (A/B): 1 256 x 128 tiles on 6 stages; 2 256 x 256 tiles (8 fat
+                                   // waves) on 5 stages where N_pad % 256 == 0, else as 1; 3 as 2 but everything else on the defaults
 static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 128 = 4 fat waves (128x64), both on
                                    // 256x128 tiles; 256 = 8 fat waves on 256x256 tiles where N_pad allows
 
@@ -2063,7 +2237,10 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8, 2>), (NtCfg<8, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4>), NT_LDS_BYTES)          \
-    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), (NtCfg<3, 1, 192>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), (NtCfg<3, 1, 192>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4, 1, 128>), (NtCfg<4, 1, 128>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4, 1, 256, 6>), (6 * NtCfg<4, 1, 256>::STAGE_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8, 2, 256, 5>), (5 * NtCfg<8, 2, 256>::STAGE_BYTES))
     AEW_SET_NT(AEW_EPI_STORE)
     AEW_SET_NT(AEW_EPI_GATED)
     AEW_SET_NT(AEW_EPI_RES_SKIP)
@@ -2072,6 +2249,8 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8>), NT_LDS_BYTES)
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 8, 2>), (NtCfg<8, 2>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_GATED, true, 4>), NT_LDS_BYTES)
+    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_STORE, true, 4>), NT_LDS_BYTES)
+    AEW_SET_LDS((k_gemm_nt_bf16<AEW_EPI_DFG, true, 4>), NT_LDS_BYTES)
 #endif
 #undef AEW_SET_NT
     AEW_SET_LDS((k_gemm_nt_f32<1, 7, 0>), (NfCfg<1, 7>::LDS_BYTES))
@@ -2103,7 +2282,17 @@ static bool fn_supported(const aew_gemm_nt_t& g);
 static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st);
 extern int g_fn_enable_flag();
 
+static int g_epi_fast = 1;         // 0: the general epilogue for every launch (aew_set_epi_fast)
+static int launch_gemm_nt_(const aew_gemm_nt_t& g, hipStream_t st);
 static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
+    if (!g_epi_fast && !AEW_FN_ABLATE) {
+        aew_gemm_nt_t a = g;
+        a.reserved |= AEW_RSV_GENERAL_EPI;
+        return launch_gemm_nt_(a, st);
+    }
+    return launch_gemm_nt_(g, st);
+}
+static int launch_gemm_nt_(const aew_gemm_nt_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.M <= 0 || g.batch <= 0 || !g.W) return AEW_E_ARG;
     if (g.W2) {
         // fused gated layer: z tile -> residual 1x1 (see aewavenet.h)
@@ -2180,32 +2369,47 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         // launches that would be a small fraction of one tile wave use 64-row tiles (default shape only)
         const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
         const bool p64r = g_nt_wave_rows == 64 && g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan;
-        const bool p128 = !p64r && g_nt_wave_rows == 0 && zspan;      // 128 x 128 tiles, K tiles of 64
+        // memory-bound launches (the K loop of G2 is 8 steps, dz carries 100 MB of epilogue operands): 128-row tiles, so
+        // that the launch is several tile waves and one block's stores run under another's K loop
+        const bool memb = g_nt_mem128 && g_nt_wave_rows == 64 && !p64r && !win_dwp(g) && zspan &&
+                          (g.epi == AEW_EPI_DFG || (g.epi == AEW_EPI_STORE && g.K_total <= 256));
+        const bool t128 = memb && g_nt_mem128 == 1;
+        const bool p128 = !p64r && (g_nt_wave_rows == 0 || (memb && g_nt_mem128 == 2)) && zspan;      // 128 x 128 tiles, K tiles of 64
         const bool p256 = g_nt_wave_rows == 1 && zspan;      // 256 x 128 tiles, K tiles of 64, one block per CU
         // 192-row tiles (8 waves of 48 x 64) where they shorten the launch.  Blocks spread over the 256 CUs before
         // they double up, and a CU is MFMA-bound with one block already, so a launch costs about
         // ceil(tiles / 256) * rows-per-tile; the 192-row shape is ~5 % less efficient per row (12 MFMAs per wave
         // and K step instead of 16), hence the margin.
         bool t192 = false;
-        if (g_nt_wave_rows == 64 && !p64r && g_nt_rows192) {
+        if (g_nt_wave_rows == 64 && !p64r && g_nt_rows192 && !memb) {
             const int tiles192 = ((g.M + 191) / 192) * g.batch * (g.N_pad / NT_BN);
             const int c256 = ((tiles256 + 255) / 256) * 256, c192 = ((tiles192 + 255) / 256) * 192;
             t192 = g_nt_rows192 == 2 || c192 * 10 < c256 * 9;
         }
-        if (!p64r && g_nt_wave_rows == 64) {                 // both taps of a dilated pair from one LDS window
+        const bool deep2 = (g_nt_deep == 2 || g_nt_deep == 3) && g_nt_wave_rows == 64 && !p64r && !memb && g.N_pad % 256 == 0 &&
+                           !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
+        const bool deep1 = (g_nt_deep == 1 || g_nt_deep == 2) && !deep2 && g_nt_wave_rows == 64 && !p64r && !memb;
+        if (deep1 || deep2) t192 = false;
+        if (!p64r && g_nt_wave_rows == 64 && !deep1 && !deep2) {   // both taps of a dilated pair from one LDS window
             const int dwp = win_dwp(g);
             if (dwp) return launch_win(g, dwp, t192, st);
         }
         // 64 x 64 tiles for launches of very few 64 x 128 blocks (see the p64 kernel's table)
         const bool p64n = p64r && g_nt_small_w8 && g_nt_small_n64 > 0 &&
                           ((g.M + 63) / 64) * g.batch * (g.N_pad / 128) <= g_nt_small_n64;
-        const int bm = p64r ? 64 : (p128 ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : (wide ? 256 : NT_BN));
+        const int bm = p64r ? 64 : ((p128 || t128) ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : ((wide || deep2) ? 256 : NT_BN));
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
 #define AEW_NT_GO(EPI, ABL)                                                                                   \
     do {                                                                                                      \
-        if (!ABL && t192)                                                                                      \
+        if (!ABL && deep2)                                                                                     \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 8, 2, 256, 5>), grid, dim3((NtCfg<8, 2>::THREADS)), (5 * NtCfg<8, 2, 256>::STAGE_BYTES), st, g); \
+        else if (!ABL && deep1)                                                                                \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 4, 1, 256, 6>), grid, dim3((NtCfg<4>::THREADS)), (6 * NtCfg<4, 1, 256>::STAGE_BYTES), st, g); \
+        else if (!ABL && t192)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), grid, dim3((NtCfg<3, 1, 192>::THREADS)), (NtCfg<3, 1, 192>::LDS_BYTES), st, g); \
+        else if (!ABL && t128)                                                                                 \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 4, 1, 128>), grid, dim3((NtCfg<4, 1, 128>::THREADS)), (NtCfg<4, 1, 128>::LDS_BYTES), st, g); \
         else if (!ABL && p64n)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 1, 4, 1, 5>), grid, dim3(256), (5 * P64Cfg<1, 4, 1>::STAGE_BYTES), st, g); \
         else if (!ABL && p64r && (int)grid.x <= g_nt_small_deep && g_nt_small_w8)                              \
@@ -2232,7 +2436,12 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 4>), grid, dim3(NtCfg<4>::THREADS), NT_LDS_BYTES, st, g); \
     } while (0)
         switch (g.epi) {
-            case AEW_EPI_STORE: AEW_NT_GO(AEW_EPI_STORE, false); break;
+            case AEW_EPI_STORE:
+#if AEW_FN_ABLATE
+                if (g.reserved && g_nt_wave_rows == 64) { AEW_NT_GO(AEW_EPI_STORE, true); break; }
+#endif
+                AEW_NT_GO(AEW_EPI_STORE, false);
+                break;
             case AEW_EPI_GATED:
 #if AEW_FN_ABLATE
                 if (g.reserved) { AEW_NT_GO(AEW_EPI_GATED, true); break; }
@@ -2240,7 +2449,12 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
                 AEW_NT_GO(AEW_EPI_GATED, false);
                 break;
             case AEW_EPI_RES_SKIP: AEW_NT_GO(AEW_EPI_RES_SKIP, false); break;
-            case AEW_EPI_DFG: AEW_NT_GO(AEW_EPI_DFG, false); break;
+            case AEW_EPI_DFG:
+#if AEW_FN_ABLATE
+                if (g.reserved && g_nt_wave_rows == 64) { AEW_NT_GO(AEW_EPI_DFG, true); break; }
+#endif
+                AEW_NT_GO(AEW_EPI_DFG, false);
+                break;
             default: return AEW_E_UNSUP;
         }
 #undef AEW_NT_GO

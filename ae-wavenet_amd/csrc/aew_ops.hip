@@ -607,23 +607,27 @@ __global__ void k_spk_bias(const aew_spk_bias_t p) {
 #define AEW_SPK_MAXB 16
 #define AEW_SPK_MAXG 16
 __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
-    // grid (L, 2): one block per (layer, filt|gate); thread = output channel co.
+    // grid (L, 2, ceil(B / 16)): one block per (layer, filt|gate, chunk of 16 batch elements); thread = output channel co.
     //   phase 1: everything a thread needs from global memory is fetched up front (column sums of dfg per batch
     //            element, its row of the speaker projection); it writes its bias / projection gradients and leaves
     //            both vectors in LDS;
     //   phase 2: thread (b, j) sums cs[b][co] * V[co][j] over the channels in ascending order.
     // (Until round 3 phase 2 was B x G cross-lane reductions per wave with LDS atomics - 80 dependent ds_bpermute
     // chains, ~45 us for 40 blocks - and its order depended on the atomics.)
+    // B <= 16 is one chunk: plain stores, deterministic.  Larger batches: the chunks add their bias / projection
+    // partial sums with atomics into the (pre-zeroed) gradient buffer.
     const int l = blockIdx.x, half = blockIdx.y;
+    const int b0 = blockIdx.z * AEW_SPK_MAXB, nb = min(AEW_SPK_MAXB, p.B - b0);
+    const bool multi = gridDim.z > 1;
     const int tid = threadIdx.x;
-    extern __shared__ float sh[];                    // gc [B][G] | cs [B][257] | vs [G][257]
+    extern __shared__ float sh[];                    // gc [nb][G] | cs [nb][257] | vs [G][257]
     float* gcs = sh;
-    float* cs = sh + p.B * p.G;
-    float* vs = cs + p.B * 257;
-    for (int i = tid; i < p.B * p.G; i += blockDim.x) gcs[i] = p.gc[i];
+    float* cs = sh + AEW_SPK_MAXB * p.G;
+    float* vs = cs + AEW_SPK_MAXB * 257;
+    for (int i = tid; i < nb * p.G; i += blockDim.x) gcs[i] = p.gc[b0 * p.G + i];
     const int64_t ob = half ? p.off_bias_gate[l] : p.off_bias_sig[l];
     const int64_t ov0 = half ? p.off_proj_gate[l] : p.off_proj_sig[l];
-    const int pb = p.G > 0 ? tid / p.G : p.B, pj = tid - pb * p.G;   // phase 2: this thread's (batch element, embedding column)
+    const int pb = p.G > 0 ? tid / p.G : nb, pj = tid - pb * p.G;   // phase 2: this thread's (batch element, embedding column)
     float dgc = 0.f;
     __syncthreads();
     for (int co0 = 0; co0 < p.D; co0 += 256) {
@@ -635,19 +639,24 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
         float csv[AEW_SPK_MAXB], vrow[AEW_SPK_MAXG];
 #pragma unroll
         for (int b = 0; b < AEW_SPK_MAXB; ++b)
-            csv[b] = (ok && b < p.B) ? p.colsum[((int64_t)b * p.L + l) * 2 * p.D_pad + n] : 0.f;
+            csv[b] = (ok && b < nb) ? p.colsum[((int64_t)(b0 + b) * p.L + l) * 2 * p.D_pad + n] : 0.f;
 #pragma unroll
         for (int j = 0; j < AEW_SPK_MAXG; ++j) vrow[j] = (ok && j < p.G) ? p.params[ov + j] : 0.f;
-        float bsum = 0.f, prev = 0.f;
+        const bool running = l < p.colsum_running;
+        float bsum = 0.f;
+        float prev = (running && ok && b0 > 0) ? p.colsum[((int64_t)(b0 - 1) * p.L + l) * 2 * p.D_pad + n] : 0.f;
 #pragma unroll
         for (int b = 0; b < AEW_SPK_MAXB; ++b) {
             const float raw = csv[b];
-            if (l < p.colsum_running && b > 0 && b < p.B) csv[b] -= prev;
+            if (running && b0 + b > 0 && b < nb) csv[b] -= prev;
             prev = raw;
             bsum += csv[b];
-            if (b < p.B) cs[b * 257 + tid] = csv[b];
+            if (b < nb) cs[b * 257 + tid] = csv[b];
         }
-        if (ok && ob >= 0) p.grads[ob + co] = bsum;
+        if (ok && ob >= 0) {
+            if (multi) atomicAdd(p.grads + ob + co, bsum);
+            else p.grads[ob + co] = bsum;
+        }
 #pragma unroll
         for (int j = 0; j < AEW_SPK_MAXG; ++j) {
             if (j < p.G) {
@@ -655,12 +664,15 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
                 float gv = 0.f;
 #pragma unroll
                 for (int b = 0; b < AEW_SPK_MAXB; ++b)
-                    if (b < p.B) gv += csv[b] * gcs[b * p.G + j];
-                if (ok) p.grads[ov + j] = gv;
+                    if (b < nb) gv += csv[b] * gcs[b * p.G + j];
+                if (ok) {
+                    if (multi) atomicAdd(p.grads + ov + j, gv);
+                    else p.grads[ov + j] = gv;
+                }
             }
         }
         __syncthreads();
-        if (pb < p.B) {
+        if (pb < nb) {
             const float* c = cs + pb * 257;
             const float* v = vs + pj * 257;
             const int nco = min(256, p.D - co0);
@@ -669,8 +681,8 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
         __syncthreads();
     }
     // speaker embedding grads accumulate over layers -> global atomics (caller zeroes them)
-    if (pb < p.B) {
-        atomicAdd(p.grads + p.off_spk_w + (int64_t)pj * p.n_speakers + p.voice[pb], dgc);
+    if (pb < nb) {
+        atomicAdd(p.grads + p.off_spk_w + (int64_t)pj * p.n_speakers + p.voice[b0 + pb], dgc);
         if (p.off_spk_b >= 0) atomicAdd(p.grads + p.off_spk_b + pj, dgc);
     }
 }
@@ -1624,8 +1636,9 @@ static int launch_spk_bias(const aew_spk_bias_t& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
-    if (p.B > AEW_SPK_MAXB || p.G > AEW_SPK_MAXG) return AEW_E_UNSUP;
-    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2), dim3(256), (p.B * p.G + (p.B + p.G) * 257) * sizeof(float), st, p);
+    if (p.G > AEW_SPK_MAXG || p.B < 1) return AEW_E_UNSUP;     // (engine.DecoderPlan refuses such a model at build time)
+    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2, (p.B + AEW_SPK_MAXB - 1) / AEW_SPK_MAXB), dim3(256),
+                       (AEW_SPK_MAXB * p.G + (AEW_SPK_MAXB + p.G) * 257) * sizeof(float), st, p);
     return (int)hipGetLastError();
 }
 static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {

@@ -252,6 +252,9 @@ extern "C" int aew_sampler_run(const aew_sampler_t* s, void* stream) {
     return launch_sampler(*s, reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int aew_set_nt_rows192(int mode) { g_nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
+extern "C" int aew_set_nt_mem128(int mode) { g_nt_mem128 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
+extern "C" int aew_set_nt_deep(int mode) { g_nt_deep = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return 0; }
+extern "C" int aew_set_epi_fast(int on) { g_epi_fast = on ? 1 : 0; return 0; }
 extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n; return 0; }
 extern "C" int aew_set_nf_loaders(int on) { g_nf_loaders = on ? 1 : 0; return 0; }
 extern "C" int aew_set_nf_deep(int max_blocks) { g_nf_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }

@@ -217,20 +217,26 @@ class DecoderPlan:
                               # independent blocks per CU reach 43 GB/s together
     wgrad_split_layers = 0    # with grouped wgrads: the TOP this-many layers keep one split-K TN op per matrix (they run
                               # under the dgrad chain and fill its tile-wave tails), the rest go to the grouped launch
+    ups_split_rows = 1024     # upsampler / lc-conv weight gradients (few output tiles): contractions longer than this many
+                              # rows x batch are cut into 512-row chunks (one block and one slab each) in the grouped launch
     split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
                               # measured slower (8.86 vs 8.62 ms/step): half-batch launches lose more than the
                               # overlap of their tails returns
 
     def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, pre: str,
                  n_lc_in: int, lc_src: Mat, wav: torch.Tensor, voice: torch.Tensor,
-                 jitter: torch.Tensor, take_compat: bool, packer: Packer, impl: int = 0):
+                 jitter: torch.Tensor, take_compat: bool, packer: Packer, impl: int = 0,
+                 wgrad_group: Optional[int] = None):
         self.ws, self.ps, self.hps, self.g, self.B, self.pre = ws, ps, hps, geom, B, pre
         self.impl = impl
         import os as _os
         if _os.environ.get("AEW_FN_OPS") is not None:          # A/B aid: comma list, "" = none
             self.fn_ops = frozenset(v for v in _os.environ["AEW_FN_OPS"].split(",") if v)
-        if _os.environ.get("AEW_WGRAD_GROUP") is not None:     # A/B aid: layers per grouped wgrad launch, 0 = off
-            self.wgrad_group = int(_os.environ["AEW_WGRAD_GROUP"])
+        if wgrad_group is not None:                            # resolved once by TrainEngine (argument, else AEW_WGRAD_GROUP,
+            self.wgrad_group = int(wgrad_group)                # else the class default) and shared with the EncoderPlan
+        if hps.n_global_embed > 16:
+            # k_spk_bwd holds a layer's speaker-projection row in registers (AEW_SPK_MAXG)
+            raise ValueError(f"n_global_embed = {hps.n_global_embed}: the speaker-gradient kernel supports at most 16")
         self.gmul_ptr = ws.bufs["loss.gmul"].data_ptr() if "loss.gmul" in ws.bufs else 0
         self.n_lc_in = n_lc_in
         self.lc_src, self.wav, self.voice, self.jitter = lc_src, wav, voice, jitter
@@ -833,17 +839,19 @@ class DecoderPlan:
         n_ups = len(hps.lc_upsample_strides)
         ugrp = TnGroupBuilder(self.ws, p + "tng_ups", 128) if grouped else None     # upsampler + LC-conv wgrads: one launch
 
-        def wgrad_ups(name, Mc, N, N_pad, gseg, segs, bias_grad=0):
+        def wgrad_ups(name, Mc, N, N_pad, gseg, segs, bias_grad=0, gmat=None):
             """One or a few output tiles with up to 8 x 1780 rows to contract: cut into chunks of ~512 rows (one block
             and one slab each) unless the whole contraction is that short (then the column-sum by-product is available)."""
             if ugrp is None:
                 return self._wgrad(plan, name, BF, Mc, N, N_pad, gseg, segs, TAG_UPS)
             t = make_tn(BF, Mc, B, N, N_pad, gseg, segs)
-            split = Mc * B > 1024
+            split = Mc * B > self.ups_split_rows
             if not split:
                 t.colsum_out = bias_grad or None
             elif bias_grad:
-                raise NotImplementedError("bias gradient of a split grouped descriptor")
+                # a split descriptor has no block that sees every row: the bias gradient (column sums of the G
+                # operand) comes from a column-sum op, as in the ungrouped plan
+                self._colsum(plan, gmat, Mc, N, bias_grad, label="db." + name)
             slabs = ugrp.set_split(t, 512) if split else 1
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, slabs)
             t.out, t.out_batch_stride = ptr, stride
@@ -873,7 +881,7 @@ class DecoderPlan:
             self._colsum(plan, dlc1, lc1.rows, Clc, ps.ptr(p + "lc_conv.bias", True), label="db.lc")
         nin = self.n_lc_in
         gp, gs, gn = wgrad_ups("lc", lc1.rows, Clc, Cp, dlc1.seg(Cp), [self.lcj.seg(Lp, row_off=t) for t in range(3)],
-                               bias_grad=ps.ptr(p + "lc_conv.bias", True) if has_lb else 0)
+                               bias_grad=ps.ptr(p + "lc_conv.bias", True) if has_lb else 0, gmat=dlc1)
         if ugrp is not None:
             with plan.side(self._next_lane("tng")):
                 ugrp.emit(plan, "wgrad.group (upsamplers, lc conv)", TAG_UPS)
@@ -905,8 +913,9 @@ class EncoderPlan:
 
     def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, n_mel: int,
                  mel_cl: Mat, packer: Packer, impl: int = 0, in_tbl: Optional[CopyTableBuilder] = None,
-                 in_mel: Optional[torch.Tensor] = None):
+                 in_mel: Optional[torch.Tensor] = None, wgrad_group: Optional[int] = None):
         self.ws, self.ps, self.hps, self.g, self.B, self.impl = ws, ps, hps, geom, B, impl
+        self.wgrad_group = DecoderPlan.wgrad_group if wgrad_group is None else int(wgrad_group)
         self.pk = packer
         self.n_mel, self.Mp, self.Mb = n_mel, ru(n_mel, 64), ru(n_mel, 128)
         self.E, self.Ep, self.Eb = hps.enc_n_out, ru(hps.enc_n_out, 64), ru(hps.enc_n_out, 128)
@@ -977,7 +986,7 @@ class EncoderPlan:
         # grouped mode (DecoderPlan.wgrad_group): the nine weight gradients as ONE launch after the dgrad chain (each
         # contracts over 8 x 29..70 rows: nine launches of a few microseconds of work each otherwise), the bias
         # gradients as its column-sum by-product
-        grp = TnGroupBuilder(self.ws, "enc.tng", 128) if (DecoderPlan.wgrad_group > 0 and impl == 0) else None
+        grp = TnGroupBuilder(self.ws, "enc.tng", 128) if (self.wgrad_group > 0 and impl == 0) else None
         for i in range(8, -1, -1):
             f, s, res = G.ENCODER_FILTERS[i], G.ENCODER_STRIDES[i], G.ENCODER_RESIDUAL[i]
             X = self.yb[i]

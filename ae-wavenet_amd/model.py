@@ -43,13 +43,21 @@ class TrainEngine:
 
     def __init__(self, hps, B: int, device, n_mel: Optional[int] = None, loss_mode: str = "intended",
                  take_compat: bool = False, update_codebook_every_step: bool = True, impl: int = 0,
-                 n_win: Optional[int] = None, use_graphs: bool = True):
+                 n_win: Optional[int] = None, use_graphs: Optional[bool] = None, wgrad_group: Optional[int] = None):
         self.hps, self.B, self.impl = hps, B, impl
         _SERIAL[0] += 1
         self.serial = _SERIAL[0]          # unique per engine (id() can be recycled after garbage collection)
         self.weights_version = 0          # bumped by adam_step(): FusedAdam writes parameters by raw pointer
-        # AEW_USE_GRAPHS=0: plans run eagerly (stream launches) instead of as captured hipGraphs (A/B aid)
-        self.use_graphs = use_graphs if os.environ.get("AEW_USE_GRAPHS") is None else os.environ["AEW_USE_GRAPHS"] == "1"
+        # plans run as captured hipGraphs unless told otherwise.  An explicit constructor argument wins; the environment
+        # (AEW_USE_GRAPHS=0: eager stream launches, AEW_WGRAD_GROUP=n: layers per grouped wgrad launch, 0 = round 2's one
+        # op per matrix) only supplies the default of an argument left at None (A/B and bisecting aid).
+        if use_graphs is None:
+            use_graphs = os.environ.get("AEW_USE_GRAPHS", "1") == "1"
+        self.use_graphs = bool(use_graphs)
+        if wgrad_group is None:
+            wgrad_group = int(os.environ["AEW_WGRAD_GROUP"]) if os.environ.get("AEW_WGRAD_GROUP") is not None \
+                else DecoderPlan.wgrad_group
+        self.wgrad_group = int(wgrad_group)
         self.kind = hps.global_model
         self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
         self.loss_mode, self.take_compat = loss_mode, take_compat
@@ -105,13 +113,13 @@ class TrainEngine:
         self.enc: Optional[EncoderPlan] = None
         if with_enc:
             self.enc = EncoderPlan(ws, ps, hps, g, B, self.n_mel, self.mel_cl, self.pk, impl, in_tbl=self.in_tbl,
-                                   in_mel=self.in_mel)
+                                   in_mel=self.in_mel, wgrad_group=self.wgrad_group)
             self._alloc_bottleneck()
             lc_src = self.code
         else:
             lc_src = self.mel_cl
         self.dec = DecoderPlan(ws, ps, hps, g, B, dec_pre, hps.n_lc_in, lc_src, self.in_wav, self.in_voice,
-                               self.in_jitter, take_compat, self.pk_dec, impl)
+                               self.in_jitter, take_compat, self.pk_dec, impl, wgrad_group=self.wgrad_group)
         self.dec.unpack_early_tbl = CopyTableBuilder(ws, "tbl.unpack_dec_early")
         self._build()
         self.adam_state = None

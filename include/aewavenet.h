@@ -532,6 +532,20 @@ int aew_set_fn_ring3(int min_k_tiles);   /* plain full-N GEMMs of >= this many 6
  * 1 k_gemm_nt_bf16_p64 (64-row tiles, small launches), 2 k_fn, 3 k_gemm_nt_f32, 4 the scalar check kernel, 5 an A/B
  * shape.  Measurement aid: lets a caller group per-op times by kernel the way a rocprofv3 kernel trace does. */
 int aew_nt_kernel(const aew_gemm_nt_t* g);
+/* Default shape only: memory-bound plain launches (DFG epilogue, or K_total <= 256: wavenet.py:103-109 and the backward of
+ * :100-102) as 128-row tiles - 0 the 256- / 192-row tiles, 1 128 x 128 tiles with K tiles of 32 (4 waves, three blocks
+ * per CU), 2 128 x 128 tiles with K tiles of 64 (two blocks per CU).  Bit-identical results. */
+int aew_set_nt_mem128(int mode);
+/* Default shape only (A/B): deep operand rings at one block per CU - 1 256 x 128 tiles on a 6-stage ring, 2 256 x 256
+ * tiles (8 waves of 128 x 64) on a 5-stage ring where N_pad % 256 == 0 and as 1 elsewhere, 3 as 2 with every other launch
+ * on its default kernel.  0 (default) off.  Same results as the kernel each launch replaces, up to the order in which the
+ * one-window kernel interleaves its taps. */
+int aew_set_nt_deep(int mode);
+/* bf16 MFMA NT kernels: 1 (default) the straight-line epilogues for the hot configurations (gated, dz, STORE with BIAS /
+ * RELU / ADD_AUX0 / RELU_POST on bf16 views: no branch in the row loop, so no store is ever waited for), 0 the general
+ * epilogue for every launch.  Same results; A/B and bisecting aid (a captured graph keeps the setting it was captured
+ * under). */
+int aew_set_epi_fast(int on);
 /* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
 int aew_set_nt_small_tiles(int n);
 /* ... and of those, launches of <= max_blocks blocks (default 256: one block per CU) run a 5-stage operand ring

@@ -193,6 +193,50 @@ def test_gemm_nt(dtype, epi):
         assert torch.equal(results[0]["O0"], results[1]["O0"])
 
 
+@pytest.mark.parametrize("epi", [L.EPI_DFG, "g2"])
+def test_gemm_nt_mem128(epi):
+    """The 128-row tile forms of the memory-bound launches (aew_set_nt_mem128: dz with its DFG epilogue, wavenet.py:100-102
+    backward, and the K = 256 residual 1x1 + add, wavenet.py:108-109) are bit-identical to the 256-row tiles."""
+    gen = torch.Generator().manual_seed(3)
+    ws_c = Workspace("cpu")
+    _alloc_nt(ws_c, BF, L.EPI_STORE)
+    for n in ("A1", "A2", "X0", "X1", "O1", "bias"):
+        _fill(ws_c, n, gen)
+    _fill(ws_c, "W", gen, 0.08)
+    lib = L.load()
+
+    def case(ws):
+        if epi == L.EPI_DFG:
+            return _nt_case(ws, BF, L.EPI_DFG, 0)
+        A2 = Mat(ws, "A2", 2, 400, 256, BF)
+        Wm = Mat(ws, "W", 1, 256, 256, BF)
+        O0 = Mat(ws, "O0", 2, 320, 512, BF)
+        X0 = Mat(ws, "X0", 2, 320, 256, BF)
+        return make_nt(BF, 300, 248, 256, 2, [A2.seg(256, row_off=-5)], Wm.ptr, flags=L.EF_ADD_AUX0,
+                       out0=O0.view(row_off=3), aux0=X0.view(row_off=-2), impl=0)
+    ref = None
+    try:
+        lib.aew_set_nt_small_tiles(0)
+        for mode, deep in ((0, 0), (1, 0), (2, 0), (0, 1), (0, 2)):     # deep: the deep-ring A/B shapes (aew_set_nt_deep)
+            lib.aew_set_nt_mem128(mode)
+            lib.aew_set_nt_deep(deep)
+            ws_g = _mirror(ws_c, DEV)
+            p = Plan("nt")
+            p.add(L.OP_GEMM_NT, case(ws_g), "nt")
+            p.run(stream())
+            torch.cuda.synchronize()
+            res = ws_g.get("O0").float().cpu()
+            if ref is None:
+                ref = res
+                assert float(ref.abs().max()) > 0
+            else:
+                assert torch.equal(res, ref), ("mem128 mode", mode, "deep", deep)
+    finally:
+        lib.aew_set_nt_mem128(0)
+        lib.aew_set_nt_deep(0)
+        lib.aew_set_nt_small_tiles(128)
+
+
 def _win_case(ws, kind, d, impl):
     """The two shapes the decoder runs on the window kernel: the gated layer (wavenet.py:100-101: x[t], x[t+d] of one
     tensor + the conditioning projection) and its input gradient (dfg[t], dfg[t-d], rows outside dfg read as zero)."""

@@ -320,3 +320,40 @@ def test_copy_table_interleave_form_addresses_the_same_elements():
             ([1, 6, 44, 2], [0, 88, 2, 1], [0, 176, 1, 44], 0, 0, L.F32, L.BF16)]        # bf16 planes need multiples of 8
     for dims, ss, ds, sp, dp, a, b in none:
         assert CopyTableBuilder._interleave_form(dims, ss, ds, sp, dp, a, b, 1, False) is None
+
+
+def test_split_grouped_descriptor_keeps_its_bias_gradient(monkeypatch):
+    """Round-3 ADVICE: with lc rows x B > 1024 the lc-conv weight gradient becomes a SPLIT grouped descriptor, which has
+    no block that sees every row and therefore no column-sum by-product; the bias gradient must then come from a
+    column-sum op (it raised NotImplementedError).  Grouped plan == one-op-per-matrix plan on every gradient."""
+    monkeypatch.setitem(PL.TORCH_DT, L.BF16, torch.float32)
+    monkeypatch.setitem(PL.ESIZE, L.BF16, 4)
+    from ae_wavenet_amd import engine as E
+    B, n_win = 3, 2500
+    monkeypatch.setattr(E.DecoderPlan, "ups_split_rows", 16)            # (1024 in production: reached at B = 16, w = 20000)
+    hps = config.make_hps("mi", n_res=8, n_dil=8, n_skp=8, n_post=8, n_lc_out=8, n_global_embed=2, n_speakers=3,
+                          n_blocks=1, n_block_layers=2, n_win_batch=n_win, n_lc_in=4)
+    gen = torch.Generator().manual_seed(5)
+    grads = {}
+    for grp in (64, 0):
+        eng = M.TrainEngine(hps, B=B, device="cpu", n_mel=4, wgrad_group=grp)
+        assert eng.dec.ups_in[0].rows * B > 16
+        assert "db.lc" in eng.bwd.labels
+        gen.manual_seed(5)
+        for k in eng.ps.names():
+            eng.ps.view(k).copy_(torch.randn(eng.ps.shape[k], generator=gen) * 0.3)
+        g = eng.geom
+        wav = torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float()
+        mel = torch.randn(B, 4, g.mel_len, generator=gen)
+        voice = torch.randint(0, 3, (B,), generator=gen)
+        jitter = torch.arange(g.embed_len).repeat(B, 1)
+        eng.set_inputs(wav, mel, voice, jitter)
+        emu = Emu(eng.ws)
+        for p in (eng.fwd_a, eng.fwd_b, eng.bwd):
+            emu.run(p)
+        grads[grp] = {k: eng.ps.view(k, grad=True).clone() for k in eng.ps.names()}
+    for k, ref in grads[0].items():
+        got = grads[64][k]
+        scale = max(float(ref.abs().max()), 1e-20)
+        assert float((got - ref).abs().max()) / scale < 2e-4, k
+    assert float(grads[64]["wavenet.lc_conv.bias"].abs().max()) > 0

@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256}
+DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0, "epi_fast": 1}
 
 
 def main():
