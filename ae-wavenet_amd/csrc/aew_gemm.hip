@@ -198,9 +198,6 @@ __device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n,
                                 MFMA / LDS-DMA order.  Bit-identical, measured null (NT 4.84 vs 4.84 ms per
                                 step), so the compiler-scheduled loop stays the default */
 #endif
-#ifndef AEW_EPI_FAST
-#define AEW_EPI_FAST 1       /* 0: every launch on the general (branchy) epilogue - A/B and bisecting aid, same results */
-#endif
 #ifndef AEW_NT_SETPRIO
 #define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
 #endif
@@ -415,165 +412,15 @@ __device__ __forceinline__ char* epi_view_row(const EpiViewCtx& c, int j) {
     return (c.p && row >= c.lo && row < c.hi) ? c.p + j * c.inc : nullptr;
 }
 
-// ---- straight-line epilogues (round 4).  The epilogue above is correct and slow: its row loop is full of branches
-// (row / channel masks as `if`, one `if` per runtime flag), and at every control-flow join the compiler's wait-count
-// insertion falls back to `s_waitcnt vmcnt(0)` before the next use of a loaded value (bias registers, the prefetched aux
-// rows) - which, vmcnt being one in-order counter for loads AND stores, also waits for the stores of the previous row
-// group to be acknowledged.  The s_memtime phase clock (tools/phase_clock.py) put 39 % (gated), 41 % (dz), 49 % (dx) and
-// 72 % (residual 1x1) of a block's lifetime into "epilogue issue"; the ISA shows one vmcnt(0) per 16-row group.
-// The forms below have NO branch after their entry test: masked rows / channels store to a sink instead of being skipped,
-// flags act through selects, every load is issued unconditionally (masked ones from the zero region) - the compiler then
-// counts its waits exactly and no store is ever waited for.  They cover the hot configurations (gated, dz, STORE with any
-// of BIAS | RELU | ADD_AUX0 | RELU_POST on bf16 views); everything else takes the general path above.  Same arithmetic,
-// same results.
-__device__ __attribute__((aligned(128))) unsigned int aew_sink[16384];   // 64 KiB, write-only: where masked stores land
-#define AEW_RSV_GENERAL_EPI 4096   /* aew_gemm_nt_t.reserved, set by the launcher under aew_set_epi_fast(0): general path everywhere */
-
-__device__ __forceinline__ void st16(char* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
-__device__ __forceinline__ uint4 pack8_bf16(const float v[8]) {
-    return make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-}
-
-template <int EPI, int MT>
-__device__ __forceinline__ bool nt_epilogue_fast(const aew_gemm_nt_t& g, f32x4_t (&acc)[4][MT], int b, int m0, int n0,
-                                                 int wm, int wn, int lane) {
-    const int fi = lane & 15, fg = lane >> 4;
-    const int mbase = m0 + wm * (16 * MT) + fi;
-    const EpiUni U = epi_uni(g);
-    const unsigned fl = U.fl;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* const sink = reinterpret_cast<char*>(aew_sink) + ((blockIdx.x * 8 + wave) & 31) * 2048 + lane * 32;
-    const char* const zr = reinterpret_cast<const char*>(aew_zero_region);
-    constexpr int S = 2 * MT;                                    // steps: (row group j, channel octet u), s = 2 j + u
-    if constexpr (EPI == AEW_EPI_GATED) {
-        const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase), c1 = epi_view_ctx(g.out1, b, mbase), c2 = epi_view_ctx(g.out2, b, mbase);
-        const int ch = ((n0 + wn * 64) >> 1) + 8 * fg;           // first of the lane's 8 channels
-        const bool ch_ok = ch < U.N;
-        const int np_f = (ch >> 4) * 32 + (ch & 15);             // packed column of the filt half
-        const float* bp = g.bias + (int64_t)b * g.bias_bs + np_f;
-        // biases go into the accumulators right away (the same fp32 add the row loop would do): no bias registers stay
-        // live across the row groups (the 128-VGPR shape spilled with them, and a scratch reload is a vmcnt(0) again)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float4 bf = *reinterpret_cast<const float4*>(bp + 4 * q);
-            const float4 bg = *reinterpret_cast<const float4*>(bp + 16 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                acc[q][j][0] += bf.x; acc[q][j][1] += bf.y; acc[q][j][2] += bf.z; acc[q][j][3] += bf.w;
-                acc[2 + q][j][0] += bg.x; acc[2 + q][j][1] += bg.y; acc[2 + q][j][2] += bg.z; acc[2 + q][j][3] += bg.w;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const bool ok = ch_ok && (mbase + j * 16 < g.M);
-            char* p0 = epi_view_row(c0, j);
-            char* p1 = epi_view_row(c1, j);
-            char* p2 = epi_view_row(c2, j);
-            p0 = (ok && p0) ? p0 + ch * 2 : sink;
-            p1 = (ok && p1) ? p1 + ch * 2 : sink;
-            p2 = (ok && p2) ? p2 + ch * 2 : sink;
-            const float f[8] = {acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3],
-                                acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
-            const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
-                                acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-            float z[8], pf[8], pg[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gated_math(f[e], q[e], z[e], pf[e], pg[e]);
-            st16(p0, pack8_bf16(z));
-            st16(p1, pack8_bf16(pf));
-            st16(p2, pack8_bf16(pg));
-        }
-        return true;
-    } else if constexpr (EPI == AEW_EPI_DFG) {
-        if (U.dt_o0 != AEW_BF16) return false;                   // (wave-uniform)
-        const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase), ca0 = epi_view_ctx(g.aux0, b, mbase), ca1 = epi_view_ctx(g.aux1, b, mbase);
-        uint4 r0[S], r1[S];
-        auto load = [&](int s) {
-            const int j = s >> 1, n = n0 + wn * 64 + (s & 1) * 32 + 8 * fg;
-            const char* a = epi_view_row(ca0, j);
-            const char* c = epi_view_row(ca1, j);
-            r0[s] = *reinterpret_cast<const uint4*>((a ? a : zr) + n * 2);
-            r1[s] = *reinterpret_cast<const uint4*>((c ? c : zr) + n * 2);
-        };
-        constexpr int AHEAD = 2;
-#pragma unroll
-        for (int s = 0; s < AHEAD && s < S; ++s) load(s);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s + AHEAD < S) load(s + AHEAD);
-            const int j = s >> 1, u = s & 1, n = n0 + wn * 64 + u * 32 + 8 * fg;
-            const float dz[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
-                                 acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
-            float pf[8], pg[8], df[8], dg[8];
-            unpack8_bf16(r0[s], pf);
-            unpack8_bf16(r1[s], pg);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { df[e] = dz[e] * pf[e]; dg[e] = dz[e] * pg[e]; }
-            char* p = epi_view_row(c0, j);
-            const bool ok = p && n < U.N && (mbase + j * 16 < g.M);
-            const int np = (n >> 4) * 32 + (n & 15);               // the 8 channels stay inside one 16-group
-            st16(ok ? p + np * 2 : sink, pack8_bf16(df));
-            st16(ok ? p + (np + 16) * 2 : sink + 16, pack8_bf16(dg));
-        }
-        return true;
-    } else if constexpr (EPI == AEW_EPI_STORE) {
-        constexpr unsigned COVERED = AEW_EF_BIAS | AEW_EF_RELU | AEW_EF_ADD_AUX0 | AEW_EF_RELU_POST;
-        if ((fl & ~COVERED) || U.dt_o0 != AEW_BF16 || ((fl & AEW_EF_ADD_AUX0) && U.dt_a0 != AEW_BF16)) return false;   // (wave-uniform)
-        const EpiViewCtx c0 = epi_view_ctx(g.out0, b, mbase), ca0 = epi_view_ctx(g.aux0, b, mbase);
-        const bool need0 = fl & AEW_EF_ADD_AUX0;
-        const bool relu_pre = fl & AEW_EF_RELU, relu_post = fl & AEW_EF_RELU_POST;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                            // biases into the accumulators (zeros when the flag is off)
-            const int n = n0 + wn * 64 + u * 32 + 8 * fg;
-            const bool bok = (fl & AEW_EF_BIAS) && n < U.N;
-            const float* bp = bok ? g.bias + (int64_t)b * g.bias_bs + n : reinterpret_cast<const float*>(zr);
-            const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                acc[2 * u][j][0] += b0.x; acc[2 * u][j][1] += b0.y; acc[2 * u][j][2] += b0.z; acc[2 * u][j][3] += b0.w;
-                acc[2 * u + 1][j][0] += b1.x; acc[2 * u + 1][j][1] += b1.y; acc[2 * u + 1][j][2] += b1.z; acc[2 * u + 1][j][3] += b1.w;
-            }
-        }
-        uint4 r0[S];
-        auto load = [&](int s) {
-            const int j = s >> 1, n = n0 + wn * 64 + (s & 1) * 32 + 8 * fg;
-            const char* a = epi_view_row(ca0, j);
-            r0[s] = *reinterpret_cast<const uint4*>(((need0 && a) ? a : zr) + n * 2);
-        };
-        constexpr int AHEAD = 3;
-#pragma unroll
-        for (int s = 0; s < AHEAD && s < S; ++s) load(s);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s + AHEAD < S) load(s + AHEAD);
-            const int j = s >> 1, u = s & 1, n = n0 + wn * 64 + u * 32 + 8 * fg;
-            float v[8] = {acc[2 * u][j][0], acc[2 * u][j][1], acc[2 * u][j][2], acc[2 * u][j][3],
-                          acc[2 * u + 1][j][0], acc[2 * u + 1][j][1], acc[2 * u + 1][j][2], acc[2 * u + 1][j][3]};
-            float a[8];
-            unpack8_bf16(r0[s], a);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                // the general path's order: + bias, relu, + aux, relu (a flag that is off adds 0 / selects nothing)
-                float t = v[e];
-                t = (relu_pre && !(t > 0.f)) ? 0.f : t;
-                t = t + a[e];
-                v[e] = (relu_post && !(t > 0.f)) ? 0.f : t;
-            }
-            char* p = epi_view_row(c0, j);
-            const bool ok = p && n < U.N && (mbase + j * 16 < g.M);
-            st16(ok ? p + n * 2 : sink, pack8_bf16(v));
-        }
-        return true;
-    }
-    return false;
-}
-
+// (Round 4, measured and removed: the row loop below compiles to one `s_waitcnt vmcnt(0)` per 16-row group - its masks
+// and flags are branches, and at a control-flow join the compiler's wait-count insertion gives up counting - so every
+// group also waits for the stores of the one before.  A branch-free form of the gated / dz / STORE epilogues (masked
+// stores into a sink, flags as selects: counted waits only, no store ever waited for; commit ae1bb12) changed nothing:
+// 6.995 vs 6.968 ms per step.  The epilogue is bound by what it moves, not by how its instructions wait:
+// tools/phase_clock.py, tools/overlap_probe.py, profiles/r04_notes.md.)
 template <int EPI, bool ABL, int MT>
 __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&acc)[4][MT], int b, int m0, int n0,
                                             int wm, int wn, int lane) {
-    if constexpr (!ABL) {
-        if (AEW_EPI_FAST && !(g.reserved & AEW_RSV_GENERAL_EPI) && nt_epilogue_fast<EPI, MT>(g, acc, b, m0, n0, wm, wn, lane)) return;
-    }
     const int fi = lane & 15, fg = lane >> 4;
     const int mbase = m0 + wm * (16 * MT) + fi;
     // views each epilogue touches: GATED o0 o1 o2 | RES_SKIP o0 o1 o2 a0 | DFG o0 a0 a1 | STORE o0 o1 a0 a1
@@ -2282,17 +2129,7 @@ static bool fn_supported(const aew_gemm_nt_t& g);
 static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st);
 extern int g_fn_enable_flag();
 
-static int g_epi_fast = 1;         // 0: the general epilogue for every launch (aew_set_epi_fast)
-static int launch_gemm_nt_(const aew_gemm_nt_t& g, hipStream_t st);
 static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
-    if (!g_epi_fast && !AEW_FN_ABLATE) {
-        aew_gemm_nt_t a = g;
-        a.reserved |= AEW_RSV_GENERAL_EPI;
-        return launch_gemm_nt_(a, st);
-    }
-    return launch_gemm_nt_(g, st);
-}
-static int launch_gemm_nt_(const aew_gemm_nt_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.M <= 0 || g.batch <= 0 || !g.W) return AEW_E_ARG;
     if (g.W2) {
         // fused gated layer: z tile -> residual 1x1 (see aewavenet.h)

@@ -83,7 +83,7 @@ static int g_lanes = 0;
 static std::vector<hipEvent_t> g_lane_ev;
 static size_t g_lane_ev_next = 0;
 
-extern "C" int aew_set_lanes(int on) { g_lanes = on ? 1 : 0; return 0; }
+extern "C" int aew_set_lanes(int on) { g_lanes = on < 0 ? 0 : (on > 2 ? 2 : on); return 0; }   // 2: lanes 4, 5 only (independent chains)
 
 static hipEvent_t lane_event() {
     const size_t POOL = 64;
@@ -118,7 +118,7 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
         hipStream_t target = st;
         const int lane = ops[i].lane;
         if (lane < 0 || lane > AEW_MAX_SIDE) { rc = AEW_E_ARG; if (fail_index) *fail_index = i; break; }
-        if (lanes && lane >= 1) {
+        if (lanes && lane >= (g_lanes == 2 ? 4 : 1)) {
             if (!g_side[lane]) {
                 hipError_t e = hipStreamCreateWithFlags(&g_side[lane], hipStreamNonBlocking);
                 if (e != hipSuccess) { rc = (int)e; break; }
@@ -254,7 +254,6 @@ extern "C" int aew_sampler_run(const aew_sampler_t* s, void* stream) {
 extern "C" int aew_set_nt_rows192(int mode) { g_nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_mem128(int mode) { g_nt_mem128 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_deep(int mode) { g_nt_deep = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return 0; }
-extern "C" int aew_set_epi_fast(int on) { g_epi_fast = on ? 1 : 0; return 0; }
 extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n; return 0; }
 extern "C" int aew_set_nf_loaders(int on) { g_nf_loaders = on ? 1 : 0; return 0; }
 extern "C" int aew_set_nf_deep(int max_blocks) { g_nf_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }

@@ -518,7 +518,10 @@ class DecoderPlan:
             P_l = lg.out_len
             for c in range(n_chains):
                 b0 = c * nb
-                plan.lane = 1 if c == 1 else 0
+                # two chains: BOTH on side lanes (4 and 5: the ones aew_set_lanes(2) honours alone).  A side op is ordered after every main-lane op emitted before
+                # it, so a chain left on the main lane would hold the other one back at every layer; with no main-lane op
+                # between the first layer and the skip sum the two lanes run free
+                plan.lane = (4 + c) if n_chains > 1 else 0
                 segs = [x.seg(Rp, b0=b0), x.seg(Rp, row_off=lg.dil, b0=b0),
                         self.cond.seg(Cp, row_off=lg.cond_lead, b0=b0)]
                 sfx = f".c{c}" if n_chains > 1 else ""
@@ -535,7 +538,7 @@ class DecoderPlan:
                 plan.add(L.OP_GEMM_NT, make_nt(
                     BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, impl=self._impl("G1"), **gkw),
                     f"G1.{l}" + sfx, TAG_G1,
-                    join=g1_join if (l == 0 and c == 0) else False)   # x[0] and the gated biases come from the side lane
+                    join=(True if n_chains > 1 else g1_join) if l == 0 else False)   # x[0] and the gated biases come from the side lane
                 if not last:
                     # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
                     plan.add(L.OP_GEMM_NT, make_nt(

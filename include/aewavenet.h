@@ -541,11 +541,6 @@ int aew_set_nt_mem128(int mode);
  * on its default kernel.  0 (default) off.  Same results as the kernel each launch replaces, up to the order in which the
  * one-window kernel interleaves its taps. */
 int aew_set_nt_deep(int mode);
-/* bf16 MFMA NT kernels: 1 (default) the straight-line epilogues for the hot configurations (gated, dz, STORE with BIAS /
- * RELU / ADD_AUX0 / RELU_POST on bf16 views: no branch in the row loop, so no store is ever waited for), 0 the general
- * epilogue for every launch.  Same results; A/B and bisecting aid (a captured graph keeps the setting it was captured
- * under). */
-int aew_set_epi_fast(int on);
 /* Default shape only: bf16 NT launches of <= n 256x128 tiles use 64x128 tiles instead (0 = never). */
 int aew_set_nt_small_tiles(int n);
 /* ... and of those, launches of <= max_blocks blocks (default 256: one block per CU) run a 5-stage operand ring

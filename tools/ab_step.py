@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0, "epi_fast": 1}
+DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0}
 
 
 def main():
@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
     ap.add_argument("--per-op", dest="per_op", action="append", default=[])
     ap.add_argument("--out", default=None, help="directory for the per-op tables")
+    ap.add_argument("--plan", default=None, help="time ONE plan of the engine (fwd_a | fwd_b | bwd | opt) instead of the step")
     args = ap.parse_args()
     import torch
     from ae_wavenet_amd import _lib as L, autoencoder_model as ae, config, engine as E
@@ -94,6 +95,9 @@ def main():
 
     def step():
         eng = cur[0]
+        if args.plan:
+            eng._run(getattr(eng, args.plan), False)
+            return
         eng.forward()
         eng.backward()
         eng.adam_step(1e-4, 1.0)
