@@ -314,6 +314,11 @@ class TnGroupBuilder:
         gp = L.GemmTNGroup()
         gp.descs, gp.tile_map, gp.n_descs, gp.n_blocks = dt.data_ptr(), mt.data_ptr(), len(self.descs), len(tm)
         gp.tile = self.tile
+        # host copy of the descriptors by op label (tools/op_roofline.py prices the group from them; the launcher only
+        # sees the device table)
+        if not hasattr(plan, "tn_groups"):
+            plan.tn_groups = {}
+        plan.tn_groups[label] = list(self.descs)
         return plan.add(L.OP_GEMM_TN_GROUP, gp, label, tag, join=join)
 
 

@@ -56,7 +56,11 @@ class _StepFn(torch.autograd.Function):
         if prev is not None:
             eng = owner._engine
             eng.ps.grads[:eng.ps.numel].add_(prev)
-        return torch.zeros_like(owner._anchor), None
+        # (the anchor's "gradient": a cached zero, not a fill kernel per step)
+        z = getattr(owner, "_anchor_zero", None)
+        if z is None or z.device != owner._anchor.device:
+            z = owner._anchor_zero = torch.zeros_like(owner._anchor)
+        return z, None
 
 
 class Objective:

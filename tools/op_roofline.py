@@ -51,6 +51,28 @@ def tn_cost(t):
     return 2.0 * rows * t.N_pad * t.K_total, a + gb + out
 
 
+def tn_group_cost(descs):
+    """A grouped launch: FLOPs of every descriptor; least bytes two ways - every distinct operand buffer of the group
+    read ONCE (the x of a layer is the A operand of its fg matrix at two row offsets and the dx of the next layer the G
+    operand of the residual matrix: one read each if the group's tiles marched in step), and every segment of every
+    descriptor read once (what a launch per matrix would have to move at least)."""
+    fl = once = every = 0.0
+    seen = set()
+    for t in descs:
+        rows = t.Mc * t.batch
+        fl += 2.0 * rows * t.N_pad * t.K_total
+        out = t.N_pad * t.K_total * 4 * max(1, t.grp_splits * t.batch if t.grp_splits > 0 else 1)
+        once += out
+        every += out
+        for ptr, width in [(t.g.ptr, t.N_pad)] + [(t.seg[i].ptr, t.seg[i].k_len) for i in range(t.n_segs)]:
+            b = rows * width * ES[t.dtype]
+            every += b
+            if ptr not in seen:
+                seen.add(ptr)
+                once += b
+    return fl, once, every
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "..", "profiles", "r01_per_op_ms.txt")
     ms = collections.OrderedDict()
@@ -61,12 +83,16 @@ def main():
     hps = config.make_hps("vqvae-ema", n_win_batch=5000, n_batch=8)
     eng = M.TrainEngine(hps, B=8, device="cpu", n_mel=39)
     groups = collections.OrderedDict()
+    extra = {}
     for plan in (eng.fwd_a, eng.fwd_b, eng.bwd):
         for op, lab in zip(plan.ops, plan.labels):
             if op.kind == L.OP_GEMM_NT:
                 fl, by = nt_cost(op.u.nt)
             elif op.kind == L.OP_GEMM_TN:
                 fl, by = tn_cost(op.u.tn)
+            elif op.kind == L.OP_GEMM_TN_GROUP and lab in getattr(plan, "tn_groups", {}):
+                fl, by, every = tn_group_cost(plan.tn_groups[lab])
+                extra[re.sub(r"\d+", "#", lab)] = every
             else:
                 continue
             if lab not in ms:
@@ -74,13 +100,17 @@ def main():
             key = re.sub(r"\d+", "#", lab)
             g = groups.setdefault(key, [0.0, 0.0, 0.0, 0])
             g[0] += fl; g[1] += by; g[2] += ms[lab]; g[3] += 1
-    print(f"{'op group':18s} {'n':>3s} {'ms':>7s} {'TFLOP/s':>8s} {'of 2500':>8s} {'TB/s':>6s} {'of 8':>6s}  bound")
+    print(f"{'op group':44s} {'n':>3s} {'ms':>7s} {'TFLOP/s':>8s} {'of 2500':>8s} {'TB/s':>6s} {'of 8':>6s}  bound")
     for k, (fl, by, t, n) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
         if t <= 0:
             continue
         tf, tb = fl / t / 1e9, by / t / 1e9
         bound = "HBM" if tb / 8.0 > tf / 2500.0 else "MFMA"
-        print(f"{k:18s} {n:3d} {t:7.3f} {tf:8.0f} {tf / 2500:8.1%} {tb:6.2f} {tb / 8:6.1%}  {bound}")
+        note = ""
+        if k in extra:
+            note = (f"   (grouped launch: {by / 1e9:.2f} GB with every operand buffer read once, {extra[k] / 1e9:.2f} GB with every "
+                    f"segment of every matrix read once = {extra[k] / t / 1e9:.2f} TB/s)")
+        print(f"{k[:44]:44s} {n:3d} {t:7.3f} {tf:8.0f} {tf / 2500:8.1%} {tb:6.2f} {tb / 8:6.1%}  {bound}{note}")
 
 
 if __name__ == "__main__":
