@@ -114,7 +114,7 @@ class SpkBwd(C.Structure):
                 ("off_proj_sig", vp), ("off_proj_gate", vp), ("off_spk_w", i64),
                 ("off_spk_b", i64), ("B", i32), ("L", i32), ("D", i32), ("D_pad", i32),
                 ("C_lc", i32), ("G", i32), ("n_speakers", i32), ("colsum", vp), ("gc", vp),
-                ("grads", vp), ("colsum_running", i32), ("pad_", i32)]
+                ("grads", vp), ("colsum_running", i32), ("layer_range", i32)]
 
 
 class BaseGather(C.Structure):
@@ -276,7 +276,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 15:
+    if lib.aew_abi_version() != 16:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib

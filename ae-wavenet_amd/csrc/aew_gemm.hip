@@ -12,6 +12,7 @@
 // lane's 4 accumulator registers are 4 consecutive CHANNELS of one row: channels-last stores
 // are then 8/16-byte vectors.
 #include "aew_common.h"
+#include <atomic>
 
 // =============================================================================================
 // epilogues: W consecutive channels n..n+W-1 of one output row (W = 8 in the bf16 MFMA kernel,
@@ -2064,8 +2065,11 @@ static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 
 
 // kernels using more than 64 KiB of dynamic LDS must opt in once per process
 static int ensure_big_lds() {
-    static int done = 0;
-    if (done) return 0;
+    static std::atomic<unsigned long long> done{0};               // one bit per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long dev_bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & dev_bit) return 0;
     hipError_t e;
 #define AEW_SET_LDS(fn, bytes)                                                                       \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
@@ -2112,7 +2116,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16_grp, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_big_grp, TNB_LDS_BYTES)
 #undef AEW_SET_LDS
-    done = 1;
+    done.fetch_or(dev_bit, std::memory_order_release);
     return 0;
 }
 

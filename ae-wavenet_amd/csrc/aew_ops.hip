@@ -616,7 +616,7 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
     // chains, ~45 us for 40 blocks - and its order depended on the atomics.)
     // B <= 16 is one chunk: plain stores, deterministic.  Larger batches: the chunks add their bias / projection
     // partial sums with atomics into the (pre-zeroed) gradient buffer.
-    const int l = blockIdx.x, half = blockIdx.y;
+    const int l = blockIdx.x + (p.layer_range & 0xffff), half = blockIdx.y;     // (layer_range = 0: first layer 0)
     const int b0 = blockIdx.z * AEW_SPK_MAXB, nb = min(AEW_SPK_MAXB, p.B - b0);
     const bool multi = gridDim.z > 1;
     const int tid = threadIdx.x;
@@ -1637,7 +1637,9 @@ static int launch_spk_bias(const aew_spk_bias_t& p, hipStream_t st) {
 }
 static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
     if (p.G > AEW_SPK_MAXG || p.B < 1) return AEW_E_UNSUP;     // (engine.DecoderPlan refuses such a model at build time)
-    hipLaunchKernelGGL(k_spk_bwd, dim3(p.L, 2, (p.B + AEW_SPK_MAXB - 1) / AEW_SPK_MAXB), dim3(256),
+    const int l0 = p.layer_range & 0xffff, ln = p.layer_range ? (p.layer_range >> 16) & 0x7fff : p.L;
+    if (ln < 1 || l0 + ln > p.L) return AEW_E_ARG;
+    hipLaunchKernelGGL(k_spk_bwd, dim3(ln, 2, (p.B + AEW_SPK_MAXB - 1) / AEW_SPK_MAXB), dim3(256),
                        (AEW_SPK_MAXB * p.G + (AEW_SPK_MAXB + p.G) * 257) * sizeof(float), st, p);
     return (int)hipGetLastError();
 }

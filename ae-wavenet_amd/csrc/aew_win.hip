@@ -262,15 +262,18 @@ static int win_dwp(const aew_gemm_nt_t& g) {
 
 template <int EPI, int MT, int DWP>
 static int win_launch(const aew_gemm_nt_t& g, hipStream_t st) {
-    static int attr_done = 0;
+    static std::atomic<unsigned long long> attr_done{0};          // one bit per device (function attributes are per device)
     typedef WinCfg<MT, DWP> Cfg;
     constexpr int lds = Cfg::LDS_BYTES;
     static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
-    if (!attr_done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {      // (racing threads both set it: harmless)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16_win<EPI, MT, DWP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = 1;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int row_tiles = ((g.M + Cfg::BM - 1) / Cfg::BM) * g.batch;
     dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / NT_BN));

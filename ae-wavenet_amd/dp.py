@@ -224,14 +224,21 @@ class DataParallel:
         """Backward with the sharded gradient exchange issued as the regions become final: decoder tail (reduce-scatter
         under the bottleneck / encoder backward), then the head.  optimizer_step() completes it."""
         n, lo = eng.ps.numel, eng.dec_grad_offset
+        hi = getattr(eng, "dec_hi_offset", None)       # engines with two grouped wgrad launches: [hi, n) is final first
         flat = eng.ps.grads
-        st = {}
+        st = {"hi": hi}
+
+        def after_decoder_hi():
+            st["dec_hi"] = self._reduce_region(flat, hi, n, bf16_grads)
 
         def after_decoder():
-            st["dec"] = self._reduce_region(flat, lo, n, bf16_grads)
+            st["dec"] = self._reduce_region(flat, lo, n if "dec_hi" not in st else hi, bf16_grads)
 
         self.allreduce_kl(eng)
-        eng.backward(after_decoder=after_decoder)
+        if hi is not None:
+            eng.backward(after_decoder=after_decoder, after_decoder_hi=after_decoder_hi)
+        else:
+            eng.backward(after_decoder=after_decoder)
         if "dec" not in st:
             after_decoder()
         st["head"] = self._reduce_region(flat, 0, lo, bf16_grads) if lo > 0 else ([], [])
@@ -241,11 +248,19 @@ class DataParallel:
         """Sharded Adam + all-gather of the updated parameters (left in flight: finish() before the next forward)."""
         n, lo = eng.ps.numel, eng.dec_grad_offset
         st, self._st = self._st, None
+        pend, counted, dec_end = [], True, n
+        if "dec_hi" in st:                               # the upper layers' region: reduced under the rest of the chain
+            for w in st["dec_hi"][0]:
+                self._wait(w, "grads.decoder_hi")
+            for f in st["dec_hi"][1]:
+                f()
+            pend += self._update_region(eng, st["hi"], n, lr, grad_scale, True, adam_kw)
+            counted, dec_end = False, st["hi"]
         for w in st["dec"][0]:
             self._wait(w, "grads.decoder")
         for f in st["dec"][1]:
             f()
-        pend = self._update_region(eng, lo, n, lr, grad_scale, True, adam_kw)      # decoder shards; all-gather in flight
+        pend += self._update_region(eng, lo, dec_end, lr, grad_scale, counted, adam_kw)   # decoder shards; all-gather in flight
         for w in st["head"][0]:
             self._wait(w, "grads.encoder")
         for f in st["head"][1]:
@@ -269,13 +284,19 @@ class DataParallel:
         self.backward_exchange(eng, bf16_grads)
         self.optimizer_step(eng, lr, grad_scale, **adam_kw)
 
+    @staticmethod
+    def _regions(eng):
+        """The regions of the flat buffer the sharded schedule exchanges separately (each has its own shard layout):
+        [upper decoder layers + post network |] decoder | encoder + bottleneck."""
+        n, lo, hi = eng.ps.numel, eng.dec_grad_offset, getattr(eng, "dec_hi_offset", None)
+        return [(hi, n), (lo, hi), (0, lo)] if hi is not None else [(lo, n), (0, lo)]
+
     def gather_moments(self, eng):
         """All-gather the Adam moments (each rank holds valid moments for its own shards only under the sharded step).
         COLLECTIVE: every rank must call it."""
         if self.world == 1:
             return
-        n, lo = eng.ps.numel, eng.dec_grad_offset
-        for a, b in ((lo, n), (0, lo)):
+        for a, b in self._regions(eng):
             s, rem = self._split(a, b)
             if s > 0:
                 for buf in (eng.adam_m, eng.adam_v):

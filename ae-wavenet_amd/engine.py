@@ -657,6 +657,15 @@ class DecoderPlan:
         grp: Optional[TnGroupBuilder] = None
         n_groups = 0
         tail_descs = []                                        # (name, descriptor): join the last group
+        # Several groups (wgrad_group < NL; data parallel: AEW_WGRAD_GROUP=NL/2): the post-network and skip weight
+        # gradients - operands complete before the chain starts - join the FIRST group instead of the last, and their
+        # results are unpacked with it.  Every gradient from layer NL - wgrad_group up (the tail of the flat buffer,
+        # `hi_first_layer`) is then final right after "unpack grads (decoder, upper layers)": a data-parallel caller
+        # starts its reduce-scatter there, under the second half of the chain (TrainEngine.bwd_a1 / bwd_a2).
+        multi = grouped and self.wgrad_group < NL
+        self.hi_first_layer = NL - self.wgrad_group if (multi and early_tbl is not None and snap_ok) else None
+        self._spk_hi_from = None
+        layers_in_grp = 0
 
         def group_add(name, t, tag):
             nonlocal grp
@@ -675,9 +684,11 @@ class DecoderPlan:
             if not grouped:
                 return self._wgrad(plan, name, dtype, Mc, N, N_pad, gseg, segs, tag) + (pk.unpack_tbl,)
             t = make_tn(dtype, Mc, B, N, N_pad, gseg, segs)
+            t.colsum_out = bias_grad or None
+            if multi and name != "base":                       # (the base layer's needs dx of layer 0: last group)
+                return group_add(name, t, tag) + (pk.unpack_tbl,)
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
             t.out, t.out_batch_stride = ptr, stride
-            t.colsum_out = bias_grad or None
             tail_descs.append((name, t))
             self.gbuf[name] = (ptr, stride, 1)
             return ptr, stride, 1, late_tbl
@@ -703,6 +714,14 @@ class DecoderPlan:
         plan.add(L.OP_GEMM_NT, make_nt(BF, w, Sp, Sp, B, [self.dh1.seg(Pp)], self.Wp1T.ptr,
                                        flags=L.EF_MUL_POS1, out0=self.dskp.view(), aux1=self.h0.view(),
                                        impl=impl), "d.post1", TAG_POST)
+        skp = None
+        if multi:
+            # skip weights of all layers (see below) into the first group: dskp and every z exist already
+            skp = wgrad_late("skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
+                             [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
+            for l in range(NL):
+                pk.rec(p + f"conv_layers.{l}.dil_skp.weight", 0, [D, 1], [S, D], None, 0, [NL * Dp, 1],
+                       g_ptr=skp[0], slabs=skp[2], slab_stride=skp[1], g_off=l * Dp)
         # ---- gated stack, last layer first
         Kfg = 2 * Rp + Cp
         Cc = Clc + self.Gc
@@ -761,13 +780,27 @@ class DecoderPlan:
                            None, row0 * Kfg, [32 * Kfg, Kfg, 1, Rp], g_ptr=gp, slabs=gn, slab_stride=gs)
                     pk.rec(q + f"proj_{nm}.weight", co0 * Cc, [16 * Cc, Cc, 1], [ng, gl, Clc],
                            None, row0 * Kfg + 2 * Rp, [32 * Kfg, Kfg, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
-            if grouped and grp is not None and len(grp.descs) >= 2 * self.wgrad_group - 1 and l > 0:
-                # (2 descriptors per layer, the last layer has no res: a full group holds wgrad_group layers)
+            if grouped and l < NL - self.wgrad_split_layers:
+                layers_in_grp += 1
+            if grouped and grp is not None and layers_in_grp >= self.wgrad_group and l > 0:
+                layers_in_grp = 0
                 with plan.side(self._next_lane("tng")):
-                    grp.emit(plan, f"wgrad.group{n_groups} (layers {l}..{l + (len(grp.descs) + 1) // 2 - 1})", TAG_WG_FG)
+                    grp.emit(plan, f"wgrad.group{n_groups} (layers {l}.., skip, post)" if n_groups == 0 else
+                             f"wgrad.group{n_groups} (layers {l}..)", TAG_WG_FG)
                 grp = None
                 n_groups += 1
                 if early_tbl is not None:
+                    if multi and snap_ok:
+                        # gated-bias / speaker-projection gradients of the layers in this group (from the running column
+                        # sums it just wrote): everything of layers >= l is final after the unpack below
+                        sb_hi = L.SpkBwd()
+                        self._fill_spk(sb_hi)
+                        sb_hi.colsum, sb_hi.gc, sb_hi.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
+                        sb_hi.colsum_running = NL
+                        sb_hi.layer_range = l | ((NL - l) << 16)
+                        self._spk_hi_from = l
+                        with plan.side(1):
+                            plan.add(L.OP_SPK_BWD, sb_hi, "spk_bwd (upper layers)", TAG_MISC, join=True)
                     with plan.side(1):                             # the first group's gradients: unpacked mid-chain
                         early_tbl.emit(plan, "unpack grads (decoder, upper layers)", join=True)
                     pk.unpack_tbl = late_tbl
@@ -801,21 +834,23 @@ class DecoderPlan:
         gp_b, gs_b, gn_b, _tbl = wgrad_late("base", BF, T, R, Rp, dx0.seg(Rp), [self.onehot.seg(Qp)], TAG_MISC,
                                             bias_grad=ps.ptr(p + "base_layer.bias", True) if has_bb else 0)
         pk.rec(p + "base_layer.weight", 0, [Q, 1], [R, Q], None, 0, [Qp, 1], g_ptr=gp_b, slabs=gn_b, slab_stride=gs_b)
-        gp, gs, gn, _tbl = wgrad_late("skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
-                                      [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
+        if skp is None:
+            gp, gs, gn, _tbl = wgrad_late("skp_all", BF, w, S, Sp, self.dskp.seg(Sp),
+                                          [self.z[l].seg(Dp, row_off=g.layers[l].skip_lead) for l in range(NL)], TAG_WG_RS)
         if grouped:
             for name, t in tail_descs:
                 if grp is None:
                     grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
                 grp.add(t, "wgrad." + name)
             with plan.side(self._next_lane("tng")):
-                grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)", TAG_WG_FG)
+                grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)" if not multi else
+                         f"wgrad.group{n_groups} (layers 0.., base)", TAG_WG_FG)
             grp = None
             if early_tbl is not None:                              # a single group: nothing was unpacked mid-chain
                 pk.unpack_tbl = late_tbl
                 late_tbl.recs.extend(early_tbl.recs)
                 early_tbl = None
-        for l in range(NL):
+        for l in range(NL if skp is None else 0):
             pk.rec(p + f"conv_layers.{l}.dil_skp.weight", 0, [D, 1], [S, D], None, 0, [NL * Dp, 1],
                    g_ptr=gp, slabs=gn, slab_stride=gs, g_off=l * Dp)
         # ---- conditioning gradient over all layers' dfg (wavenet.py:100-101 cond terms).  With split_multiseg the
@@ -835,6 +870,8 @@ class DecoderPlan:
         self._fill_spk(sbw)
         sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
         sbw.colsum_running = max(0, NL - self.wgrad_split_layers) if snap_ok else 0
+        if getattr(self, "_spk_hi_from", None):                    # the upper layers were done after the first group
+            sbw.layer_range = 0 | (self._spk_hi_from << 16)
         with plan.side(1):                                         # reads the side lanes' wgrad slabs: side join
             colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
             plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)

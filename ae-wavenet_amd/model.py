@@ -414,6 +414,23 @@ class TrainEngine:
         self.bwd_a, self.bwd_b = Plan("bwd_a"), Plan("bwd_b")
         self.bwd_a.ops, self.bwd_a.labels = bw.ops[:cut], bw.labels[:cut]
         self.bwd_b.ops, self.bwd_b.labels = bw.ops[cut:], bw.labels[cut:]
+        # ... and, with the stack's weight gradients as two grouped launches (wgrad_group < layers, e.g. AEW_WGRAD_GROUP=10),
+        # bwd_a itself in two: after bwd_a1 every gradient from layer `hi_first_layer` up (+ the post network: the tail of
+        # the flat buffer from dec_hi_offset) is final, so that exchange starts under the second half of the chain
+        self.bwd_a1 = self.bwd_a2 = None
+        self.dec_hi_offset = None
+        hi = getattr(self.dec, "hi_first_layer", None)
+        lab_hi = "unpack grads (decoder, upper layers)"
+        if hi is not None and lab_hi in bw.labels[:cut]:
+            c1 = bw.labels.index(lab_hi) + 1
+            self.bwd_a1, self.bwd_a2 = Plan("bwd_a1"), Plan("bwd_a2")
+            self.bwd_a1.ops, self.bwd_a1.labels = bw.ops[:c1], bw.labels[:c1]
+            self.bwd_a2.ops, self.bwd_a2.labels = bw.ops[c1:cut], bw.labels[c1:cut]
+            self.dec_hi_offset = min(ps.off[n] for n in ps.names() if n.startswith(self.dec.pre + f"conv_layers.{hi}."))
+            later = [n for n in ps.names() if ps.off[n] >= self.dec_hi_offset]
+            assert all(n.startswith(self.dec.pre + "post") or
+                       (n.startswith(self.dec.pre + "conv_layers.") and int(n[len(self.dec.pre) + 12:].split(".")[0]) >= hi)
+                       for n in later), "layers >= hi and the post network form the tail of the flat buffer"
         dec_names = [n for n in ps.names() if n.startswith(self.dec.pre)]
         self.dec_grad_offset = min(ps.off[n] for n in dec_names)
         assert all(ps.off[n] >= self.dec_grad_offset for n in dec_names) and \
@@ -578,15 +595,24 @@ class TrainEngine:
         else:
             self.gmul[:1].fill_(float(g))
 
-    def backward(self, timing=False, after_decoder=None):
+    def backward(self, timing=False, after_decoder=None, after_decoder_hi=None):
         """after_decoder: optional callback invoked between the decoder part of the backward (all
-        decoder gradients final in ps.grads[dec_grad_offset:]) and the bottleneck / encoder part."""
+        decoder gradients final in ps.grads[dec_grad_offset:]) and the bottleneck / encoder part.
+        after_decoder_hi: optional callback invoked as soon as ps.grads[dec_hi_offset:] is final (engines built with two
+        grouped weight-gradient launches only: dec_hi_offset is not None)."""
         if after_decoder is None or not self.bwd_b.ops:
             self._run(self.bwd, timing)
+            if after_decoder_hi is not None and self.dec_hi_offset is not None:
+                after_decoder_hi()
             if after_decoder is not None:
                 after_decoder()
         else:
-            self._run(self.bwd_a, timing)
+            if after_decoder_hi is not None and self.bwd_a1 is not None:
+                self._run(self.bwd_a1, timing)
+                after_decoder_hi()
+                self._run(self.bwd_a2, timing)
+            else:
+                self._run(self.bwd_a, timing)
             after_decoder()
             self._run(self.bwd_b, timing)
         self.finish_ema(timing)

@@ -104,4 +104,9 @@ class FusedAdam(torch.optim.Optimizer):
         # the backward plan rewrites the flat gradient buffer: "cleared" is a flag the next backward reads (no memset;
         # without it the next backward adds to the existing .grad like any torch module, surface._grads_carried)
         self.model._grads_cleared = True
+        if set_to_none:
+            # like torch: nothing that looks at .grad between zero_grad() and the next backward sees last step's values
+            # (the backward re-attaches the views into the flat gradient buffer, surface._after_backward)
+            for p in self.model.parameters():
+                p.grad = None
         return None

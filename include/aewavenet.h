@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 15
+#define AEW_ABI_VERSION 16
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -314,7 +314,10 @@ typedef struct {                 /* backward of the above from per-batch column 
     float* grads;                /* flat fp32 gradient buffer (same offsets as params)        */
     int32_t colsum_running;      /* layers l < colsum_running: colsum[b][l] holds the sum over batch elements 0..b
                                     (aew_gemm_tn_t.snap_out); the per-batch value is colsum[b] - colsum[b-1]  */
-    int32_t pad_;
+    int32_t layer_range;         /* 0: all L layers.  Else first layer | count << 16: this op covers layers [first, first +
+                                    count) only (data parallel with two grouped wgrad launches: the upper layers' bias /
+                                    projection gradients right after the first group; the speaker-embedding sums of the
+                                    parts add up in `grads`)                                                       */
 } aew_spk_bwd_t;
 
 typedef struct {                 /* base layer as a column gather (wavenet.py:348-351)        */

@@ -374,7 +374,9 @@ class Emu:
         gc = self.rd(p.gc, torch.arange(p.B * p.G)).view(p.B, p.G)
         pi = self._pack_idx(p.D)
         dgc = torch.zeros(p.B, p.G)
-        for l in range(p.L):
+        l0 = p.layer_range & 0xffff
+        ln = (p.layer_range >> 16) if p.layer_range else p.L
+        for l in range(l0, l0 + ln):
             for gate, ob, ov in ((0, obs[l], ops_[l]), (1, obg[l], opg[l])):
                 c = cs[:, l, pi + 16 * gate]                                   # B,D
                 if ob >= 0:

@@ -157,14 +157,19 @@ def _global_batch(eng_geom, n_mel, world, seed=3):
     return wav, mel, voice, jitter
 
 
-def _real_worker(rank, world, port, bn, q):
+def _real_worker(rank, world, port, bn, q, wg=None):
     from tests.plan_emulator import emulate
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         hps = _tiny(bn)
-        eng = emulate(M.TrainEngine(hps, B=1, device="cpu", n_mel=5))
+        eng = emulate(M.TrainEngine(hps, B=1, device="cpu", n_mel=5, wgrad_group=wg))
+        if wg is not None:
+            # two grouped weight-gradient launches: the upper layer's region is exchanged on its own, after bwd_a1
+            assert eng.dec_hi_offset is not None and eng.dec_grad_offset < eng.dec_hi_offset < eng.ps.numel
+            assert eng.bwd_a1.labels[-1] == "unpack grads (decoder, upper layers)" and "spk_bwd (upper layers)" in eng.bwd_a1.labels
+            assert len(eng.bwd_a1.ops) + len(eng.bwd_a2.ops) == len(eng.bwd_a.ops)
         d = dp.DataParallel()
         d.prepare_vae(eng)
         batch = _global_batch(eng.geom, 5, world)
@@ -194,7 +199,7 @@ def _real_worker(rank, world, port, bn, q):
                          eng.emb.numpy().copy() if eng.bn_type == "vqvae-ema" else None)    # numpy: pickled by value
         ref = None
         if rank == 0:                                             # the same two steps in ONE process, global batch
-            one = emulate(M.TrainEngine(hps, B=world, device="cpu", n_mel=5))
+            one = emulate(M.TrainEngine(hps, B=world, device="cpu", n_mel=5))      # (one grouped launch, one region)
             _seed_engine(one)
             one.set_inputs(*batch, eps=eps_all)
             if bn == "vae":
@@ -209,17 +214,21 @@ def _real_worker(rank, world, port, bn, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bn,world", [("vqvae-ema", 2), ("ae", 2), ("vqvae-ema", 3), ("vae", 2)])
-def test_dp_real_steps_match_single_process_global_batch(bn, world):
+@pytest.mark.parametrize("bn,world,wg", [("vqvae-ema", 2, None), ("ae", 2, None), ("vqvae-ema", 3, None), ("vae", 2, None),
+                                         ("vqvae-ema", 2, 1), ("vqvae-ema", 3, 1)])
+def test_dp_real_steps_match_single_process_global_batch(bn, world, wg):
     """Sum-type loss (VQ-VAE-EMA: summed gradients, one codebook from summed EMA statistics) and mean-type loss (AE:
     the optimizer scales the summed gradient by 1 / world): N ranks with one window each == one process with all N.
     world = 3: shards that do not divide the regions (the replicated remainder), a ring that is not a power of two.
     VAE (vae_bn.py:90-116): mean-type NLL + the KL SUM over all windows of the global batch behind a free-nats clamp - the
-    gate has to see the global KL (one scalar all-reduce) and the KL gradient must not be divided by world."""
+    gate has to see the global KL (one scalar all-reduce) and the KL gradient must not be divided by world.
+    wg = 1: the engines of the ranks emit the stack's weight gradients as TWO grouped launches (AEW_WGRAD_GROUP) and the
+    sharded schedule exchanges three regions - the upper layer's as soon as bwd_a1 has run; same parameters, moments and
+    codebook as the single process with its one launch."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_real_worker, args=(r, world, port, bn, q)) for r in range(world)]
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, bn, q, wg)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])

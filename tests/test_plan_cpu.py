@@ -204,7 +204,19 @@ def test_grouped_wgrad_plan(golden_dir, monkeypatch, group, split, tile):
                    for lab in eng.bwd.labels)
     assert sum(lab.startswith("wgrad.fg") for lab in eng.bwd.labels) == split
     spk = [op.u.spkb for op in eng.bwd.ops if op.kind == L.OP_SPK_BWD]
-    assert len(spk) == 1 and spk[0].colsum_running == NL - split
+    if group < NL and split == 0:
+        # several groups: the first one (layers NL - group .., skip, post network) is followed by the speaker / gated-bias
+        # gradients of ITS layers and the early unpack - everything from that layer up is final there (the data-parallel
+        # schedule exchanges that region first: TrainEngine.bwd_a1 / dec_hi_offset); the rest of the layers at the end
+        hi = NL - group
+        assert len(spk) == 2 and [(s_.layer_range & 0xffff, s_.layer_range >> 16) for s_ in spk] == [(hi, NL - hi), (0, hi)]
+        i_grp = eng.bwd.labels.index("wgrad.group0 (layers %d.., skip, post)" % hi)
+        assert eng.bwd.labels[i_grp + 1: i_grp + 3] == ["spk_bwd (upper layers)", "unpack grads (decoder, upper layers)"]
+        assert eng.dec_hi_offset == min(eng.ps.off[n] for n in eng.ps.names() if f"conv_layers.{hi}." in n)
+        assert len(eng.bwd_a1.ops) == i_grp + 3 and len(eng.bwd_a1.ops) + len(eng.bwd_a2.ops) == len(eng.bwd_a.ops)
+    else:
+        assert len(spk) == 1 and spk[0].colsum_running == NL - split and spk[0].layer_range == 0
+        assert eng.dec_hi_offset is None and eng.bwd_a1 is None
     run(eng, z)
     check_grads(eng, z, "grad", "wide")
 
