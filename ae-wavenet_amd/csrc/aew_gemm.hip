@@ -199,6 +199,9 @@ __device__ __forceinline__ void epi_dfg(const EpiUni& U, const EpiRow& R, int n,
                                 MFMA / LDS-DMA order.  Bit-identical, measured null (NT 4.84 vs 4.84 ms per
                                 step), so the compiler-scheduled loop stays the default */
 #endif
+#ifndef AEW_TILE_ORDER_PROBE
+#define AEW_TILE_ORDER_PROBE 0   /* 1 (tools library): aew_gemm_nt_t.reserved bits 16-17 pick another order of the row tiles */
+#endif
 #ifndef AEW_NT_SETPRIO
 #define AEW_NT_SETPRIO 0     /* measured null on this structure (profiles/r01_notes.md) */
 #endif
@@ -531,25 +534,33 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
 // ABL = true builds the ablation variant used by tools/ablate_gemm.py (switches in g.reserved).  It is instantiated
 // in the tools library only (hipcc -DAEW_FN_ABLATE=1 -o lib/libaewavenet_hip_abl.so); the product library has the
 // ABL = false instantiations, which contain none of that code and ignore g.reserved.
-// ST = ring depth.  A K step is bound by the latency of the LDS-DMA stream, not by its volume (tools/membound_probe.py,
-// profiles/r04_notes.md): a block advances one K tile per (DMA latency / tiles in flight), so the default 3 stages (two
-// blocks per CU, 2 x 2 tiles in flight) and a deep ring of one block per CU are different points on the same curve.
+// ST = ring depth (round 4: deeper rings at one block per CU measured slower, aew_set_nt_deep; profiles/r04_notes.md §2).
 template <int N>
 __device__ __forceinline__ void nt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM, int ST = NT_STAGES>
-__global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+// one output tile: block index L of the launch's tile order
+template <int EPI, bool ABL, int MT, int NB, int BMV, int ST>
+__device__ __forceinline__ void nt_tile(const aew_gemm_nt_t& g, char* smem, const int L_) {
     typedef NtCfg<MT, NB, BMV> Cfg;
     static_assert(ST >= 3 && (ST - 2) * (Cfg::XP + Cfg::WP) <= 63 && ST * Cfg::STAGE_BYTES <= 160 * 1024, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % Cfg::WAVES_N, wm = wave / Cfg::WAVES_N;
     // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (observed dispatch rule; used for
     // speed only).  All N tiles of one (batch, row-tile) are consecutive on ONE XCD, so the
     // activation tile is fetched from HBM into that XCD's L2 once and re-hit by the others.
     const int n_mt = (g.M + Cfg::BM - 1) / Cfg::BM, n_nt = g.N_pad / Cfg::BN;
-    const int L = blockIdx.x, seq = L >> 3;
-    const int rt = (seq / n_nt) * 8 + (L & 7);
+    const int L = L_, seq = L >> 3;
+    int gi = seq / n_nt;                                       // group of 8 consecutive row tiles (one per XCD)
+#if AEW_TILE_ORDER_PROBE
+    {   // diagnostic (tools/b16_probe.py): other orders of the row-tile groups, selected by reserved bits 16-17
+        const int ord = (g.reserved >> 16) & 3, ng = (n_mt * g.batch + 7) / 8;
+        if (ord == 1) gi = (gi & 1) * ((ng + 1) / 2) + (gi >> 1);            // first and second half of the rows interleaved
+        else if (ord == 2) gi = ng - 1 - gi;                                  // reversed
+        else if (ord == 3) gi = (gi & 3) * ((ng + 3) / 4) + (gi >> 2);        // four quarters interleaved
+        if (gi >= ng) return;
+    }
+#endif
+    const int rt = gi * 8 + (L & 7);
     if (rt >= n_mt * g.batch) return;
     const int b = rt / n_mt;
     const int m0 = (rt - b * n_mt) * Cfg::BM, n0 = (seq % n_nt) * Cfg::BN;
@@ -754,6 +765,16 @@ __global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>:
     }
     nt_epilogue<EPI, ABL, MT>(g, acc, b, m0, n0, wm, wn, lane);
 }
+
+template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM, int ST = NT_STAGES>
+__global__ __launch_bounds__((NtCfg<MT, NB, BMV>::THREADS), (NtCfg<MT, NB, BMV>::MINW)) void k_gemm_nt_bf16(const aew_gemm_nt_t g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nt_tile<EPI, ABL, MT, NB, BMV, ST>(g, smem, blockIdx.x);
+}
+
+// (Round 4, measured and removed: the same tiles as PERSISTENT blocks - a grid of two blocks per CU, each walking the tile
+// order with stride gridDim.x, no workgroup dispatched after the first wave - G2 33.1 vs 31.2 us, at B = 16 62.3 vs 53.4: the
+// ~10 us a launch costs beyond its tiles is not workgroup dispatch.  profiles/r04_notes.md §13.)
 
 // =============================================================================================
 // Software-pipelined form of the fat-wave kernel ("pipe"): same tiles, waves, LDS ring and results
