@@ -146,7 +146,8 @@ def cpu_baseline(hps, eng, seconds_budget=30.0):
         opt.step()
         return time.time() - t0
     t_start = time.time()
-    plain = step(False)                                    # also the warm-up (allocator, thread pool) of the timed three
+    step(False)                                            # warm-up (allocator, thread pool, first-touch of 95 MB of moments)
+    plain = step(False)
     ts = []
     for _ in range(3):
         ts.append(step(True))
@@ -160,8 +161,8 @@ def cpu_baseline(hps, eng, seconds_budget=30.0):
             "value_without_diagnostic_backward": n / plain,
             "sample": f"oracle forward + backward + Adam on {nb} of the batch's 8 windows ({n} samples): median of "
                       f"{len(ts)} timed steps with the reference's diagnostic second backward (what its run() does) "
-                      f"{med:.2f} s (fastest {ts[0]:.2f}, slowest {ts[-1]:.2f}); the first step, without it, "
-                      f"{plain:.2f} s; time per window is independent of the batch size on the CPU"}
+                      f"{med:.2f} s (fastest {ts[0]:.2f}, slowest {ts[-1]:.2f}); one timed step without it "
+                      f"{plain:.2f} s (after one untimed warm-up step); time per window is independent of the batch size on the CPU"}
 
 
 def kernel_source_sha():
@@ -176,7 +177,7 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
-def pmc_traffic(kernel_prefix, tag="r03"):
+def pmc_traffic(kernel_prefix, tag="r04"):
     """HBM bytes per launch (a number, as the bench contract asks) of the dominant kernel from the committed PMC passes
     (profiles/<tag>_pmc_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
     FETCH doubled per MI355X_MICROARCH.md; written by tools/measure_round.sh together with <tag>_pmc_hbm_traffic.sha =

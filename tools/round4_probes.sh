@@ -3,7 +3,9 @@
 # profiles/r04_raw/ by hand).  Needs the tools library: hipcc ... -DAEW_FN_ABLATE=1 -o ae-wavenet_amd/lib/libaewavenet_hip_abl.so
 #   usage (on the GPU box): tools/round4_probes.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r04_probes; mkdir -p $O; cd $R
-ABL=ae-wavenet_amd/lib/libaewavenet_hip_abl.so
+ABL=ae-wavenet_amd/lib/libaewavenet_hip_abl.so      # tools build: not shipped with the snapshot (.gpurunignore), built here
+[ -f $ABL ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=off -Wno-unused-result -Wno-inline-asm \
+    -DAEW_FN_ABLATE=1 ae-wavenet_amd/csrc/aewavenet.hip -o $ABL
 python tools/membound_probe.py > $O/membound_probe.log 2>&1
 AEW_LIB_PATH=$ABL python tools/phase_clock.py > $O/phase_clock.log 2>&1
 AEW_LIB_PATH=$ABL python tools/overlap_probe.py > $O/overlap_plain_kernel.log 2>&1
