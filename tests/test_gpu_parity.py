@@ -754,6 +754,45 @@ def test_autoencoder_vae_step(golden_dir):
     grads_vs_golden(eg, z, "g")
 
 
+@pytest.mark.parametrize("B", [16, 20, 37])
+def test_speaker_and_bias_gradients_at_large_batch(B):
+    """Round-3 ADVICE: the speaker backward kept B and G in registers (B <= 16 only) and, with the grouped wgrads, recovers
+    the per-batch column sums of dfg as differences of running fp32 snapshots - worse cancellation for later batch
+    elements.  B = 16 (the reference default n_batch: the edge of the old kernel), B = 20 and 37 (two and three chunks of
+    16 batch elements: partial sums added with atomics): gated biases, speaker projections, speaker embedding against the
+    CPU interpreter of the same plans."""
+    hps = config.make_hps("mi", n_res=32, n_dil=32, n_skp=32, n_post=32, n_lc_out=16, n_global_embed=10, n_speakers=7,
+                          n_blocks=2, n_block_layers=3, n_win_batch=40, n_lc_in=12)
+    engs = []
+    for dev in ("cpu", DEV):
+        e = M.TrainEngine(hps, B=B, device=dev, n_mel=12)
+        gen = torch.Generator().manual_seed(17)
+        for k in e.ps.names():
+            e.ps.view(k).copy_(torch.randn(e.ps.shape[k], generator=gen) * 0.25)
+        engs.append(e)
+    ec, eg = engs
+    assert len([op for op in eg.bwd.ops if op.kind == L.OP_SPK_BWD]) == 1
+    g = ec.geom
+    gen = torch.Generator().manual_seed(18)
+    z = {"wav": torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float().numpy(),
+         "mel": torch.randn(B, 12, g.mel_len, generator=gen).numpy(),
+         "voice": torch.randint(0, 7, (B,), generator=gen).numpy(),
+         "jitter": torch.arange(g.embed_len).repeat(B, 1).numpy()}
+    run_pair(ec, eg, z)
+    checked = 0
+    for k in ec.ps.names():
+        if not ("speaker_embedding" in k or ".proj_" in k or k.endswith("conv_signal.bias") or k.endswith("conv_gate.bias")):
+            continue
+        ref, got = ec.ps.view(k, grad=True), eg.ps.view(k, grad=True).cpu()
+        scale = float(ref.abs().max())
+        assert scale > 0, k
+        err = float((got - ref).abs().max()) / scale
+        cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
+        assert err < 3e-2 and cos > 0.999, (k, err, cos)
+        checked += 1
+    assert checked == 2 + 4 * len(g.layers)
+
+
 # ----------------------------------------------------------------------------------------------
 # bit-exact sub-path at full width: encoder -> linear -> VQ vs the exact-order C oracle
 # ----------------------------------------------------------------------------------------------
