@@ -117,6 +117,12 @@ class SpkBwd(C.Structure):
                 ("grads", vp), ("colsum_running", i32), ("layer_range", i32)]
 
 
+class Tuning(C.Structure):
+    """aew_tuning_t: kernel-shape choices as a record (the aew_set_* switches edit the process-wide one; Plan.run(...,
+    tuning=...) / aew_run_plan_tuned apply a caller's own to one call)."""
+    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("reserved_", i32 * 10)]
+
+
 class BaseGather(C.Structure):
     _fields_ = [("wav", vp), ("wav_pitch", i32), ("wav_off", i32), ("W", vp), ("bias", vp),
                 ("Wt", vp), ("B", i32), ("T", i32), ("R", i32), ("R_pad", i32), ("Q", i32), ("x", vp),
@@ -271,12 +277,16 @@ def load():
     lib.aew_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.aew_graph_destroy.argtypes = [C.c_void_p]
     lib.aew_sampler_run.argtypes = [C.c_void_p, C.c_void_p]
-    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler)):
+    lib.aew_run_plan_tuned.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+    lib.aew_graph_capture_tuned.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+    for fn in (lib.aew_tuning_default, lib.aew_tuning_get, lib.aew_tuning_set):
+        fn.argtypes = [C.c_void_p]
+    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler), (8, Tuning)):
         want = lib.aew_sizeof(which)
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 16:
+    if lib.aew_abi_version() != 17:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -287,6 +297,17 @@ def check(rc, what="aew call", fail_index=None):
         msg = load().aew_strerror(rc).decode()
         at = f" at op {fail_index}" if fail_index is not None else ""
         raise AewError(f"{what} failed{at}: rc={rc} ({msg})")
+
+
+def default_tuning(**over) -> "Tuning":
+    """The library's default tuning record, with fields overridden by keyword."""
+    t = Tuning()
+    check(load().aew_tuning_default(C.byref(t)), "aew_tuning_default")
+    for k, v in over.items():
+        if not hasattr(t, k):
+            raise AttributeError(f"aew_tuning_t has no field {k}")
+        setattr(t, k, int(v))
+    return t
 
 
 def tn_slabs(tn: GemmTN) -> int:
@@ -300,4 +321,5 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
            "aew_set_lanes", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nt_small_waves", "aew_set_nf_deep", "aew_set_nf_loaders", "aew_set_nt_rows192",
-           "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_set_fn_ring3", "aew_set_nt_small_n64", "aew_tn_group_check", "aew_set_nt_mem128", "aew_set_nt_deep")
+           "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_set_fn_ring3", "aew_set_nt_small_n64", "aew_tn_group_check", "aew_set_nt_mem128", "aew_set_nt_deep", "aew_tuning_default", "aew_tuning_get",
+           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned")

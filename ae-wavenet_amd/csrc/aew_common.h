@@ -20,6 +20,12 @@ __device__ __attribute__((aligned(16))) unsigned int aew_zero_page[4] = {0u, 0u,
 #define AEW_ZERO_SPAN 16384
 __device__ __attribute__((aligned(128))) unsigned int aew_zero_region[2 * AEW_ZERO_SPAN / 4];
 
+// ---- tuning context (aew_tuning_t, aewavenet.h): the process-wide record the aew_set_* switches edit, and the record of
+// the call in progress when a caller passed its own (aew_run_plan_tuned): launchers read AEW_T().field
+static aew_tuning_t g_tune = {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static thread_local const aew_tuning_t* t_tune = nullptr;
+static inline const aew_tuning_t& AEW_T() { return t_tune ? *t_tune : g_tune; }
+
 // ---- bf16 <-> f32, round-to-nearest-even (matches torch .to(bfloat16)) --------------------
 __device__ __forceinline__ uint16_t f2bf(float f) {
     uint32_t u = __float_as_uint(f);

@@ -638,11 +638,9 @@ __global__ __launch_bounds__(FN_THREADS, 3) void k_fn(const aew_gemm_nt_t g) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-static int g_fn_enable = 1;
-static int g_fn_ring3 = 16;                                    // K tiles from which plain full-N GEMMs take the 3-stage ring (0: never)
-extern "C" int aew_set_fn(int on) { g_fn_enable = on; return 0; }
-extern "C" int aew_set_fn_ring3(int min_k_tiles) { g_fn_ring3 = min_k_tiles < 0 ? 0 : min_k_tiles; return 0; }
-int g_fn_enable_flag() { return g_fn_enable; }
+extern "C" int aew_set_fn(int on) { g_tune.fn_enable = on ? 1 : 0; return 0; }
+extern "C" int aew_set_fn_ring3(int min_k_tiles) { g_tune.fn_ring3 = min_k_tiles < 0 ? 0 : min_k_tiles; return 0; }
+int g_fn_enable_flag() { return AEW_T().fn_enable; }
 
 template <int NTW, int EPI, int NTW2, int NST = 2, int MTCAP = 0>
 static int fn_launch(const aew_gemm_nt_t& g, hipStream_t st) {
@@ -696,7 +694,7 @@ static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st) {
             return fn_launch<3, AEW_EPI_DFG, 0>(g, st);
         default:
             // long K (the multi-segment skip sum / cond gradient): three-stage ring, see k_fn
-            if (g_fn_ring3 && g.K_total >= 64 * g_fn_ring3) {
+            if (AEW_T().fn_ring3 && g.K_total >= 64 * AEW_T().fn_ring3) {
                 if (a == 1) return fn_launch<1, AEW_EPI_STORE, 0, 3, 0>(g, st);
                 if (a == 2) return fn_launch<2, AEW_EPI_STORE, 0, 3, 10>(g, st);
             }
@@ -718,12 +716,12 @@ extern "C" int aew_nt_kernel(const aew_gemm_nt_t* gp) {
     if (g.impl == 1) return 4;
     if (g.dtype != AEW_BF16) return 3;
     if (g.impl == 2 && g_fn_enable_flag() && fn_supported(g)) return 2;
-    if (g_nt_wave_rows != 64) return 5;
+    if (AEW_T().nt_wave_rows != 64) return 5;
     bool zspan = true;
     for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
     const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
-    if (g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan) return 1;
+    if (AEW_T().nt_small_tiles > 0 && tiles256 <= AEW_T().nt_small_tiles && zspan) return 1;
     return win_dwp(g) ? 6 : 0;
 }
 
-extern "C" int aew_set_nt_window(int max_dist) { g_nt_window = max_dist < 0 ? 0 : (max_dist > 64 ? 64 : max_dist); return 0; }
+extern "C" int aew_set_nt_window(int max_dist) { g_tune.nt_window = max_dist < 0 ? 0 : (max_dist > 64 ? 64 : max_dist); return 0; }

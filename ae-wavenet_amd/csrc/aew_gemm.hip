@@ -2068,21 +2068,6 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 // =============================================================================================
 // host-side launchers
 // =============================================================================================
-static int g_tn_safe = 0;                              // 1: scalar LDS gather instead of tr-read
-static int g_nt_pipe = 1;          // fat shapes use the software-pipelined kernel
-static int g_nt_rows192 = 1;      // default shape: 0 never, 1 cost model, 2 always use 192-row tiles
-static int g_nf_loaders = 1;        // fp32 NT: four dedicated loader waves per block (0: the consumer waves stage their own operands)
-static int g_nf_deep = 256;         // fp32 NT: launches of <= this many blocks get one block per CU and a 12-14 stage ring
-static int g_nt_small_n64 = 256;   // ... and as 64 x 64 tiles when the launch has <= this many 64 x 128 blocks (0: never)
-static int g_nt_small_w8 = 1;       // ... with 8 waves (16 rows x 64 channels each) instead of 2: the LDS-DMA issue is shared
-static int g_nt_small_deep = 256;   // 64-row launches of <= this many blocks (one per CU) use the 5-stage ring (120 KiB)
-static int g_nt_small_tiles = 128; // default shape: launches of <= this many 256x128 tiles use 64-row tiles
-static int g_nt_mem128 = 0;        // memory-bound plain launches (DFG epilogue, or K_total <= 256) as 128-row tiles: 0 off,
-                                   // 1: 128 x 128 K32 tiles, 4 waves, three blocks per CU; 2: 128 x 128 K64 tiles (p64), two per CU
-static int g_nt_deep = 0;          // deep operand rings, one block per CU (A/B): 1 256 x 128 tiles on 6 stages; 2 256 x 256 tiles (8 fat
-                                   // waves) on 5 stages where N_pad % 256 == 0, else as 1; 3 as 2 but everything else on the defaults
-static int g_nt_wave_rows = 64;    // bf16 NT shape: 64 = 8 thin waves (64x64), 128 = 4 fat waves (128x64), both on
-                                   // 256x128 tiles; 256 = 8 fat waves on 256x256 tiles where N_pad allows
 
 // kernels using more than 64 KiB of dynamic LDS must opt in once per process
 static int ensure_big_lds() {
@@ -2226,39 +2211,39 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         if (rc) return rc;
         bool zspan = true;                                   // masked rows stream from aew_zero_region
         for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
-        const bool wide = g_nt_wave_rows == 256 && g.N_pad % 256 == 0 && !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
-        const bool p64 = wide && g_nt_pipe == 2 && zspan;    // 256 x 256 tiles, K tiles of 64
+        const bool wide = AEW_T().nt_wave_rows == 256 && g.N_pad % 256 == 0 && !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
+        const bool p64 = wide && AEW_T().nt_pipe == 2 && zspan;    // 256 x 256 tiles, K tiles of 64
         // launches that would be a small fraction of one tile wave use 64-row tiles (default shape only)
         const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
-        const bool p64r = g_nt_wave_rows == 64 && g_nt_small_tiles > 0 && tiles256 <= g_nt_small_tiles && zspan;
+        const bool p64r = AEW_T().nt_wave_rows == 64 && AEW_T().nt_small_tiles > 0 && tiles256 <= AEW_T().nt_small_tiles && zspan;
         // memory-bound launches (the K loop of G2 is 8 steps, dz carries 100 MB of epilogue operands): 128-row tiles, so
         // that the launch is several tile waves and one block's stores run under another's K loop
-        const bool memb = g_nt_mem128 && g_nt_wave_rows == 64 && !p64r && !win_dwp(g) && zspan &&
+        const bool memb = AEW_T().nt_mem128 && AEW_T().nt_wave_rows == 64 && !p64r && !win_dwp(g) && zspan &&
                           (g.epi == AEW_EPI_DFG || (g.epi == AEW_EPI_STORE && g.K_total <= 256));
-        const bool t128 = memb && g_nt_mem128 == 1;
-        const bool p128 = !p64r && (g_nt_wave_rows == 0 || (memb && g_nt_mem128 == 2)) && zspan;      // 128 x 128 tiles, K tiles of 64
-        const bool p256 = g_nt_wave_rows == 1 && zspan;      // 256 x 128 tiles, K tiles of 64, one block per CU
+        const bool t128 = memb && AEW_T().nt_mem128 == 1;
+        const bool p128 = !p64r && (AEW_T().nt_wave_rows == 0 || (memb && AEW_T().nt_mem128 == 2)) && zspan;      // 128 x 128 tiles, K tiles of 64
+        const bool p256 = AEW_T().nt_wave_rows == 1 && zspan;      // 256 x 128 tiles, K tiles of 64, one block per CU
         // 192-row tiles (8 waves of 48 x 64) where they shorten the launch.  Blocks spread over the 256 CUs before
         // they double up, and a CU is MFMA-bound with one block already, so a launch costs about
         // ceil(tiles / 256) * rows-per-tile; the 192-row shape is ~5 % less efficient per row (12 MFMAs per wave
         // and K step instead of 16), hence the margin.
         bool t192 = false;
-        if (g_nt_wave_rows == 64 && !p64r && g_nt_rows192 && !memb) {
+        if (AEW_T().nt_wave_rows == 64 && !p64r && AEW_T().nt_rows192 && !memb) {
             const int tiles192 = ((g.M + 191) / 192) * g.batch * (g.N_pad / NT_BN);
             const int c256 = ((tiles256 + 255) / 256) * 256, c192 = ((tiles192 + 255) / 256) * 192;
-            t192 = g_nt_rows192 == 2 || c192 * 10 < c256 * 9;
+            t192 = AEW_T().nt_rows192 == 2 || c192 * 10 < c256 * 9;
         }
-        const bool deep2 = (g_nt_deep == 2 || g_nt_deep == 3) && g_nt_wave_rows == 64 && !p64r && !memb && g.N_pad % 256 == 0 &&
+        const bool deep2 = (AEW_T().nt_deep == 2 || AEW_T().nt_deep == 3) && AEW_T().nt_wave_rows == 64 && !p64r && !memb && g.N_pad % 256 == 0 &&
                            !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
-        const bool deep1 = (g_nt_deep == 1 || g_nt_deep == 2) && !deep2 && g_nt_wave_rows == 64 && !p64r && !memb;
+        const bool deep1 = (AEW_T().nt_deep == 1 || AEW_T().nt_deep == 2) && !deep2 && AEW_T().nt_wave_rows == 64 && !p64r && !memb;
         if (deep1 || deep2) t192 = false;
-        if (!p64r && g_nt_wave_rows == 64 && !deep1 && !deep2) {   // both taps of a dilated pair from one LDS window
+        if (!p64r && AEW_T().nt_wave_rows == 64 && !deep1 && !deep2) {   // both taps of a dilated pair from one LDS window
             const int dwp = win_dwp(g);
             if (dwp) return launch_win(g, dwp, t192, st);
         }
         // 64 x 64 tiles for launches of very few 64 x 128 blocks (see the p64 kernel's table)
-        const bool p64n = p64r && g_nt_small_w8 && g_nt_small_n64 > 0 &&
-                          ((g.M + 63) / 64) * g.batch * (g.N_pad / 128) <= g_nt_small_n64;
+        const bool p64n = p64r && AEW_T().nt_small_w8 && AEW_T().nt_small_n64 > 0 &&
+                          ((g.M + 63) / 64) * g.batch * (g.N_pad / 128) <= AEW_T().nt_small_n64;
         const int bm = p64r ? 64 : ((p128 || t128) ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : ((wide || deep2) ? 256 : NT_BN));
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
@@ -2274,9 +2259,9 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 4, 1, 128>), grid, dim3((NtCfg<4, 1, 128>::THREADS)), (NtCfg<4, 1, 128>::LDS_BYTES), st, g); \
         else if (!ABL && p64n)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 1, 4, 1, 5>), grid, dim3(256), (5 * P64Cfg<1, 4, 1>::STAGE_BYTES), st, g); \
-        else if (!ABL && p64r && (int)grid.x <= g_nt_small_deep && g_nt_small_w8)                              \
+        else if (!ABL && p64r && (int)grid.x <= AEW_T().nt_small_deep && AEW_T().nt_small_w8)                              \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 1, 4, 2, 5>), grid, dim3(512), (5 * P64Cfg<1, 4, 2>::STAGE_BYTES), st, g); \
-        else if (!ABL && p64r && (int)grid.x <= g_nt_small_deep)                                               \
+        else if (!ABL && p64r && (int)grid.x <= AEW_T().nt_small_deep)                                               \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 1, 2, 5>), grid, dim3(128), (5 * P64Cfg<4, 1, 2>::STAGE_BYTES), st, g); \
         else if (!ABL && p64r)                                                                                 \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 1, 2>), grid, dim3(128), (P64Cfg<4, 1, 2>::LDS_BYTES), st, g); \
@@ -2286,13 +2271,13 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), grid, dim3(256), (P64Cfg<4, 2, 2>::LDS_BYTES), st, g); \
         else if (!ABL && p64)                                                                                  \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), grid, dim3(512), (P64Cfg<8, 2, 4>::LDS_BYTES), st, g); \
-        else if (!ABL && g_nt_pipe && wide)                                                                   \
+        else if (!ABL && AEW_T().nt_pipe && wide)                                                                   \
             hipLaunchKernelGGL((k_gemm_nt_bf16_pipe<EPI, 2>), grid, dim3((NtCfg<8, 2>::THREADS)), (NtCfg<8, 2>::LDS_BYTES), st, g); \
-        else if (!ABL && g_nt_pipe && g_nt_wave_rows == 128)                                                  \
+        else if (!ABL && AEW_T().nt_pipe && AEW_T().nt_wave_rows == 128)                                                  \
             hipLaunchKernelGGL((k_gemm_nt_bf16_pipe<EPI, 1>), grid, dim3((NtCfg<8, 1>::THREADS)), (NtCfg<8, 1>::LDS_BYTES), st, g); \
         else if (wide)                                                                                        \
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 8, 2>), grid, dim3((NtCfg<8, 2>::THREADS)), (NtCfg<8, 2>::LDS_BYTES), st, g); \
-        else if (g_nt_wave_rows == 128)                                                                       \
+        else if (AEW_T().nt_wave_rows == 128)                                                                       \
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 8>), grid, dim3(NtCfg<8>::THREADS), NT_LDS_BYTES, st, g); \
         else                                                                                                  \
             hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, ABL, 4>), grid, dim3(NtCfg<4>::THREADS), NT_LDS_BYTES, st, g); \
@@ -2300,7 +2285,7 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         switch (g.epi) {
             case AEW_EPI_STORE:
 #if AEW_FN_ABLATE
-                if (g.reserved && g_nt_wave_rows == 64) { AEW_NT_GO(AEW_EPI_STORE, true); break; }
+                if (g.reserved && AEW_T().nt_wave_rows == 64) { AEW_NT_GO(AEW_EPI_STORE, true); break; }
 #endif
                 AEW_NT_GO(AEW_EPI_STORE, false);
                 break;
@@ -2313,7 +2298,7 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             case AEW_EPI_RES_SKIP: AEW_NT_GO(AEW_EPI_RES_SKIP, false); break;
             case AEW_EPI_DFG:
 #if AEW_FN_ABLATE
-                if (g.reserved && g_nt_wave_rows == 64) { AEW_NT_GO(AEW_EPI_DFG, true); break; }
+                if (g.reserved && AEW_T().nt_wave_rows == 64) { AEW_NT_GO(AEW_EPI_DFG, true); break; }
 #endif
                 AEW_NT_GO(AEW_EPI_DFG, false);
                 break;
@@ -2330,35 +2315,29 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         const int tiles1 = ((rows + 15) / 16) * n_nt, tiles2 = ((rows + 31) / 32) * n_nt;
 #define AEW_NF_GO(RT, S, GRID)                                                                                       \
     do {                                                                                                             \
-        if (g_nf_loaders) hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 1>), dim3(GRID), dim3(512), (NfCfg<RT, S>::LDS_BYTES), st, g); \
+        if (AEW_T().nf_loaders) hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 1>), dim3(GRID), dim3(512), (NfCfg<RT, S>::LDS_BYTES), st, g); \
         else hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 0>), dim3(GRID), dim3(256), (NfCfg<RT, S>::LDS_BYTES), st, g);  \
     } while (0)
-        if (g_nf_deep && tiles1 <= g_nf_deep) AEW_NF_GO(1, 14, tiles1);
-        else if (g_nf_deep && tiles2 <= g_nf_deep) AEW_NF_GO(2, 12, tiles2);
+        if (AEW_T().nf_deep && tiles1 <= AEW_T().nf_deep) AEW_NF_GO(1, 14, tiles1);
+        else if (AEW_T().nf_deep && tiles2 <= AEW_T().nf_deep) AEW_NF_GO(2, 12, tiles2);
         else AEW_NF_GO(1, 7, tiles1);
 #undef AEW_NF_GO
     }
     return (int)hipGetLastError();
 }
 
-static int g_tn_big = 0;                              // 1: 256 x 256 tiles (k_gemm_tn_bf16_big) for large bf16 outputs.  Off: measured equal CU time
-                                                     // to the 128 x 128 kernel on this workload and it writes more slabs (profiles/r02_notes.md)
-static int g_tn_big_target = 256;                    // ... split-K until about this many blocks (one block per CU)
-static int g_tn_fold_rows = 4096;                    // contractions up to this many rows fold the batch
-static int g_tn_target_blocks = 512;                 // split-K until a TN launch has about this many blocks
-static int g_tn_small_tiles = 8, g_tn_small_target = 128;   // outputs of <= small_tiles tiles split to small_target blocks
 
 // does this op run on the big-tile kernel?  (bf16, MFMA path, at least one full 256 x 256 tile's worth of output)
 static bool tn_use_big(const aew_gemm_tn_t& g) {
-    return g_tn_big && !g_tn_safe && g.dtype == AEW_BF16 && g.impl != 1 && g.N_pad >= 256 && g.K_total >= 256 &&
-           (int64_t)g.Mc * g.batch > g_tn_fold_rows;
+    return AEW_T().tn_big && !AEW_T().tn_safe && g.dtype == AEW_BF16 && g.impl != 1 && g.N_pad >= 256 && g.K_total >= 256 &&
+           (int64_t)g.Mc * g.batch > AEW_T().tn_fold_rows;
 }
 
 // split heuristic: aim for >= ~2 blocks per CU
 static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* rps, int* fold) {
     if (tn_use_big(g)) {
         const int tiles = ((g.N_pad / 128 + 1) / 2) * ((g.K_total / 128 + 1) / 2);
-        int want = (g_tn_big_target + tiles * g.batch - 1) / (tiles * g.batch);
+        int want = (AEW_T().tn_big_target + tiles * g.batch - 1) / (tiles * g.batch);
         int max_sp = (g.Mc + 8 * rc - 1) / (8 * rc);       // keep >= 8 stages per block
         if (max_sp < 1) max_sp = 1;
         int sp = want < 1 ? 1 : (want > max_sp ? max_sp : want);
@@ -2369,12 +2348,12 @@ static void tn_plan(const aew_gemm_tn_t& g, int tile, int rc, int* splits, int* 
         return;
     }
     const int tiles = (g.N_pad / tile) * (g.K_total / tile);
-    int f = ((int64_t)g.Mc * g.batch <= g_tn_fold_rows) ? 1 : 0;   // short contractions: fold the batch loop
+    int f = ((int64_t)g.Mc * g.batch <= AEW_T().tn_fold_rows) ? 1 : 0;   // short contractions: fold the batch loop
     int slabs_b = f ? 1 : g.batch;
     // small outputs (a handful of tiles) would need ~100 row splits to fill the chip on their own, and
     // every split is a slab that is written here and read again by the unpack; they run on the side lane
     // next to chip-filling kernels, so they are split much less
-    const int target = (tiles <= g_tn_small_tiles) ? g_tn_small_target : g_tn_target_blocks;
+    const int target = (tiles <= AEW_T().tn_small_tiles) ? AEW_T().tn_small_target : AEW_T().tn_target_blocks;
     int want = (target + tiles * slabs_b - 1) / (tiles * slabs_b);
     int max_sp = (g.Mc + 4 * rc - 1) / (4 * rc);        // keep >= 4 stages per block
     if (max_sp < 1) max_sp = 1;
@@ -2403,7 +2382,7 @@ extern "C" int aew_tn_fold(const aew_gemm_tn_t* g) {
     return fold;
 }
 
-extern "C" int aew_set_tn_fold_rows(int rows) { g_tn_fold_rows = rows; return 0; }
+extern "C" int aew_set_tn_fold_rows(int rows) { g_tune.tn_fold_rows = rows; return 0; }
 
 // host copy of a group's descriptors is not available (they live in device memory): the builder validated them with
 // aew_tn_group_check before uploading
@@ -2474,7 +2453,7 @@ static int launch_gemm_tn(const aew_gemm_tn_t& g, hipStream_t st) {
             return (int)hipGetLastError();
         }
         dim3 grid(((n_chunks + 7) / 8) * 8 * (g.N_pad / TN_BT) * (g.K_total / TN_BT));
-        if (g_tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
+        if (AEW_T().tn_safe) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
         else hipLaunchKernelGGL(k_gemm_tn_bf16<0>, grid, dim3(TN_THREADS), TN_LDS_BYTES, st, g, sp, rps, fold);
     } else {
         dim3 grid((g.N_pad / TF_BT) * (g.K_total / TF_BT), sp, fold ? 1 : g.batch);

@@ -243,18 +243,17 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt_bf16_win(const aew_gemm_nt_t
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
-static int g_nt_window = 64;      // largest tap distance that uses the window kernel (0: never)
 
 // window pieces beyond the tile's own that the descriptor needs (1 | 4), or 0 if it cannot use the window kernel
 static int win_dwp(const aew_gemm_nt_t& g) {
-    if (!g_nt_window || g.dtype != AEW_BF16 || g.impl != 0 || g.n_segs < 2 || g.W2) return 0;
+    if (!AEW_T().nt_window || g.dtype != AEW_BF16 || g.impl != 0 || g.n_segs < 2 || g.W2) return 0;
     if (g.epi != AEW_EPI_GATED && g.epi != AEW_EPI_STORE) return 0;
     const aew_seg_t &a = g.seg[0], &c = g.seg[1];
     if (a.ptr != c.ptr || a.batch_stride != c.batch_stride || a.row_pitch != c.row_pitch || a.row_step != 1 ||
         c.row_step != 1 || a.row_lo != c.row_lo || a.row_hi != c.row_hi || a.k_len != c.k_len)
         return 0;
     const int d = a.row_off > c.row_off ? a.row_off - c.row_off : c.row_off - a.row_off;
-    if (d < 1 || d > 64 || d > g_nt_window) return 0;
+    if (d < 1 || d > 64 || d > AEW_T().nt_window) return 0;
     for (int s = 0; s < g.n_segs; ++s)
         if (g.seg[s].k_len % NT_BK || g.seg[s].k_len * 2 > AEW_ZERO_SPAN) return 0;
     return d <= 16 ? 1 : 4;

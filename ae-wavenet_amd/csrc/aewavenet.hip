@@ -67,6 +67,7 @@ extern "C" int aew_sizeof(int which) {
         case 5: return (int)sizeof(aew_copy_rec_t);
         case 6: return (int)sizeof(aew_actor_t);
         case 7: return (int)sizeof(aew_sampler_t);
+        case 8: return (int)sizeof(aew_tuning_t);
         default: return -1;
     }
 }
@@ -79,11 +80,10 @@ extern "C" int aew_sizeof(int which) {
 // Default OFF (round 3): with the weight gradients in one launch after the chain there is little left to overlap, and in a
 // captured graph every fork / join edge is a cross-branch dependency the replay pays for - measured on one box, one
 // process: graph + lanes 6.96 ms/step, graph serial 6.81, eager serial 6.80, eager + lanes 6.77 (profiles/r03_notes.md).
-static int g_lanes = 0;
 static std::vector<hipEvent_t> g_lane_ev;
 static size_t g_lane_ev_next = 0;
 
-extern "C" int aew_set_lanes(int on) { g_lanes = on < 0 ? 0 : (on > 2 ? 2 : on); return 0; }   // 2: lanes 4, 5 only (independent chains)
+extern "C" int aew_set_lanes(int on) { g_tune.lanes = on < 0 ? 0 : (on > 2 ? 2 : on); return 0; }   // 2: lanes 4, 5 only (independent chains)
 
 static hipEvent_t lane_event() {
     const size_t POOL = 64;
@@ -108,7 +108,7 @@ static int edge(hipStream_t from, hipStream_t to) {          // `to` continues a
 static hipStream_t g_side[AEW_MAX_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [1..AEW_MAX_SIDE]
 
 static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, bool timing) {
-    const bool lanes = g_lanes && !timing;
+    const bool lanes = AEW_T().lanes && !timing;
     bool main_ahead[AEW_MAX_SIDE + 1];   // main has work side stream k has not been ordered after
     bool open[AEW_MAX_SIDE + 1];         // side stream k has work that main (or a joining side op) has not waited for
     for (int k = 0; k <= AEW_MAX_SIDE; ++k) { main_ahead[k] = true; open[k] = false; }
@@ -118,7 +118,7 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
         hipStream_t target = st;
         const int lane = ops[i].lane;
         if (lane < 0 || lane > AEW_MAX_SIDE) { rc = AEW_E_ARG; if (fail_index) *fail_index = i; break; }
-        if (lanes && lane >= (g_lanes == 2 ? 4 : 1)) {
+        if (lanes && lane >= (AEW_T().lanes == 2 ? 4 : 1)) {
             if (!g_side[lane]) {
                 hipError_t e = hipStreamCreateWithFlags(&g_side[lane], hipStreamNonBlocking);
                 if (e != hipSuccess) { rc = (int)e; break; }
@@ -165,6 +165,55 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
 extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index) {
     if (!ops || n < 0) return AEW_E_ARG;
     return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing != 0);
+}
+
+// ---- tuning context: a caller's own record for the duration of one call (thread-local), see aewavenet.h
+struct TuneScope {
+    const aew_tuning_t* prev;
+    explicit TuneScope(const aew_tuning_t* t) : prev(t_tune) { if (t) t_tune = t; }
+    ~TuneScope() { t_tune = prev; }
+};
+static void tune_clamp(aew_tuning_t& t) {
+    auto cl = [](int32_t& v, int lo, int hi) { v = v < lo ? lo : (v > hi ? hi : v); };
+    if (t.nt_wave_rows != 0 && t.nt_wave_rows != 1 && t.nt_wave_rows != 64 && t.nt_wave_rows != 128 && t.nt_wave_rows != 256)
+        t.nt_wave_rows = 64;
+    cl(t.nt_pipe, 0, 2); cl(t.nt_rows192, 0, 2); cl(t.nt_window, 0, 64); cl(t.nt_mem128, 0, 2); cl(t.nt_deep, 0, 3);
+    cl(t.lanes, 0, 2); cl(t.nt_small_w8, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
+    cl(t.nt_small_tiles, 0, 1 << 30); cl(t.nt_small_n64, 0, 1 << 30); cl(t.nt_small_deep, 0, 1 << 30); cl(t.nf_deep, 0, 1 << 30);
+    cl(t.fn_ring3, 0, 1 << 30); cl(t.tn_big_target, 1, 1 << 30); cl(t.tn_fold_rows, 0, 1 << 30); cl(t.tn_target_blocks, 1, 1 << 30);
+    cl(t.tn_small_tiles, 0, 1 << 30); cl(t.tn_small_target, 1, 1 << 30);
+}
+extern "C" int aew_tuning_default(aew_tuning_t* out) {
+    if (!out) return AEW_E_ARG;
+    static const aew_tuning_t d = {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    *out = d;
+    return 0;
+}
+extern "C" int aew_tuning_get(aew_tuning_t* out) {
+    if (!out) return AEW_E_ARG;
+    *out = g_tune;
+    return 0;
+}
+extern "C" int aew_tuning_set(const aew_tuning_t* in) {
+    if (!in) return AEW_E_ARG;
+    aew_tuning_t t = *in;
+    tune_clamp(t);
+    g_tune = t;
+    return 0;
+}
+extern "C" int aew_run_plan_tuned(const aew_op_t* ops, int n, void* stream, int* fail_index, const aew_tuning_t* tuning) {
+    if (!ops || n < 0) return AEW_E_ARG;
+    aew_tuning_t t;
+    if (tuning) { t = *tuning; tune_clamp(t); }
+    TuneScope scope(tuning ? &t : nullptr);
+    return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing != 0);
+}
+extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, int* fail_index);
+extern "C" int aew_graph_capture_tuned(const aew_op_t* ops, int n, void** exec_out, int* fail_index, const aew_tuning_t* tuning) {
+    aew_tuning_t t;
+    if (tuning) { t = *tuning; tune_clamp(t); }
+    TuneScope scope(tuning ? &t : nullptr);
+    return aew_graph_capture(ops, n, exec_out, fail_index);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,40 +279,40 @@ extern "C" int aew_timing_read(float* ms, int32_t* tags, int capacity, int* coun
     return 0;
 }
 
-extern "C" int aew_set_tn_safe(int on) { g_tn_safe = on ? 1 : 0; return 0; }
+extern "C" int aew_set_tn_safe(int on) { g_tune.tn_safe = on ? 1 : 0; return 0; }
 extern "C" int aew_set_tn_big(int on, int target_blocks) {
-    g_tn_big = on ? 1 : 0;
-    if (target_blocks > 0) g_tn_big_target = target_blocks;
+    g_tune.tn_big = on ? 1 : 0;
+    if (target_blocks > 0) g_tune.tn_big_target = target_blocks;
     return 0;
 }
 extern "C" int aew_set_tn_small(int max_tiles, int target_blocks) {
     if (max_tiles < 0 || target_blocks < 1) return AEW_E_ARG;
-    g_tn_small_tiles = max_tiles;
-    g_tn_small_target = target_blocks;
+    g_tune.tn_small_tiles = max_tiles;
+    g_tune.tn_small_target = target_blocks;
     return 0;
 }
 extern "C" int aew_set_tn_target_blocks(int n) {
     if (n < 1) return AEW_E_ARG;
-    g_tn_target_blocks = n;
+    g_tune.tn_target_blocks = n;
     return 0;
 }
 extern "C" int aew_sampler_run(const aew_sampler_t* s, void* stream) {
     if (!s) return AEW_E_ARG;
     return launch_sampler(*s, reinterpret_cast<hipStream_t>(stream));
 }
-extern "C" int aew_set_nt_rows192(int mode) { g_nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
-extern "C" int aew_set_nt_mem128(int mode) { g_nt_mem128 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
-extern "C" int aew_set_nt_deep(int mode) { g_nt_deep = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return 0; }
-extern "C" int aew_set_nt_small_tiles(int n) { g_nt_small_tiles = n < 0 ? 0 : n; return 0; }
-extern "C" int aew_set_nf_loaders(int on) { g_nf_loaders = on ? 1 : 0; return 0; }
-extern "C" int aew_set_nf_deep(int max_blocks) { g_nf_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
-extern "C" int aew_set_nt_small_waves(int waves) { g_nt_small_w8 = waves >= 8 ? 1 : 0; return 0; }
-extern "C" int aew_set_nt_small_n64(int max_blocks) { g_nt_small_n64 = max_blocks < 0 ? 0 : max_blocks; return 0; }
-extern "C" int aew_set_nt_small_deep(int max_blocks) { g_nt_small_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
-extern "C" int aew_set_nt_pipe(int mode) { g_nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
+extern "C" int aew_set_nt_rows192(int mode) { g_tune.nt_rows192 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
+extern "C" int aew_set_nt_mem128(int mode) { g_tune.nt_mem128 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
+extern "C" int aew_set_nt_deep(int mode) { g_tune.nt_deep = mode < 0 ? 0 : (mode > 3 ? 3 : mode); return 0; }
+extern "C" int aew_set_nt_small_tiles(int n) { g_tune.nt_small_tiles = n < 0 ? 0 : n; return 0; }
+extern "C" int aew_set_nf_loaders(int on) { g_tune.nf_loaders = on ? 1 : 0; return 0; }
+extern "C" int aew_set_nf_deep(int max_blocks) { g_tune.nf_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
+extern "C" int aew_set_nt_small_waves(int waves) { g_tune.nt_small_w8 = waves >= 8 ? 1 : 0; return 0; }
+extern "C" int aew_set_nt_small_n64(int max_blocks) { g_tune.nt_small_n64 = max_blocks < 0 ? 0 : max_blocks; return 0; }
+extern "C" int aew_set_nt_small_deep(int max_blocks) { g_tune.nt_small_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
+extern "C" int aew_set_nt_pipe(int mode) { g_tune.nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_wave_rows(int rows) {
     if (rows != 0 && rows != 1 && rows != 64 && rows != 128 && rows != 256) return AEW_E_ARG;
-    g_nt_wave_rows = rows;
+    g_tune.nt_wave_rows = rows;
     return 0;
 }
 

@@ -43,7 +43,8 @@ class TrainEngine:
 
     def __init__(self, hps, B: int, device, n_mel: Optional[int] = None, loss_mode: str = "intended",
                  take_compat: bool = False, update_codebook_every_step: bool = True, impl: int = 0,
-                 n_win: Optional[int] = None, use_graphs: Optional[bool] = None, wgrad_group: Optional[int] = None):
+                 n_win: Optional[int] = None, use_graphs: Optional[bool] = None, wgrad_group: Optional[int] = None,
+                 tuning=None):
         self.hps, self.B, self.impl = hps, B, impl
         _SERIAL[0] += 1
         self.serial = _SERIAL[0]          # unique per engine (id() can be recycled after garbage collection)
@@ -58,6 +59,7 @@ class TrainEngine:
             wgrad_group = int(os.environ["AEW_WGRAD_GROUP"]) if os.environ.get("AEW_WGRAD_GROUP") is not None \
                 else DecoderPlan.wgrad_group
         self.wgrad_group = int(wgrad_group)
+        self.tuning = tuning              # _lib.Tuning (aew_tuning_t) for this engine's launches, or None
         self.kind = hps.global_model
         self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
         self.loss_mode, self.take_compat = loss_mode, take_compat
@@ -528,10 +530,12 @@ class TrainEngine:
         self.anneal_bwd.fill_(float(a) * float(getattr(self, "dp_world", 1)))
 
     def _run(self, plan, timing=False):
+        # self.tuning: an aew_tuning_t of this engine's own (None: the process-wide switches).  Note that plan
+        # CONSTRUCTION (split-K slab counts) always follows the process-wide record.
         if self.use_graphs and not timing:
-            plan.run_graph(self._stream())
+            plan.run_graph(self._stream(), tuning=self.tuning)
         else:
-            plan.run(self._stream())
+            plan.run(self._stream(), tuning=self.tuning)
 
     def _sub_plan(self, name: str, src: Plan, keep) -> Plan:
         """A plan made of the ops of `src` whose (index, label) passes `keep` (shares the op records)."""

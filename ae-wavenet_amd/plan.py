@@ -172,27 +172,37 @@ class Plan:
             L.load().aew_graph_destroy(self._graph)
             self._graph = None
 
-    def run_graph(self, stream: int = 0):
-        """Replay the plan as a hipGraph (captured on first use)."""
+    def run_graph(self, stream: int = 0, tuning: Optional["L.Tuning"] = None):
+        """Replay the plan as a hipGraph (captured on first use; `tuning` is what the capture runs under - a captured
+        graph keeps it, invalidate_graph() to change)."""
         if not self.ops:
             return
         lib = L.load()
         if self._graph is None:
             h = C.c_void_p()
             fail = C.c_int(-1)
-            rc = lib.aew_graph_capture(C.cast(self.array(), C.c_void_p), len(self.ops), C.byref(h), C.byref(fail))
+            if tuning is not None:
+                rc = lib.aew_graph_capture_tuned(C.cast(self.array(), C.c_void_p), len(self.ops), C.byref(h), C.byref(fail),
+                                                 C.byref(tuning))
+            else:
+                rc = lib.aew_graph_capture(C.cast(self.array(), C.c_void_p), len(self.ops), C.byref(h), C.byref(fail))
             if rc != 0:
                 lab = self.labels[fail.value] if 0 <= fail.value < len(self.labels) else "?"
                 L.check(rc, f"graph capture of plan '{self.name}' (op '{lab}')", fail.value)
             self._graph = h
         L.check(lib.aew_graph_launch(self._graph, C.c_void_p(stream)), f"graph launch '{self.name}'")
 
-    def run(self, stream: int = 0):
+    def run(self, stream: int = 0, tuning: Optional["L.Tuning"] = None):
+        """tuning: an aew_tuning_t for THIS call only (kernel shapes; the process-wide switches are not touched)."""
         if not self.ops:
             return
         fail = C.c_int(-1)
-        rc = L.load().aew_run_plan(C.cast(self.array(), C.c_void_p), len(self.ops), C.c_void_p(stream),
-                                   C.byref(fail))
+        if tuning is not None:
+            rc = L.load().aew_run_plan_tuned(C.cast(self.array(), C.c_void_p), len(self.ops), C.c_void_p(stream),
+                                             C.byref(fail), C.byref(tuning))
+        else:
+            rc = L.load().aew_run_plan(C.cast(self.array(), C.c_void_p), len(self.ops), C.c_void_p(stream),
+                                       C.byref(fail))
         if rc != 0:
             lab = self.labels[fail.value] if 0 <= fail.value < len(self.labels) else "?"
             L.check(rc, f"plan '{self.name}' op '{lab}'", fail.value)

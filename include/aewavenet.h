@@ -14,7 +14,8 @@
  *   - activations are CHANNELS-LAST: tensor[b][t][c], c fastest.  bf16 is stored as uint16
  *   - "row" means a time index t; a buffer is addressed as
  *         ptr + b*batch_stride + row*row_pitch + c            (element units)
- *   - descriptors carry everything an op computes WITH; the only process-wide state are the aew_set_* switches
+ *   - descriptors carry everything an op computes WITH; kernel-shape choices live in a tuning record (aew_tuning_t): the
+ *     aew_set_* switches edit the process-wide one, aew_run_plan_tuned takes a caller's own
  *     (kernel shape / schedule choices for A-B measurements and bisecting; results are the same under every setting
  *     unless a switch says otherwise).  They default to the production choice, are not thread-safe, and take effect
  *     for launches / graph captures made afterwards; a caller that never touches them gets a stateless library
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 16
+#define AEW_ABI_VERSION 17
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -515,6 +516,45 @@ int aew_graph_destroy(void* exec);
 /* Per-op timing: while enabled, aew_run_plan brackets every op with HIP events on `stream`;
  * aew_timing_read synchronises the stream and returns elapsed ms per executed op (in
  * execution order since the last enable) and its tag. */
+/* =======================================================================================
+ * Tuning context (ABI 17).  Every aew_set_* switch below edits ONE process-wide instance of this record; a caller that
+ * wants its own settings - two engines with different shapes in one process, an A/B that must not leak - passes a record
+ * to aew_run_plan_tuned / aew_graph_capture_tuned instead, which applies to that call only (thread-local for its duration;
+ * a captured graph keeps the settings it was captured under).  aew_tuning_default fills in the library defaults,
+ * aew_tuning_get the current process-wide values.  None of the fields changes a result beyond what the individual
+ * switch documents (bit-identical shapes; the one-window kernel's summation order).
+ * ======================================================================================= */
+typedef struct {
+    int32_t nt_wave_rows;
+    int32_t nt_pipe;
+    int32_t nt_rows192;
+    int32_t nt_small_tiles;
+    int32_t nt_small_n64;
+    int32_t nt_small_w8;
+    int32_t nt_small_deep;
+    int32_t nt_window;
+    int32_t nt_mem128;
+    int32_t nt_deep;
+    int32_t nf_loaders;
+    int32_t nf_deep;
+    int32_t fn_enable;
+    int32_t fn_ring3;
+    int32_t tn_safe;
+    int32_t tn_big;
+    int32_t tn_big_target;
+    int32_t tn_fold_rows;
+    int32_t tn_target_blocks;
+    int32_t tn_small_tiles;
+    int32_t tn_small_target;
+    int32_t lanes;
+    int32_t reserved_[10];
+} aew_tuning_t;
+int aew_tuning_default(aew_tuning_t* out);
+int aew_tuning_get(aew_tuning_t* out);
+int aew_tuning_set(const aew_tuning_t* in);          /* replaces the process-wide instance (values are clamped like the setters') */
+int aew_run_plan_tuned(const aew_op_t* ops, int n, void* stream, int* fail_index, const aew_tuning_t* tuning);
+int aew_graph_capture_tuned(const aew_op_t* ops, int n, void** exec_out, int* fail_index, const aew_tuning_t* tuning);
+
 int aew_timing_enable(int on);
 int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);
 

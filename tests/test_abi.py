@@ -38,10 +38,37 @@ def test_abi_version_and_struct_sizes():
     version = int(re.search(r"#define\s+AEW_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
     assert lib.aew_abi_version() == version
     for which, cls in ((0, L.Op), (1, L.GemmNT), (2, L.GemmTN), (3, L.Seg), (4, L.View), (5, L.CopyRec), (6, L.Actor),
-                       (7, L.Sampler)):
+                       (7, L.Sampler), (8, L.Tuning)):
         assert lib.aew_sizeof(which) == C.sizeof(cls), cls.__name__
     assert lib.aew_sizeof(99) == -1
     assert lib.aew_strerror(-1) and lib.aew_strerror(0)
+
+
+def test_tuning_record_defaults_get_set_and_clamping():
+    """aew_tuning_t (ABI 17): the aew_set_* switches edit the process-wide record, aew_tuning_get reads it back,
+    aew_tuning_set replaces it (clamped like the setters), aew_tuning_default never changes.  Host logic only."""
+    lib = L.load()
+    d, cur = L.Tuning(), L.Tuning()
+    assert lib.aew_tuning_default(C.byref(d)) == 0 and lib.aew_tuning_get(C.byref(cur)) == 0
+    assert (d.nt_wave_rows, d.nt_window, d.nt_rows192, d.lanes, d.fn_enable, d.tn_target_blocks) == (64, 64, 1, 0, 1, 512)
+    assert bytes(d) == bytes(cur), "the process-wide record starts at the defaults"
+    try:
+        lib.aew_set_nt_window(16)
+        lib.aew_set_lanes(7)                                     # clamped to 2
+        lib.aew_tuning_get(C.byref(cur))
+        assert (cur.nt_window, cur.lanes) == (16, 2)
+        t = L.default_tuning(nt_wave_rows=77, nt_mem128=9, tn_target_blocks=0)     # nonsense values: clamped / reset
+        assert lib.aew_tuning_set(C.byref(t)) == 0
+        lib.aew_tuning_get(C.byref(cur))
+        assert (cur.nt_wave_rows, cur.nt_mem128, cur.tn_target_blocks, cur.nt_window) == (64, 2, 1, 64)
+        lib.aew_tuning_default(C.byref(cur))
+        assert bytes(cur) == bytes(d)
+        with pytest.raises(AttributeError):
+            L.default_tuning(no_such_field=1)
+    finally:
+        lib.aew_tuning_set(C.byref(d))
+    lib.aew_tuning_get(C.byref(cur))
+    assert bytes(cur) == bytes(d)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

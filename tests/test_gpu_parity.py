@@ -237,6 +237,39 @@ def test_gemm_nt_mem128(epi):
         lib.aew_set_nt_small_tiles(128)
 
 
+def test_tuned_run_uses_the_callers_record_and_leaves_the_process_state_alone():
+    """aew_run_plan_tuned: a caller's aew_tuning_t applies to that call only.  The same GEMM through three records (fat
+    waves, 192-row tiles, 128-row memory-bound tiles) gives the bit-identical result of the default shape, and the
+    process-wide record - what aew_nt_kernel and every untuned call see - is untouched."""
+    import ctypes as C
+    gen = torch.Generator().manual_seed(9)
+    ws_c = Workspace("cpu")
+    _alloc_nt(ws_c, BF, L.EPI_DFG)
+    for n in ("A1", "A2", "X0", "X1", "O1", "bias"):
+        _fill(ws_c, n, gen)
+    _fill(ws_c, "W", gen, 0.08)
+    lib = L.load()
+    before = L.Tuning()
+    lib.aew_tuning_get(C.byref(before))
+    ref = None
+    for over in ({}, dict(nt_wave_rows=128), dict(nt_rows192=2, nt_small_tiles=0), dict(nt_mem128=1, nt_small_tiles=0),
+                 dict(nt_wave_rows=256, nt_pipe=0)):
+        ws_g = _mirror(ws_c, DEV)
+        p = Plan("nt")
+        g = _nt_case(ws_g, BF, L.EPI_DFG, 0)
+        p.add(L.OP_GEMM_NT, g, "nt")
+        p.run(stream(), tuning=L.default_tuning(**over) if over else None)
+        torch.cuda.synchronize()
+        res = ws_g.get("O0").float().cpu()
+        if ref is None:
+            ref = res
+            assert float(ref.abs().max()) > 0
+        assert torch.equal(res, ref), over
+        after = L.Tuning()
+        lib.aew_tuning_get(C.byref(after))
+        assert bytes(after) == bytes(before), over
+
+
 def _win_case(ws, kind, d, impl):
     """The two shapes the decoder runs on the window kernel: the gated layer (wavenet.py:100-101: x[t], x[t+d] of one
     tensor + the conditioning projection) and its input gradient (dfg[t], dfg[t-d], rows outside dfg read as zero)."""
