@@ -37,6 +37,9 @@ class TrainEngine:
     VQ-VAE-EMA); the reference only refreshes at global_step == 10000 (chassis.py:175-176).
     """
     DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
+    LANE_PACK_DEC = 1         # side lane of the decoder's forward-layout weight pack (joined by the end of fwd_a) ...
+    LANE_PACK_LATE = 2        # ... and of the backward-layout pack at the head of fwd_b (joined by its end).  4 / 5: the lanes
+                              # aew_set_lanes(2) honours alone (A/B: each a single fork / join, profiles/r04_notes.md §16)
     PACK_LANE = 2             # side lane of the forward-layout weight pack (layers 1.. of the encoder, biases, bottleneck)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
                               # forward plan; A/B: 8.02 -> 7.99 ms per step)
@@ -238,7 +241,7 @@ class TrainEngine:
                 an = self._ae_norm_op(False)
                 fa.add(L.OP_AE_NORM, an, "ae.norm", TAG_VQ)
         # ===== forward, part B: decoder + loss
-        with fb.side(2):                                       # only the backward reads these: hidden under the decoder
+        with fb.side(self.LANE_PACK_LATE):                     # only the backward reads these: hidden under the decoder
             self.pack_late.emit(fb, "pack weights (backward layouts)")
         for op in fb.ops[-1:] if self.pack_late.recs else []:
             op.tag = TAG_PACK
@@ -449,7 +452,7 @@ class TrainEngine:
             self.cb.add(L.OP_VQ_EMA, em, "vq.codebook", TAG_VQ)
         # pack goes first in fwd_a (its table is complete only now)
         pk_plan = Plan("pack")
-        with pk_plan.side():                                   # joined by the end of fwd_a
+        with pk_plan.side(self.LANE_PACK_DEC):                 # joined by the end of fwd_a
             self.pack_dec.emit(pk_plan, "pack weights (decoder)")
         if self.pack_first is not None and self.pack_first.recs:
             self.pack_first.emit(pk_plan, "pack weights (encoder layer 0)")

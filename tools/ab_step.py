@@ -55,6 +55,9 @@ def main():
 
     def owner(k):                                  # E.tiled: the copy-table builder's switch; everything else DecoderPlan's
         from ae_wavenet_amd import plan as PLN
+        if k.startswith("LANE_"):
+            from ae_wavenet_amd import model as MDL
+            return MDL.TrainEngine
         return PLN.CopyTableBuilder if k in ("tiled", "interleave") else E.DecoderPlan
 
     def engine_for(ekey):
@@ -66,7 +69,7 @@ def main():
             model = ae.AutoEncoder(hps, n_mel=39).to(dev)
             eng = model._ensure_engine(args.batch)
             for k, v in e_defaults.items():
-                setattr(E.DecoderPlan, k, v)
+                setattr(owner(k), k, v)
             g = eng.geom
             gen = torch.Generator().manual_seed(0)
             wav = torch.randint(0, 256, (args.batch, g.enc_in_len), generator=gen).float().to(dev)
