@@ -7,6 +7,7 @@
 #include "aew_sampler.hip"
 
 #include <vector>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // timing (HIP events on the plan's stream; used by bench.py for the roofline numbers)
@@ -89,7 +90,11 @@ static hipEvent_t lane_event() {
     const size_t POOL = 64;
     if (g_lane_ev.size() < POOL) {
         hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        // device-scope release: an event recorded for a wait on another stream of the SAME device must not flush to
+        // system scope (AEW_LANE_EVENT_FLAGS: A/B aid, profiles/r04_notes.md §16)
+        static const char* fl = getenv("AEW_LANE_EVENT_FLAGS");
+        const unsigned flags = fl ? (unsigned)strtoul(fl, nullptr, 0) : (hipEventDisableTiming | hipEventReleaseToDevice);
+        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return nullptr;
         g_lane_ev.push_back(e);
         return e;
     }
