@@ -310,6 +310,17 @@ def default_tuning(**over) -> "Tuning":
     return t
 
 
+def current_tuning(**over) -> "Tuning":
+    """A copy of the process-wide tuning record (what the aew_set_* switches have made of it), fields overridden by keyword."""
+    t = Tuning()
+    check(load().aew_tuning_get(C.byref(t)), "aew_tuning_get")
+    for k, v in over.items():
+        if not hasattr(t, k):
+            raise AttributeError(f"aew_tuning_t has no field {k}")
+        setattr(t, k, int(v))
+    return t
+
+
 def tn_slabs(tn: GemmTN) -> int:
     """Number of fp32 partial slabs a TN op writes (host-side mirror is the library itself so
     the split heuristic has a single definition)."""

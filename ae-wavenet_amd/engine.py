@@ -215,6 +215,15 @@ class DecoderPlan:
                               # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
                               # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
                               # independent blocks per CU reach 43 GB/s together
+    tail_lane = 0             # 4: the LAST grouped weight-gradient launch, the speaker / gated-bias gradients that read its column
+                              # sums and the decoder's gradient unpack form one side branch on this lane (lane mode 2 honours
+                              # lanes 4 / 5 alone; TrainEngine.graph_lanes), and everything else after the dgrad chain - cond
+                              # gradient, upsampler / LC backward, bottleneck and encoder backward: ~0.6 ms of small launches
+                              # that depend on no weight gradient - runs beside it on the main lane: ONE fork after dx.0, one
+                              # join before the last unpack.  Measured on three boxes, interleaved: 6.83 vs 6.91, 6.99 vs 6.97,
+                              # 6.99 vs 6.90 ms per step - the grouped launch holds three blocks on most CUs for its whole 1.6
+                              # ms, so the small launches only get the leftover slots, and the fork / join costs what that
+                              # returns (profiles/r04_notes.md 18).  0 (default): serial plan order
     wgrad_split_layers = 0    # with grouped wgrads: the TOP this-many layers keep one split-K TN op per matrix (they run
                               # under the dgrad chain and fill its tile-wave tails), the rest go to the grouped launch
     ups_split_rows = 1024     # upsampler / lc-conv weight gradients (few output tiles): contractions longer than this many
@@ -617,7 +626,8 @@ class DecoderPlan:
             plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
 
     def _next_lane(self, kind: str = "") -> int:
-        self._lane_rr = getattr(self, "_lane_rr", 0) % max(1, min(self.n_side_lanes, Plan.N_SIDE)) + 1
+        n = min(self.n_side_lanes, Plan.N_SIDE, 3)             # lanes 4 / 5 are for explicit branches (tail_lane, split_chains)
+        self._lane_rr = getattr(self, "_lane_rr", 0) % max(1, n) + 1
         return self._lane_rr
 
     def _wgrad(self, plan: Plan, name: str, dtype: int, Mc: int, N: int, N_pad: int, gseg: L.Seg,
@@ -842,7 +852,7 @@ class DecoderPlan:
                 if grp is None:
                     grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
                 grp.add(t, "wgrad." + name)
-            with plan.side(self._next_lane("tng")):
+            with plan.side(self.tail_lane or self._next_lane("tng")):
                 grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)" if not multi else
                          f"wgrad.group{n_groups} (layers 0.., base)", TAG_WG_FG)
             grp = None
@@ -853,6 +863,20 @@ class DecoderPlan:
         for l in range(NL if skp is None else 0):
             pk.rec(p + f"conv_layers.{l}.dil_skp.weight", 0, [D, 1], [S, D], None, 0, [NL * Dp, 1],
                    g_ptr=gp, slabs=gn, slab_stride=gs, g_off=l * Dp)
+        # ---- speaker / gated-bias gradients (tail_lane: right behind the last grouped launch, before any main-lane op,
+        # so that the branch needs no second edge from the main lane)
+        def emit_spk():
+            sbw = L.SpkBwd()
+            self._fill_spk(sbw)
+            sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
+            sbw.colsum_running = max(0, NL - self.wgrad_split_layers) if snap_ok else 0
+            if getattr(self, "_spk_hi_from", None):                    # the upper layers were done after the first group
+                sbw.layer_range = 0 | (self._spk_hi_from << 16)
+            with plan.side(self.tail_lane or 1):                       # reads the side lanes' wgrad slabs: side join
+                colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
+                plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)
+        if self.tail_lane:
+            emit_spk()
         # ---- conditioning gradient over all layers' dfg (wavenet.py:100-101 cond terms).  With split_multiseg the
         # layers [n_lo, NL) were summed on a side lane mid-chain (dcond_part); this GEMM adds them.
         lo = self.n_lo
@@ -865,16 +889,8 @@ class DecoderPlan:
             segs = [self.dfg[l].seg(2 * Dp, row_off=-lg.cond_lead) for l, lg in enumerate(g.layers)]
             plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT_lo.ptr, out0=self.dcond.view(),
                                            impl=self._impl("dcond")), "dcond", TAG_DCOND)
-        # ---- speaker / gated-bias gradients
-        sbw = L.SpkBwd()
-        self._fill_spk(sbw)
-        sbw.colsum, sbw.gc, sbw.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
-        sbw.colsum_running = max(0, NL - self.wgrad_split_layers) if snap_ok else 0
-        if getattr(self, "_spk_hi_from", None):                    # the upper layers were done after the first group
-            sbw.layer_range = 0 | (self._spk_hi_from << 16)
-        with plan.side(1):                                         # reads the side lanes' wgrad slabs: side join
-            colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
-            plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)
+        if not self.tail_lane:
+            emit_spk()
         # ---- upsamplers, last stage first (wavenet.py:154)
         n_ups = len(hps.lc_upsample_strides)
         ugrp = TnGroupBuilder(self.ws, p + "tng_ups", 128) if grouped else None     # upsampler + LC-conv wgrads: one launch

@@ -38,6 +38,9 @@ class TrainEngine:
     """
     DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
     LANE_PACK_DEC = 1         # side lane of the decoder's forward-layout weight pack (joined by the end of fwd_a) ...
+    graph_lanes = 2           # lane mode of graph captures when the process-wide mode is 0 (aew_set_lanes): 2 = lanes 4 / 5 are
+                              # branches, everything else in plan order.  Eager runs stay serial (one cross-stream edge costs
+                              # more there than the branch returns: 7.27 vs 6.90 ms per step).  0: never
     LANE_PACK_LATE = 2        # ... and of the backward-layout pack at the head of fwd_b (joined by its end).  4 / 5: the lanes
                               # aew_set_lanes(2) honours alone (A/B: each a single fork / join, profiles/r04_notes.md §16)
     PACK_LANE = 2             # side lane of the forward-layout weight pack (layers 1.. of the encoder, biases, bottleneck)
@@ -356,7 +359,7 @@ class TrainEngine:
             mo.out = self.gstat.data_ptr() + 4 * slot
             with bw.side(1):
                 bw.add(L.OP_MOMENTS, mo, f"grad stats ({nm})", TAG_LOSS)
-        with bw.side(1):                                       # after every decoder wgrad on any side lane
+        with bw.side(self.dec.tail_lane or 1):                 # after every decoder wgrad on any side lane
             self.unpack_dec.emit(bw, "unpack grads (decoder)", join=True)
         if self.enc is not None:
             moments(self.dec.dlc_src, hps.bn_n_out, 4, "bn")
@@ -536,7 +539,14 @@ class TrainEngine:
         # self.tuning: an aew_tuning_t of this engine's own (None: the process-wide switches).  Note that plan
         # CONSTRUCTION (split-K slab counts) always follows the process-wide record.
         if self.use_graphs and not timing:
-            plan.run_graph(self._stream(), tuning=self.tuning)
+            tun = self.tuning
+            if self.graph_lanes and plan._graph is None and any(op.lane >= 4 for op in plan.ops):
+                # capture: lanes 4 / 5 (DecoderPlan.tail_lane: the last grouped weight-gradient launch as a branch beside
+                # the rest of the backward) become graph branches unless the caller chose a lane mode itself
+                tun = L.current_tuning() if tun is None else L.Tuning.from_buffer_copy(tun)
+                if tun.lanes == 0:
+                    tun.lanes = self.graph_lanes
+            plan.run_graph(self._stream(), tuning=tun)
         else:
             plan.run(self._stream(), tuning=self.tuning)
 

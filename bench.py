@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--jitter-prob", dest="jitter_prob", type=float, default=0.12, help="par/train.basic.json")
-    ap.add_argument("--lanes", type=int, default=0, help="1: side-lane ops on their own streams / graph branches (default 0: serial plan order)")
+    ap.add_argument("--lanes", type=int, default=0, help="1: every side-lane op on its own stream / graph branch (default 0: plan order, except the tail branch below)")
+    ap.add_argument("--tail-lane", dest="tail_lane", type=int, default=0, help="4: the last grouped wgrad launch as a graph branch beside the rest of the backward (A/B aid); 0: serial")
     ap.add_argument("--nt-wave-rows", dest="nt_wave_rows", type=int, default=64, help="bf16 NT shape (64|128|256)")
     ap.add_argument("--nt-pipe", dest="nt_pipe", type=int, default=1, help="0 plain loop, 1 pipelined, 2 pipelined K=64 tiles")
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")
@@ -268,6 +269,7 @@ def main():
         lib.aew_set_tn_small(a, b)
     from ae_wavenet_amd import engine as _E
     _E.DecoderPlan.split_chains = args.chains == 2
+    _E.DecoderPlan.tail_lane = args.tail_lane
     if args.side_lanes:
         _E.DecoderPlan.n_side_lanes = args.side_lanes
     if os.environ.get("AEW_DIAG_EARLY") is not None:             # A/B aid: 0 = per-step diagnostics at the tail of the forward plan

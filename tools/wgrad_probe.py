@@ -19,7 +19,24 @@ B, M, NL = 8, int(os.environ.get("ROWS", "6500")), 20
 Rp, Dp, Cp = 384, 256, 128
 
 
+def layer_rows():
+    """rows each layer's matrices contract over per batch element: VARY=1 the model's (7045 ... 5000: the output length
+    shrinks by the dilation per layer), else ROWS for every layer"""
+    if os.environ.get("VARY", "0") != "1":
+        return [M] * NL
+    rows, n = [], 7046
+    for l in range(NL):
+        n -= 1 << (l % 10)
+        rows.append(n)
+    if os.environ.get("VARY_MEAN", "0") == "1":                 # the same total work, spread evenly
+        return [sum(rows) // NL] * NL
+    return rows
+
+
 def build(shared, tile=128, order=None):
+    global M
+    rows = layer_rows()
+    M = max(rows)
     ws = Workspace(dev)
     nbuf = 1 if shared else NL
     x = [Mat.new(ws, f"x{l}", B, M + 600, Rp, L.BF16) for l in range(nbuf)]
@@ -34,11 +51,12 @@ def build(shared, tile=128, order=None):
     for l in range(NL):
         k = 0 if shared else l
         d = 1 << (l % 10)
-        t = make_tn(L.BF16, M, B, 2 * Dp, 2 * Dp, dfg[k].seg(2 * Dp), [x[k].seg(Rp), x[k].seg(Rp, row_off=d), cond.seg(Cp, row_off=d)])
+        Ml = rows[l]
+        t = make_tn(L.BF16, Ml, B, 2 * Dp, 2 * Dp, dfg[k].seg(2 * Dp), [x[k].seg(Rp), x[k].seg(Rp, row_off=d), cond.seg(Cp, row_off=d)])
         o = ws.alloc(f"ofg{l}", 2 * Dp * (2 * Rp + Cp), torch.float32)
         t.out, t.out_batch_stride = o.data_ptr(), 2 * Dp * (2 * Rp + Cp)
         gb.add(t, f"fg{l}")
-        t = make_tn(L.BF16, M, B, 368, Rp, dx[k].seg(Rp), [z[k].seg(Dp)])
+        t = make_tn(L.BF16, Ml, B, 368, Rp, dx[k].seg(Rp), [z[k].seg(Dp)])
         o = ws.alloc(f"ors{l}", Rp * Dp, torch.float32)
         t.out, t.out_batch_stride = o.data_ptr(), Rp * Dp
         gb.add(t, f"res{l}")
@@ -63,7 +81,8 @@ def timeit(p):
 
 
 def main():
-    flops = NL * 2.0 * B * M * (2 * Dp * (2 * Rp + Cp) + Rp * Dp)
+    flops = sum(layer_rows()) * 2.0 * B * (2 * Dp * (2 * Rp + Cp) + Rp * Dp)
+    print("rows per layer:", layer_rows())
     for shared in (False, True):
         ws, p, gb = build(shared)
         ms = timeit(p)
