@@ -215,6 +215,7 @@ class DecoderPlan:
                               # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
                               # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
                               # independent blocks per CU reach 43 GB/s together
+    split_chains_bwd = False  # the backward's dz / dx chain as two half-batch chains on lanes 4 / 5 (see split_chains)
     tail_lane = 0             # 4: the LAST grouped weight-gradient launch, the speaker / gated-bias gradients that read its column
                               # sums and the decoder's gradient unpack form one side branch on this lane (lane mode 2 honours
                               # lanes 4 / 5 alone; TrainEngine.graph_lanes), and everything else after the dgrad chain - cond
@@ -228,9 +229,14 @@ class DecoderPlan:
                               # under the dgrad chain and fill its tile-wave tails), the rest go to the grouped launch
     ups_split_rows = 1024     # upsampler / lc-conv weight gradients (few output tiles): contractions longer than this many
                               # rows x batch are cut into 512-row chunks (one block and one slab each) in the grouped launch
-    split_chains = False      # True: gated stack as two half-batch chains on the two lanes (build_forward);
-                              # measured slower (8.86 vs 8.62 ms/step): half-batch launches lose more than the
-                              # overlap of their tails returns
+    split_chains = False      # True: gated stack as two half-batch chains on lanes 4 / 5 (build_forward); split_chains_bwd: the
+                              # same for the backward's dz / dx chain.  Captured as graph branches (TrainEngine.graph_lanes) both
+                              # together return 0.07-0.125 ms per step (five boxes, interleaved: 6.95 -> 6.85, 6.97 -> 6.905,
+                              # 6.98 -> 6.885, 6.85 -> 6.755, 6.945 -> 6.82; either one alone: -0.09 ... +0.03), bit-identical
+                              # results (tests/test_gpu_parity.py).  Default off: two concurrent half-batch launches each run
+                              # longer than half a full-batch launch, so every per-kernel duration - HIP events in serial
+                              # timing mode, rocprofv3 under overlap - and with it the roofline line of bench.py would stop
+                              # describing the kernel; 1.5 % of the step is less than the box-to-box spread (profiles/r04_notes.md 19)
 
     def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, pre: str,
                  n_lc_in: int, lc_src: Mat, wav: torch.Tensor, voice: torch.Tensor,
@@ -737,6 +743,14 @@ class DecoderPlan:
         Cc = Clc + self.Gc
         dx_next: Optional[Mat] = None
         colsum_tbl = CopyTableBuilder(self.ws, p + "tbl.colsum")
+        # split_chains_bwd: the dz / dx chain as two independent half-batch chains on lanes 4 / 5 (the mirror of the
+        # forward's split_chains; grouped weight gradients only, so that nothing else sits inside the chain)
+        n_chains = 2 if (self.split_chains_bwd and grouped and not multi and snap_ok and self.wgrad_split_layers == 0
+                         and B % 2 == 0 and self.n_lo >= NL) else 1
+        nb = B // n_chains
+        # (the tail branch is for the one-chain plan only: queued behind a chain on lane 4 it needs lanes 4 and 5 to wait
+        # for each other in turn, and capturing that shape crashes inside the runtime - ROCm 7.2)
+        tail = self.tail_lane_used = self.tail_lane if n_chains == 1 else 0
         for l in range(NL - 1, -1, -1):
             lg = g.layers[l]
             last = l == NL - 1
@@ -746,9 +760,16 @@ class DecoderPlan:
             if not last:
                 segs.append(dx_next.seg(Rp, hi=P_l))
             segs.append(self.dskp.seg(Sp, row_off=-lg.skip_lead))
-            plan.add(L.OP_GEMM_NT, make_nt(BF, P_l, Dp, Dp, B, segs, self.WrsT[l].ptr, epi=L.EPI_DFG,
-                                           aux0=self.pf[l].view(), aux1=self.pg[l].view(),
-                                           out0=self.dfg[l].view(), impl=self._impl("dz")), f"dz.{l}", TAG_DZ)
+            for c in range(n_chains):
+                b0 = c * nb
+                plan.lane = (4 + c) if n_chains > 1 else 0
+                csegs = segs if n_chains == 1 else \
+                    ([] if last else [dx_next.seg(Rp, hi=P_l, b0=b0)]) + [self.dskp.seg(Sp, row_off=-lg.skip_lead, b0=b0)]
+                plan.add(L.OP_GEMM_NT, make_nt(BF, P_l, Dp, Dp, nb, csegs, self.WrsT[l].ptr, epi=L.EPI_DFG,
+                                               aux0=self.pf[l].view(b0=b0), aux1=self.pg[l].view(b0=b0),
+                                               out0=self.dfg[l].view(b0=b0), impl=self._impl("dz")),
+                         f"dz.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_DZ)
+            plan.lane = 0
             if self.n_lo < NL and l == self.n_lo:
                 hsegs = [self.dfg[k].seg(2 * Dp, row_off=-g.layers[k].cond_lead) for k in range(self.n_lo, NL)]
                 with plan.side(self.EARLY_LANE):               # upper half of the cond gradient: inputs complete
@@ -816,12 +837,17 @@ class DecoderPlan:
                     pk.unpack_tbl = late_tbl
                     early_tbl = None
             dx = self.dx[l]
-            segs = [self.dfg[l].seg(2 * Dp), self.dfg[l].seg(2 * Dp, row_off=-d)]
-            plan.add(L.OP_GEMM_NT, make_nt(
-                BF, lg.in_len, Rp, Rp, B, segs, self.WfgT[l].ptr,
-                flags=0 if last else L.EF_ADD_AUX0,
-                out0=dx.view(hi=lg.in_len),
-                aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l), impl=self._impl("dx")), f"dx.{l}", TAG_DX)
+            for c in range(n_chains):
+                b0 = c * nb
+                plan.lane = (4 + c) if n_chains > 1 else 0
+                segs = [self.dfg[l].seg(2 * Dp, b0=b0), self.dfg[l].seg(2 * Dp, row_off=-d, b0=b0)]
+                plan.add(L.OP_GEMM_NT, make_nt(
+                    BF, lg.in_len, Rp, Rp, nb, segs, self.WfgT[l].ptr,
+                    flags=0 if last else L.EF_ADD_AUX0,
+                    out0=dx.view(hi=lg.in_len, b0=b0),
+                    aux0=null_view() if last else dx_next.view(row_off=-d, hi=P_l, b0=b0), impl=self._impl("dx")),
+                    f"dx.{l}" + (f".c{c}" if n_chains > 1 else ""), TAG_DX)
+            plan.lane = 0
             dx_next = dx
             if not grouped and early_tbl is not None and l == NL // 2:
                 with plan.side(1):                                 # after the wgrads issued so far, on any lane
@@ -852,9 +878,9 @@ class DecoderPlan:
                 if grp is None:
                     grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
                 grp.add(t, "wgrad." + name)
-            with plan.side(self.tail_lane or self._next_lane("tng")):
+            with plan.side(tail or self._next_lane("tng")):
                 grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)" if not multi else
-                         f"wgrad.group{n_groups} (layers 0.., base)", TAG_WG_FG)
+                         f"wgrad.group{n_groups} (layers 0.., base)", TAG_WG_FG, join=n_chains > 1)
             grp = None
             if early_tbl is not None:                              # a single group: nothing was unpacked mid-chain
                 pk.unpack_tbl = late_tbl
@@ -872,10 +898,10 @@ class DecoderPlan:
             sbw.colsum_running = max(0, NL - self.wgrad_split_layers) if snap_ok else 0
             if getattr(self, "_spk_hi_from", None):                    # the upper layers were done after the first group
                 sbw.layer_range = 0 | (self._spk_hi_from << 16)
-            with plan.side(self.tail_lane or 1):                       # reads the side lanes' wgrad slabs: side join
+            with plan.side(tail or 1):                                 # reads the side lanes' wgrad slabs: side join
                 colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
                 plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)
-        if self.tail_lane:
+        if tail:
             emit_spk()
         # ---- conditioning gradient over all layers' dfg (wavenet.py:100-101 cond terms).  With split_multiseg the
         # layers [n_lo, NL) were summed on a side lane mid-chain (dcond_part); this GEMM adds them.
@@ -888,8 +914,9 @@ class DecoderPlan:
         else:
             segs = [self.dfg[l].seg(2 * Dp, row_off=-lg.cond_lead) for l, lg in enumerate(g.layers)]
             plan.add(L.OP_GEMM_NT, make_nt(BF, T, Cp, Cp, B, segs, self.VfgT_lo.ptr, out0=self.dcond.view(),
-                                           impl=self._impl("dcond")), "dcond", TAG_DCOND)
-        if not self.tail_lane:
+                                           impl=self._impl("dcond")), "dcond", TAG_DCOND,
+                     join=n_chains > 1)          # two chains: the main lane meets them here at the latest (every lane mode)
+        if not tail:
             emit_spk()
         # ---- upsamplers, last stage first (wavenet.py:154)
         n_ups = len(hps.lc_upsample_strides)

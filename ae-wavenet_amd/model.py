@@ -359,7 +359,7 @@ class TrainEngine:
             mo.out = self.gstat.data_ptr() + 4 * slot
             with bw.side(1):
                 bw.add(L.OP_MOMENTS, mo, f"grad stats ({nm})", TAG_LOSS)
-        with bw.side(self.dec.tail_lane or 1):                 # after every decoder wgrad on any side lane
+        with bw.side(getattr(self.dec, "tail_lane_used", 0) or 1):                 # after every decoder wgrad on any side lane
             self.unpack_dec.emit(bw, "unpack grads (decoder)", join=True)
         if self.enc is not None:
             moments(self.dec.dlc_src, hps.bn_n_out, 4, "bn")

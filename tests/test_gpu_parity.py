@@ -1342,6 +1342,54 @@ def test_full_size_properties():
     assert torch.equal(eng.logits(), lg0)
 
 
+def test_half_batch_chains_and_tail_branch_are_bit_identical_to_the_serial_plan(monkeypatch):
+    """DecoderPlan.split_chains / split_chains_bwd (the gated stack and its dgrad chain as two half-batch chains on lanes
+    4 / 5) and tail_lane (the last grouped weight-gradient launch as a branch) only re-schedule: captured as graph branches
+    (TrainEngine.graph_lanes) or run serially they must give the one-chain engine's loss and gradients, replay after
+    replay - a missing dependency shows as a mismatch."""
+    from ae_wavenet_amd import engine as E
+    for k in ("split_chains", "split_chains_bwd", "tail_lane"):
+        monkeypatch.setattr(E.DecoderPlan, k, 0)
+    hps, eng0, wts, emb, inp = seeded_full_engine(B=8, w=5000, seed=11)
+    wav, mel, voice, jitter = [t.to(DEV) for t in inp]
+
+    def step(eng):
+        eng.init_ema_from_emb()
+        loss = float(eng.forward())
+        eng.backward()
+        torch.cuda.synchronize()
+        return loss, eng.ps.grads[:eng.ps.numel].clone()
+
+    eng0.set_inputs(wav, mel, voice, jitter)
+    assert not any(op.lane >= 4 for op in eng0.bwd.ops + eng0.fwd_b.ops)
+    l_ref, g_ref = step(eng0)
+    atomic = [n for n in eng0.ps.names() if n.endswith(".bias") or "speaker_embedding" in n]
+    mask = torch.ones(eng0.ps.numel, dtype=torch.bool, device=DEV)
+    for n in atomic:                                   # fp32-atomic column sums: round-off, as in the lane test below
+        o = (eng0.ps.view(n, True).data_ptr() - eng0.ps.grads.data_ptr()) // 4
+        mask[o:o + eng0.ps.numel_of(n)] = False
+    del eng0
+    torch.cuda.empty_cache()
+    for cfg in (dict(split_chains=1, split_chains_bwd=1), dict(tail_lane=4)):
+        for k in ("split_chains", "split_chains_bwd", "tail_lane"):
+            monkeypatch.setattr(E.DecoderPlan, k, cfg.get(k, 0))
+        _, eng, _, _, _ = seeded_full_engine(B=8, w=5000, seed=11)
+        eng.set_inputs(wav, mel, voice, jitter)
+        assert any(op.lane >= 4 for op in eng.bwd.ops)
+        assert eng.graph_lanes == 2 and eng.use_graphs
+        for rep in range(4):
+            l, g = step(eng)
+            assert l == l_ref, (cfg, rep, l, l_ref)
+            assert torch.equal(g[mask], g_ref[mask]), (cfg, rep)
+            d = (g[~mask] - g_ref[~mask]).abs().max().item()
+            assert d <= 2e-6 * g_ref[~mask].abs().max().item(), (cfg, rep, d)
+        eng.use_graphs = False                         # eager: serial plan order (lanes stay off outside a capture)
+        l, g = step(eng)
+        assert l == l_ref and torch.equal(g[mask], g_ref[mask]), cfg
+        del eng
+        torch.cuda.empty_cache()
+
+
 def test_two_lane_schedule_is_bit_identical_to_serial():
     """The side-lane assignment (wgrads / column sums off the dgrad chain, aew_op_t.lane) must not
     change any result: serial plan order is the reference schedule.  Replayed several times in graph
