@@ -55,7 +55,8 @@ class GemmTN(C.Structure):
 
 
 class GemmTNGroup(C.Structure):
-    _fields_ = [("descs", vp), ("tile_map", vp), ("n_descs", i32), ("n_blocks", i32), ("tile", i32), ("pad_", i32)]
+    _fields_ = [("descs", vp), ("tile_map", vp), ("n_descs", i32), ("n_blocks", i32), ("tile", i32), ("cursor_stride", i32),
+                ("cursors", vp)]
 
 
 class CopyRec(C.Structure):
@@ -120,7 +121,7 @@ class SpkBwd(C.Structure):
 class Tuning(C.Structure):
     """aew_tuning_t: kernel-shape choices as a record (the aew_set_* switches edit the process-wide one; Plan.run(...,
     tuning=...) / aew_run_plan_tuned apply a caller's own to one call)."""
-    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("reserved_", i32 * 10)]
+    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("reserved_", i32 * 8)]
 
 
 class BaseGather(C.Structure):
@@ -286,7 +287,7 @@ def load():
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 17:
+    if lib.aew_abi_version() != 18:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -330,7 +331,7 @@ def tn_slabs(tn: GemmTN) -> int:
 EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_timing_read", "aew_strerror", "aew_selftest", "aew_tn_slabs", "aew_set_tn_safe",
            "aew_graph_capture", "aew_graph_launch", "aew_graph_destroy", "aew_tn_fold", "aew_set_tn_fold_rows",
-           "aew_set_lanes", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
+           "aew_set_lanes", "aew_set_tn_cursor", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nt_small_waves", "aew_set_nf_deep", "aew_set_nf_loaders", "aew_set_nt_rows192",
            "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_set_fn_ring3", "aew_set_nt_small_n64", "aew_tn_group_check", "aew_set_nt_mem128", "aew_set_nt_deep", "aew_tuning_default", "aew_tuning_get",
            "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned")

@@ -22,7 +22,7 @@ __device__ __attribute__((aligned(128))) unsigned int aew_zero_region[2 * AEW_ZE
 
 // ---- tuning context (aew_tuning_t, aewavenet.h): the process-wide record the aew_set_* switches edit, and the record of
 // the call in progress when a caller passed its own (aew_run_plan_tuned): launchers read AEW_T().field
-static aew_tuning_t g_tune = {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static aew_tuning_t g_tune = {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
 static thread_local const aew_tuning_t* t_tune = nullptr;
 static inline const aew_tuning_t& AEW_T() { return t_tune ? *t_tune : g_tune; }
 
@@ -154,6 +154,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // vmcnt waits + barriers.  lds_off = byte offset in LDS (wave-uniform).
 __device__ __forceinline__ void glds16_raw(const void* gsrc, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(gsrc), "s"(lds_off) : "memory", "m0");
+}
+
+// one dword per lane (all lanes may pass the same address): LDS[lds_off + 4 * lane]
+__device__ __forceinline__ void glds4_raw(const void* gsrc, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1"
                  :: "v"(gsrc), "s"(lds_off) : "memory", "m0");
 }
 

@@ -1593,7 +1593,8 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
 }
 
 #define TN_STAGES 3
-#define TN_LDS_BYTES (TN_STAGES * TN_STAGE_BYTES)    // 48 KiB: two (VGPR-limited) blocks per CU
+#define TN_LDS_RING_BYTES (TN_STAGES * TN_STAGE_BYTES)
+#define TN_LDS_BYTES (TN_LDS_RING_BYTES + 256)       // 48 KiB ring (three blocks per CU) + the row cursor's mailbox
 #define TN_THREADS 256
 
 // 4 waves as 2 (k) x 2 (n): each wave owns 64 (k cols of the A segment) x 64 (n cols of G) of the
@@ -1603,9 +1604,28 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int r0, int c
 // tn_bf16_tile: one output tile (kt, nt) contracted over rows [r_lo, r_hi) of the batch elements [b_lo, b_hi), in
 // that order, result to `out` ([N_pad][K_total] fp32).  SNAP: after each batch element the running sums of column
 // g.snap_k go to g.snap_out (see aewavenet.h; the caller passes SNAP only when the block contracts over everything).
-template <int SAFE, bool SNAP>
+// Row cursor of a grouped launch (aew_gemm_tn_group_t.cursors).  The tiles of ONE matrix share their operands - the k tiles
+// of an n column re-read the same 128 columns of G, the n tiles of a k column the same 128 columns of A - and sit on one
+// XCD, whose L2 holds ~300 rows of the matrices marching through it: a tile that falls further behind its siblings than
+// that re-fetches everything from the fabric (PMC, round 3: 7.8 GB against 3.3-4.7 GB least).  The cursor bounds the
+// drift: the contraction is cut into epochs of `e` stages (32 rows each); tile i keeps prog[i] = the epoch it is about to
+// issue (a plain store per boundary: a shared counter was tried first - 28 tiles adding to one word at the same moment
+// serialise in the L2's atomic unit, 1.8 us per boundary), and starts issuing epoch x only when every tile has reached
+// epoch x - d + 1.  The row is polled ONE step ahead by an LDS-DMA load into a mailbox (free: measured), read back at the
+// boundary and min-reduced across the wave.  L2-scope loads (the tiles of a matrix are placed on one XCD; if they are not,
+// or not all resident, the wait times out once and the tile runs free from there on - it keeps publishing).  Wave 0 does
+// the protocol in front of the per-stage barrier, the other waves meet it there.  At most 64 tiles per matrix.
+struct TnCursor { unsigned* prog; int e, d, n, me; };
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+template <int SAFE, bool SNAP, bool CUR = false>      // CUR: the row-cursor protocol is compiled in (its own kernel: the default path carries none of it)
 __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem, int kt, int nt, int b_lo, int b_hi,
-                                             int r_lo, int r_hi, float* out) {
+                                             int r_lo, int r_hi, float* out, const TnCursor C = {nullptr, 0, 0, 0, 0}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 1, wn = wave >> 1;
     const int n0 = nt * TN_BT;
@@ -1645,9 +1665,53 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (s16x8_t){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+    bool cur_wait = CUR && C.prog != nullptr;          // false once a wait has timed out
+    int cur_next = (CUR && C.prog && C.e >= 2) ? C.e : 0x7fffffff;  // first stage of the next epoch to be issued (stages 0, 1 are out)
+    // The poll of a boundary is an LDS-DMA load of the progress row into a mailbox behind the ring (no VGPR is written
+    // asynchronously), issued ONE step ahead so that it is fresh, and counted: wave 0's queue then holds one (the poll) or
+    // two (+ the progress store) more operations than the 4 loads per stage the other waves leave in flight.
+    const uint32_t cur_box = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem) + TN_LDS_RING_BYTES;
+    const unsigned* cur_mine = C.prog ? C.prog + (lane < C.n ? lane : 0) : nullptr;     // the word this lane polls
+    bool cur_polled = false;
+    int cur_e1 = 0;                                    // wave 0's extra operations issued during the previous step
     for (int t = 0; t < total; ++t) {
-        if (t + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 loads per stage per wave
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool w0 = CUR && C.prog != nullptr && wave == 0;
+        const bool boundary = w0 && t + 2 == cur_next && t + 2 < total;       // this step issues the first stage of an epoch
+        int e0 = 0;
+        if (w0 && cur_wait && t + 3 == cur_next && t + 3 < total && cur_next / C.e >= C.d) {   // the next step is a boundary
+            glds4_raw(cur_mine, cur_box);
+            cur_polled = true;
+            e0 = 1;
+        }
+        // 4 loads per stage per wave stay in flight (+ wave 0's extras; a boundary step lets its poll land)
+        const int allowed = CUR ? 4 + e0 + (boundary ? 0 : cur_e1) : 4;
+        if (t + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        cur_e1 = e0;
+        if (boundary) {
+            const int ep = cur_next / C.e;
+            if (lane == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(C.prog + C.me), "v"((unsigned)ep) : "memory");
+            ++cur_e1;
+            if (cur_wait && ep >= C.d) {
+                const unsigned need = (unsigned)(ep - C.d + 1);
+                // (ds_read by hand: through a generic pointer the compiler emits a FLAT load and waits vmcnt(0) for it -
+                // the whole operand ring drained at every boundary, 2 us each)
+                unsigned have = 0;
+                if (cur_polled) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(have) : "v"(cur_box + 4 * lane) : "memory");
+                have = wave_min_u32(have);
+                if (have < need) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                    while (wave_min_u32(__hip_atomic_load(cur_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (__builtin_amdgcn_s_memtime() - t0 > 3000ull) { cur_wait = false; break; }   // 30 us of the 100 MHz clock
+                    }
+                }
+            }
+            cur_polled = false;
+        }
+        if (CUR && t + 2 == cur_next) cur_next += C.e;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 2 < total) issue_next();
@@ -1723,9 +1787,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
 // Grouped form (aew_gemm_tn_group_t): block p takes tile tile_map[p] of descriptor table `descs` (device memory,
 // read with scalar loads: the index is wave-uniform and the table is never written while a plan runs) and contracts
 // it over every row of every batch element - one result, no slabs.
-__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp(const aew_gemm_tn_t* __restrict__ descs,
-                                                                    const int32_t* __restrict__ tile_map) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool CUR>
+__device__ __forceinline__ void tn_grp_block(const aew_gemm_tn_t* __restrict__ descs, const int32_t* __restrict__ tile_map,
+                                             char* smem, unsigned* cursors, int cur_stride, int cur_e, int cur_d) {
     const int rec = __builtin_amdgcn_readfirstlane(tile_map[blockIdx.x]);
     if (rec < 0) return;
     const aew_gemm_tn_t& g = descs[rec >> 22];
@@ -1737,7 +1801,25 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp(const aew_ge
                                g.out + (int64_t)chunk * g.out_batch_stride);
         return;
     }
-    tn_bf16_tile<0, true>(g, smem, tile % nkt, tile / nkt, 0, g.batch, 0, g.Mc, g.out);
+    const int n_tiles = nkt * (g.N_pad / TN_BT);
+    TnCursor C = {nullptr, 0, 0, 0, 0};
+    if (CUR && cursors && n_tiles > 1 && n_tiles <= 64 && cur_stride >= 64)
+        C = TnCursor{cursors + (int64_t)(rec >> 22) * cur_stride, cur_e, cur_d, n_tiles, tile};
+    tn_bf16_tile<0, true, CUR>(g, smem, tile % nkt, tile / nkt, 0, g.batch, 0, g.Mc, g.out, C);
+}
+
+__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp(const aew_gemm_tn_t* __restrict__ descs,
+                                                                    const int32_t* __restrict__ tile_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_grp_block<false>(descs, tile_map, smem, nullptr, 0, 0, 0);
+}
+
+// the same launch with the row cursor (aew_gemm_tn_group_t.cursors + aew_set_tn_cursor)
+__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp_cur(const aew_gemm_tn_t* __restrict__ descs,
+                                                                        const int32_t* __restrict__ tile_map,
+                                                                        unsigned* cursors, int cur_stride, int cur_e, int cur_d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_grp_block<true>(descs, tile_map, smem, cursors, cur_stride, cur_e, cur_d);
 }
 
 // =============================================================================================
@@ -2120,6 +2202,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_grp, TN_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16_grp_cur, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_big_grp, TNB_LDS_BYTES)
 #undef AEW_SET_LDS
     done.fetch_or(dev_bit, std::memory_order_release);
@@ -2414,8 +2497,17 @@ static int launch_gemm_tn_group(const aew_gemm_tn_group_t& p, hipStream_t st) {
     if (rc) return rc;
     if (p.tile == 256)
         hipLaunchKernelGGL(k_gemm_tn_bf16_big_grp, dim3(p.n_blocks), dim3(TNB_THREADS), TNB_LDS_BYTES, st, p.descs, p.tile_map);
-    else if (p.tile == 128)
-        hipLaunchKernelGGL(k_gemm_tn_bf16_grp, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
+    else if (p.tile == 128) {
+        // row cursor: the caller provides one zeroed progress word per tile (64 per descriptor); off unless the tuning
+        // record switches it on (tn_cursor_epoch stages per epoch, 0 = off) - its own kernel, the default carries none of it
+        const int e = AEW_T().tn_cursor_epoch, d = AEW_T().tn_cursor_slack;
+        const bool on = p.cursors && p.cursor_stride >= 64 && e >= 3 && d >= 1;
+        if (on)
+            hipLaunchKernelGGL(k_gemm_tn_bf16_grp_cur, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map,
+                               p.cursors, p.cursor_stride, e, d);
+        else
+            hipLaunchKernelGGL(k_gemm_tn_bf16_grp, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
+    }
     else
         return AEW_E_ARG;
     return (int)hipGetLastError();

@@ -215,6 +215,8 @@ class DecoderPlan:
                               # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
                               # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
                               # independent blocks per CU reach 43 GB/s together
+    wgrad_cursor = False      # True: the grouped weight-gradient launches of the stack get row-cursor counters
+                              # (aew_gemm_tn_group_t.cursors; used when the tuning record switches the cursor on)
     split_chains_bwd = False  # the backward's dz / dx chain as two half-batch chains on lanes 4 / 5 (see split_chains)
     tail_lane = 0             # 4: the LAST grouped weight-gradient launch, the speaker / gated-bias gradients that read its column
                               # sums and the decoder's gradient unpack form one side branch on this lane (lane mode 2 honours
@@ -687,6 +689,7 @@ class DecoderPlan:
             nonlocal grp
             if grp is None:
                 grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
+                grp.cursor = bool(self.wgrad_cursor)
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
             t.out, t.out_batch_stride = ptr, stride
             grp.add(t, "wgrad." + name)
@@ -877,6 +880,7 @@ class DecoderPlan:
             for name, t in tail_descs:
                 if grp is None:
                     grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
+                    grp.cursor = bool(self.wgrad_cursor)
                 grp.add(t, "wgrad." + name)
             with plan.side(tail or self._next_lane("tng")):
                 grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)" if not multi else

@@ -265,6 +265,7 @@ class TnGroupBuilder:
         self.ws, self.name, self.tile = ws, name, tile
         self.descs: List[L.GemmTN] = []
         self.labels: List[str] = []
+        self.cursor = False               # True: emit() provides the row-cursor counters (and the op that zeroes them)
 
     def _grid(self, t: L.GemmTN) -> Tuple[int, int]:
         """(k tiles, n tiles) of a descriptor's output in this builder's tile size."""
@@ -324,6 +325,13 @@ class TnGroupBuilder:
         gp = L.GemmTNGroup()
         gp.descs, gp.tile_map, gp.n_descs, gp.n_blocks = dt.data_ptr(), mt.data_ptr(), len(self.descs), len(tm)
         gp.tile = self.tile
+        if self.tile == 128 and self.cursor:
+            # row cursor (aew_gemm_tn_group_t.cursors): one progress word per tile of a descriptor, zeroed by an op right in
+            # front of the launch; whether the kernel uses it is the tuning record's decision (aew_set_tn_cursor)
+            gp.cursor_stride = 64
+            cur = self.ws.alloc(f"{self.name}.cursors", len(self.descs) * gp.cursor_stride, torch.int32, zero=True)
+            gp.cursors = cur.data_ptr()
+            plan.zero(self.ws, f"{self.name}.cursors")
         # host copy of the descriptors by op label (tools/op_roofline.py prices the group from them; the launcher only
         # sees the device table)
         if not hasattr(plan, "tn_groups"):

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 17
+#define AEW_ABI_VERSION 18
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -192,7 +192,15 @@ typedef struct {
                                     256: 256 x 256 tiles (half the operand bytes staged per FLOP), 8 waves, one block
                                          per CU; tile = nt * ((K_total / 128 + 1) / 2) + kt in 256-column units, halves
                                          beyond N_pad / K_total are skipped                                  */
-    int32_t pad_;
+    int32_t cursor_stride;       /* words per descriptor in `cursors` (>= 64)                                          */
+    /* Optional row cursor (ABI 18; tile = 128 only; on when the tuning record says so, aew_set_tn_cursor): device
+     * [n_descs][cursor_stride] uint32, ZERO before every launch; word i of a descriptor's row = the epoch tile i is
+     * about to issue.  The output tiles of one descriptor share their operand columns; the cursor keeps them within
+     * `slack` epochs (of `epoch` 32-row stages) of each other as they walk down the rows, so that what one tile
+     * fetched is still in its XCD's L2 when its siblings read it.  Performance only: a tile whose wait times out (a
+     * sibling not resident, or on another XCD) runs free from there on; descriptors with > 64 tiles are not paced.
+     * NULL = off.                                                                                                    */
+    uint32_t* cursors;
 } aew_gemm_tn_group_t;
 
 /* ---------------------------------------------------------------------------------------
@@ -547,7 +555,9 @@ typedef struct {
     int32_t tn_small_tiles;
     int32_t tn_small_target;
     int32_t lanes;
-    int32_t reserved_[10];
+    int32_t tn_cursor_epoch;     /* ABI 18: aew_set_tn_cursor */
+    int32_t tn_cursor_slack;
+    int32_t reserved_[8];
 } aew_tuning_t;
 int aew_tuning_default(aew_tuning_t* out);
 int aew_tuning_get(aew_tuning_t* out);
@@ -612,6 +622,9 @@ int aew_set_nt_window(int max_dist);
 /* 0 (default): ignore aew_op_t.lane - every op on the caller's stream, in plan order.  1: side-lane ops on private
  * streams (branches of a captured graph).  Same results either way (the atomically accumulated bias sums up to order). */
 int aew_set_lanes(int on);
+/* Row cursor of the grouped weight-gradient launch (aew_gemm_tn_group_t.cursors): epoch = 32-row stages per epoch (0 = off,
+ * the default; else 2..64), slack = epochs a tile may run ahead of the slowest tile of its matrix (1..8). */
+int aew_set_tn_cursor(int epoch, int slack);
 
 /* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */
 int aew_tn_slabs(const aew_gemm_tn_t* g);

@@ -486,6 +486,36 @@ def test_gemm_tn_group(tile):
     g1 = ws_c.get("G1")[:B * 700 * 256].view(B, 700, 256).float()
     run_sum = torch.cumsum(g1[:, :690].sum(1), 0)
     assert (ws_g.get("snap")[:B * 256].view(B, 256).cpu() - run_sum).abs().max().item() <= 2e-3 * run_sum.abs().max().item()
+    if tile == 128:
+        # the same launch paced by the row cursor (aew_gemm_tn_group_t.cursors, aew_set_tn_cursor): the tiles of a matrix
+        # wait for each other every few stages, which changes when a row is read and nothing about what is summed
+        lib = L.load()
+        ws_2 = _mirror(ws_c, DEV)
+        for n in ("o1", "o2", "o3", "o4", "snap", "cs1"):
+            ws_2.get(n).zero_()
+        gb = TnGroupBuilder(ws_2, "tngc", tile)
+        gb.cursor = True
+        for i, t in enumerate(build(ws_2)):
+            if i == 3:
+                gb.set_split(t, 220)
+            gb.add(t, f"d{i}")
+        p = Plan("g")
+        gb.emit(p, "group")
+        assert p.labels[0].startswith("zero:") and len(p.ops) == 2
+        try:
+            for epoch, slack in ((3, 1), (4, 2)):
+                assert lib.aew_set_tn_cursor(epoch, slack) == 0
+                p.run(stream())
+                torch.cuda.synchronize()
+                prog = ws_2.get("tngc.cursors").view(-1, 64).cpu()
+                stages = 3 * ((690 + 31) // 32)
+                assert int(prog[0, :14].min()) == int(prog[0, :14].max()) == (stages - 1) // epoch, prog[0, :16]
+                assert int(prog[2].max()) == 0 or 3 * 2 > epoch            # the 33-row matrix has 6 stages
+                for n in ("o1", "o2", "o3", "o4", "snap", "cs1", "cs2"):
+                    assert torch.equal(ws_2.get(n), ws_g.get(n)), (n, epoch, slack)
+            assert lib.aew_set_tn_cursor(1, 1) != 0 and lib.aew_set_tn_cursor(4, 9) != 0
+        finally:
+            lib.aew_set_tn_cursor(0, 0)
 
 
 @pytest.mark.parametrize("Np,ks", [(256, (128, 128, 256)), (384, (128, 256)), (128 * 5, (384, 384, 128)), (512, (384, 384, 128))])

@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0}
+DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0, "tn_cursor": 0}
 
 
 def main():
@@ -89,6 +89,9 @@ def main():
         for k, v in vals.items():
             if k == "graphs":                      # 0: plans run eagerly (real streams + events) instead of as hipGraphs
                 eng.use_graphs = bool(v)
+                continue
+            if k == "tn_cursor":                   # epoch * 10 + slack (0 = off)
+                lib.aew_set_tn_cursor(v // 10, v % 10)
                 continue
             getattr(lib, "aew_set_" + k)(v)
         for p in (eng.fwd_a, eng.fwd_b, eng.bwd, getattr(eng, "bwd_a", None), getattr(eng, "bwd_b", None),
