@@ -221,6 +221,35 @@ def test_grouped_wgrad_plan(golden_dir, monkeypatch, group, split, tile):
     check_grads(eng, z, "grad", "wide")
 
 
+def test_schedule_options_leave_the_plan_results_alone(golden_dir, monkeypatch):
+    """DecoderPlan.split_chains / split_chains_bwd (half-batch chains on lanes 4 / 5), tail_lane (the last grouped launch as a
+    branch; ignored when the chain is split) and wgrad_cursor (progress words + the op that zeroes them in front of the
+    grouped launch) re-schedule or pace; serially interpreted, the plans give the golden gradients."""
+    monkeypatch.setitem(PL.TORCH_DT, L.BF16, torch.float32)
+    monkeypatch.setitem(PL.ESIZE, L.BF16, 4)
+    from ae_wavenet_amd import engine as E
+    z = load(golden_dir, "mi_tiny_jitter.npz")
+    for cfg in (dict(split_chains=True, split_chains_bwd=True, tail_lane=4), dict(tail_lane=4, wgrad_cursor=True)):
+        for k in ("split_chains", "split_chains_bwd", "tail_lane", "wgrad_cursor"):
+            monkeypatch.setattr(E.DecoderPlan, k, cfg.get(k, 0))
+        hps, eng = make_engine(z, "mfcc_inverter", 7)
+        labs, ops = eng.bwd.labels, eng.bwd.ops
+        i_grp = next(i for i, lab in enumerate(labs) if lab.startswith("wgrad.group0"))
+        if cfg.get("split_chains_bwd"):
+            assert eng.B % 2 == 0 and "dz.0.c0" in labs and "dx.0.c1" in labs and "dz.0" not in labs
+            assert {ops[labs.index(f"dz.1.c{c}")].lane for c in (0, 1)} == {4, 5}
+            assert ops[i_grp].lane not in (4, 5) and ops[i_grp].join == 1         # meets both chains; no tail branch behind a chain
+            assert ops[labs.index("dcond")].join == 1 and eng.dec.tail_lane_used == 0
+            assert any(lab.endswith(".c1") for lab in eng.fwd_b.labels)
+        else:
+            assert ops[i_grp].lane == 4 and labs[i_grp + 1] == "spk_bwd" and ops[i_grp + 1].lane == 4
+            assert labs[i_grp - 1].startswith("zero:") and labs[i_grp - 1].endswith(".cursors") and ops[i_grp - 1].lane == 4
+            assert ops[i_grp].u.tng.cursor_stride == 64 and ops[i_grp].u.tng.cursors
+            assert ops[labs.index("unpack grads (decoder)")].lane == 4
+        run(eng, z)
+        check_grads(eng, z, "grad", "wide")
+
+
 def test_autoencoder_vae_plan(golden_dir, mode):
     z = load(golden_dir, "ae_tiny_vae_random.npz")
     hps, eng = make_engine(z, "autoencoder", None)
