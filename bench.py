@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="vqvae-ema", help="config.make_hps architecture; anything but the default (vae, deep: BASELINE configs[3], [4] per GPU at --batch 4 --n-win 65536) is a side measurement, not the bench line")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +91,7 @@ def spawn(args):
 def make_model(args, device):
     import torch
     from ae_wavenet_amd import autoencoder_model as ae, config, optim
-    hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=args.jitter_prob)
+    hps = config.make_hps(args.arch, n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=args.jitter_prob)
     torch.manual_seed(2507)                                       # hparams.py:92 random_seed
     model = ae.AutoEncoder(hps, n_mel=39).to(device)              # Xavier weights, zero biases, codebook gain 10
     opt = optim.FusedAdam(model, lr=args.lr)
