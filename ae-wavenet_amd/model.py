@@ -38,6 +38,7 @@ class TrainEngine:
     """
     DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
     LANE_PACK_DEC = 1         # side lane of the decoder's forward-layout weight pack (joined by the end of fwd_a) ...
+    merge_packs = False       # True: all weight-layout packs of a step as one copy-table launch at the head of fwd_a
     graph_lanes = 2           # lane mode of graph captures when the process-wide mode is 0 (aew_set_lanes): 2 = lanes 4 / 5 are
                               # branches, everything else in plan order.  Eager runs stay serial (one cross-stream edge costs
                               # more there than the branch returns: 7.27 vs 6.90 ms per step).  0: never
@@ -244,10 +245,11 @@ class TrainEngine:
                 an = self._ae_norm_op(False)
                 fa.add(L.OP_AE_NORM, an, "ae.norm", TAG_VQ)
         # ===== forward, part B: decoder + loss
-        with fb.side(self.LANE_PACK_LATE):                     # only the backward reads these: hidden under the decoder
-            self.pack_late.emit(fb, "pack weights (backward layouts)")
-        for op in fb.ops[-1:] if self.pack_late.recs else []:
-            op.tag = TAG_PACK
+        if not self.merge_packs:
+            with fb.side(self.LANE_PACK_LATE):                 # only the backward reads these: hidden under the decoder
+                self.pack_late.emit(fb, "pack weights (backward layouts)")
+            for op in fb.ops[-1:] if self.pack_late.recs else []:
+                op.tag = TAG_PACK
         # Per-step diagnostics (what the reference's loss modules report, vqema_bn.py:251-264, chassis.py:266-270) are
         # side-lane ops placed where their inputs become final, not after the plan's last op (a side op starts after
         # every main-lane op that precedes it in the plan: appended at the end they were ~0.09 ms of exposed tail):
@@ -455,13 +457,22 @@ class TrainEngine:
             self.cb.add(L.OP_VQ_EMA, em, "vq.codebook", TAG_VQ)
         # pack goes first in fwd_a (its table is complete only now)
         pk_plan = Plan("pack")
-        with pk_plan.side(self.LANE_PACK_DEC):                 # joined by the end of fwd_a
-            self.pack_dec.emit(pk_plan, "pack weights (decoder)")
-        if self.pack_first is not None and self.pack_first.recs:
+        if self.merge_packs:
+            # every weight layout of the step in ONE table launch at the head of fwd_a (serial plans: three launches fewer)
+            allp = CopyTableBuilder(ws, "tbl.pack_all")
+            for tb in (self.pack_first, self.pack_tbl, self.pack_dec, self.pack_late):
+                if tb is not None:
+                    allp.recs.extend(tb.recs)
+            allp.emit(pk_plan, "pack weights (all layouts)")
+        elif self.pack_first is not None and self.pack_first.recs:
+            with pk_plan.side(self.LANE_PACK_DEC):             # joined by the end of fwd_a
+                self.pack_dec.emit(pk_plan, "pack weights (decoder)")
             self.pack_first.emit(pk_plan, "pack weights (encoder layer 0)")
             with pk_plan.side(self.PACK_LANE):
                 self.pack_tbl.emit(pk_plan, "pack weights")
         else:
+            with pk_plan.side(self.LANE_PACK_DEC):             # joined by the end of fwd_a
+                self.pack_dec.emit(pk_plan, "pack weights (decoder)")
             self.pack_tbl.emit(pk_plan, "pack weights")
         fa.ops[pack_slot:pack_slot] = pk_plan.ops
         fa.labels[pack_slot:pack_slot] = pk_plan.labels
