@@ -13,8 +13,10 @@ Two schedules for the gradient exchange (same result up to fp32 summation order)
   train_step_sharded  reduce-scatter + SHARDED Adam + all-gather (what xm.optimizer_step amounts to on a ring):
                       every rank receives and updates only its 1/world shard of each region (a ring reduce-scatter moves
                       half the bytes of an all-reduce before the optimizer can start, and the Adam pass shrinks by
-                      world), then the updated shards are all-gathered; the decoder region's exchange runs under the
-                      encoder backward and the head's reduce-scatter, its all-gather under the head's Adam.  Optional
+                      world), then the updated shards are all-gathered; the decoder region's reduce-scatter runs under the
+                      encoder backward, and its all-gather - issued behind the head's - under the NEXT step's encoder
+                      forward: forward() waits for the head's parameters before the first forward plan and for the
+                      decoder's only between the two (TrainEngine.pack_dec_late).  Optional
                       bf16 gradient transport (half the xGMI bytes of the reduce-scatter; fp32 master parameters and
                       moments unchanged).
 """
@@ -197,9 +199,11 @@ class DataParallel:
             work.append(dist.all_reduce(flat[rem:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return work, fin
 
-    def _update_region(self, eng, a: int, b: int, lr, grad_scale, count, adam_kw):
+    def _update_region(self, eng, a: int, b: int, lr, grad_scale, count, adam_kw, defer=None):
         """Adam on this rank's shard of region [a, b) (+ the replicated remainder), then the all-gather of the updated
-        parameter shards (async; returned)."""
+        parameter shards (async; returned).  defer: a list - the all-gather is appended to it as a callable instead of
+        being issued (collectives complete in issue order: optimizer_step issues the head's first when the decoder's
+        may stay in flight under the next encoder forward)."""
         s, rem = self._split(a, b)
         work = []
         if s > 0:
@@ -209,16 +213,35 @@ class DataParallel:
             main = eng.ps.params[a:a + self.world * s]
             src = self._buf("ag.in", a, s, main.dtype, main.device)     # (in place all-gather is not valid on every backend)
             src.copy_(eng.ps.params[lo:lo + s])
-            work.append(dist.all_gather_into_tensor(main, src, group=self.group, async_op=True))
+
+            def gather():
+                return dist.all_gather_into_tensor(main, src, group=self.group, async_op=True)
+            if defer is None:
+                work.append(gather())
+            else:
+                defer.append(gather)
         if rem < b:
             eng.adam_step(lr, grad_scale, lo=rem, hi=b, count=count, **adam_kw)
         return work
 
-    def finish(self):
-        """Wait for the parameter all-gathers of the previous sharded step (called before the next forward)."""
-        for w in getattr(self, "_pending", []):
-            self._wait(w, "params.all_gather")
-        self._pending = []
+    def finish(self, region=None):
+        """Wait for the parameter all-gathers of the previous sharded step.  region = None: all of them (before anything
+        reads the parameters); "head": only the encoder / bottleneck region - what the first forward plan reads; the
+        decoder's shards may stay in flight under it until forward(before_decoder=self.finish) (TrainEngine.pack_dec_late)."""
+        keep = []
+        for tag, w in getattr(self, "_pending", []):
+            if region is None or tag == region:
+                self._wait(w, "params.all_gather" + ("" if tag == "head" else ".decoder"))
+            else:
+                keep.append((tag, w))
+        self._pending = keep
+
+    def forward(self, eng):
+        """The forward of a sharded step: the encoder part starts as soon as ITS parameters are complete, the decoder's
+        all-gather is waited for between the two forward plans."""
+        late = bool(getattr(eng, "pack_dec_late", False)) and not getattr(eng, "merge_packs", False)
+        self.finish("head" if late else None)
+        return eng.forward(self.allreduce_ema_async, before_decoder=self.finish if late else None)
 
     def backward_exchange(self, eng, bf16_grads: bool = False):
         """Backward with the sharded gradient exchange issued as the regions become final: decoder tail (reduce-scatter
@@ -249,24 +272,31 @@ class DataParallel:
         n, lo = eng.ps.numel, eng.dec_grad_offset
         st, self._st = self._st, None
         pend, counted, dec_end = [], True, n
+        # late: the next forward waits for the head's parameters first and for the decoder's only between its two plans
+        # (forward()); collectives complete in issue order, so the head's all-gather goes out first and the decoder's
+        # right behind it.  Otherwise the decoder's all-gather is issued at once and runs under the head's Adam.
+        late = lo > 0 and bool(getattr(eng, "pack_dec_late", False)) and not getattr(eng, "merge_packs", False)
+        dec_gathers = [] if late else None
         if "dec_hi" in st:                               # the upper layers' region: reduced under the rest of the chain
             for w in st["dec_hi"][0]:
                 self._wait(w, "grads.decoder_hi")
             for f in st["dec_hi"][1]:
                 f()
-            pend += self._update_region(eng, st["hi"], n, lr, grad_scale, True, adam_kw)
+            pend += [("dec", w) for w in self._update_region(eng, st["hi"], n, lr, grad_scale, True, adam_kw, dec_gathers)]
             counted, dec_end = False, st["hi"]
         for w in st["dec"][0]:
             self._wait(w, "grads.decoder")
         for f in st["dec"][1]:
             f()
-        pend += self._update_region(eng, lo, dec_end, lr, grad_scale, counted, adam_kw)   # decoder shards; all-gather in flight
+        pend += [("dec", w) for w in self._update_region(eng, lo, dec_end, lr, grad_scale, counted, adam_kw, dec_gathers)]
         for w in st["head"][0]:
             self._wait(w, "grads.encoder")
         for f in st["head"][1]:
             f()
         if lo > 0:
-            pend += self._update_region(eng, 0, lo, lr, grad_scale, False, adam_kw)
+            pend += [("head", w) for w in self._update_region(eng, 0, lo, lr, grad_scale, False, adam_kw)]
+        for g in dec_gathers or []:
+            pend.append(("dec", g()))
         self._pending = pend
 
     def train_step_sharded(self, eng, lr: float, grad_scale: float = 1.0, bf16_grads: bool = False, **adam_kw):
@@ -279,8 +309,7 @@ class DataParallel:
             eng.backward()
             eng.adam_step(lr, grad_scale, **adam_kw)
             return
-        self.finish()
-        eng.forward(self.allreduce_ema_async)
+        self.forward(eng)
         self.backward_exchange(eng, bf16_grads)
         self.optimizer_step(eng, lr, grad_scale, **adam_kw)
 

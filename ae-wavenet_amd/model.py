@@ -38,6 +38,7 @@ class TrainEngine:
     """
     DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
     LANE_PACK_DEC = 1         # side lane of the decoder's forward-layout weight pack (joined by the end of fwd_a) ...
+    pack_dec_late = True      # the decoder's weight pack at the head of fwd_b instead of fwd_a (see build: data-parallel overlap)
     merge_packs = False       # True: all weight-layout packs of a step as one copy-table launch at the head of fwd_a
     graph_lanes = 2           # lane mode of graph captures when the process-wide mode is 0 (aew_set_lanes): 2 = lanes 4 / 5 are
                               # branches, everything else in plan order.  Eager runs stay serial (one cross-stream edge costs
@@ -411,6 +412,21 @@ class TrainEngine:
         # Deferred EMA (data parallel): the EMA accumulators are not read again before the codebook
         # refresh, so the cross-rank sum of z_sum | n_sum can run asynchronously under the whole
         # decoder forward + backward; fwd_b_noema / ema_plan are fwd_b without / only its leading vq.ema op
+        # The decoder's weight layouts are packed at the head of fwd_b (behind vq.ema), not of fwd_a: nothing in fwd_a
+        # reads a decoder parameter, so a data-parallel caller lets the all-gather of the updated decoder shards run
+        # under the encoder forward and waits for it only between the two plans (forward(before_decoder=...)).  Serial
+        # plans: the same launches in the same total time.
+        if self.pack_dec_late and not self.merge_packs and self.pack_dec.recs:
+            pkd = Plan("pack_dec")
+            with pkd.side(self.LANE_PACK_DEC):
+                self.pack_dec.emit(pkd, "pack weights (decoder)")
+            at = 1 if (fb.labels and fb.labels[0] == "vq.ema") else 0
+            for op in pkd.ops:
+                op.tag = TAG_PACK
+            fb.ops[at:at] = pkd.ops
+            fb.labels[at:at] = pkd.labels
+            fb.keep += pkd.keep
+            self._pack_dec_emitted = True
         self.fwd_b_noema, self.ema_plan = None, None
         if fb.labels and fb.labels[0] == "vq.ema":
             self.fwd_b_noema, self.ema_plan = Plan("fwd_b_noema"), Plan("ema")
@@ -465,14 +481,16 @@ class TrainEngine:
                     allp.recs.extend(tb.recs)
             allp.emit(pk_plan, "pack weights (all layouts)")
         elif self.pack_first is not None and self.pack_first.recs:
-            with pk_plan.side(self.LANE_PACK_DEC):             # joined by the end of fwd_a
-                self.pack_dec.emit(pk_plan, "pack weights (decoder)")
+            if not getattr(self, "_pack_dec_emitted", False):
+                with pk_plan.side(self.LANE_PACK_DEC):         # joined by the end of fwd_a
+                    self.pack_dec.emit(pk_plan, "pack weights (decoder)")
             self.pack_first.emit(pk_plan, "pack weights (encoder layer 0)")
             with pk_plan.side(self.PACK_LANE):
                 self.pack_tbl.emit(pk_plan, "pack weights")
         else:
-            with pk_plan.side(self.LANE_PACK_DEC):             # joined by the end of fwd_a
-                self.pack_dec.emit(pk_plan, "pack weights (decoder)")
+            if not getattr(self, "_pack_dec_emitted", False):
+                with pk_plan.side(self.LANE_PACK_DEC):         # joined by the end of fwd_a
+                    self.pack_dec.emit(pk_plan, "pack weights (decoder)")
             self.pack_tbl.emit(pk_plan, "pack weights")
         fa.ops[pack_slot:pack_slot] = pk_plan.ops
         fa.labels[pack_slot:pack_slot] = pk_plan.labels
@@ -593,13 +611,17 @@ class TrainEngine:
         d = self.dec
         return d.cond.tensor(), d.bias_bl[:self.B * d.NL * 2 * d.Dp].view(self.B, d.NL, 2 * d.Dp)
 
-    def forward(self, ema_allreduce=None, timing=False):
+    def forward(self, ema_allreduce=None, timing=False, before_decoder=None):
         """timing=True forces eager launches (the per-op event timing needs them).
+        before_decoder(): called between the two forward plans - the first point at which a decoder parameter is read
+        (pack_dec_late); a data-parallel caller waits there for the all-gather of the decoder's parameter shards.
         ema_allreduce(z_sum, n_sum): cross-rank sum of the EMA statistics.  If it returns a work handle
         (async collective) the EMA accumulation is deferred to finish_ema(), called by backward() - or by the next
         forward() if no backward came in between (forward-only use: the accumulation must not be lost)."""
         self.finish_ema(timing)
         self._run(self.fwd_a, timing)
+        if before_decoder is not None:
+            before_decoder()
         if ema_allreduce is not None and self.bn_type == "vqvae-ema":
             work = ema_allreduce(self.z_sum, self.n_sum)
             if work is not None and self.ema_plan is not None:

@@ -31,7 +31,11 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, owner):
         ctx.owner = owner
-        loss = owner._engine.forward(owner._ema_allreduce)
+        dp = owner._dp
+        if dp is not None and dp.sharded and dp.world > 1:
+            loss = dp.forward(owner._engine)                 # the decoder's parameter all-gather stays in flight under the encoder
+        else:
+            loss = owner._engine.forward(owner._ema_allreduce)
         return loss.clone()
 
     @staticmethod
@@ -374,8 +378,8 @@ class HipModelBase(nn.Module):
         (B, w-1), loss scalar with a grad_fn whose backward fills every parameter's .grad."""
         B = wav.shape[0]
         eng = self._ensure_engine(B)
-        if self._dp is not None:
-            self._dp.finish()                                # parameter all-gathers of the previous sharded step
+        if self._dp is not None and not (self._dp.sharded and self._dp.world > 1):
+            self._dp.finish()                                # (sharded: _StepFn.forward waits region by region)
         eng.set_inputs(wav, mel, voice, jitter, eps=eps)
         loss = _StepFn.apply(self._anchor, self)
         w, g = eng.n_win, eng.geom

@@ -192,7 +192,17 @@ def _real_worker(rank, world, port, bn, q, wg=None):
                     d.train_step(eng, 1e-2, gs)
                 else:
                     d.train_step_sharded(eng, 1e-2, gs, bf16_grads=name.endswith("bf16"))
+                    if name == "sharded" and it == 0:
+                        # the parameter all-gathers stay in flight: the head's (what the encoder forward reads) was issued
+                        # first - collectives complete in issue order - and is the only one the next forward waits for
+                        # before its first plan; the decoder's weights are packed at the head of the second plan
+                        tags = [t for t, _ in d._pending]
+                        assert tags and tags[0] == "head" and set(tags[1:]) == {"dec"}, tags
+                        assert "pack weights (decoder)" in eng.fwd_b.labels and "pack weights (decoder)" not in eng.fwd_a.labels
+                        d.finish("head")
+                        assert [t for t, _ in d._pending] == tags[1:]
             d.finish()
+            assert d._pending == []
             if name != "allreduce":
                 d.gather_moments(eng)
             out[name] = (eng.ps.params[:n].numpy().copy(), eng.adam_m[:n].numpy().copy(),
