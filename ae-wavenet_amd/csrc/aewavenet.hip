@@ -196,7 +196,7 @@ static void tune_clamp(aew_tuning_t& t) {
 }
 extern "C" int aew_tuning_default(aew_tuning_t* out) {
     if (!out) return AEW_E_ARG;
-    static const aew_tuning_t d = {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+    static const aew_tuning_t d = AEW_TUNING_DEFAULTS;
     *out = d;
     return 0;
 }
