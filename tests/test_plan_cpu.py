@@ -398,3 +398,32 @@ def test_split_grouped_descriptor_keeps_its_bias_gradient(monkeypatch):
         scale = max(float(ref.abs().max()), 1e-20)
         assert float((got - ref).abs().max()) / scale < 2e-4, k
     assert float(grads[64]["wavenet.lc_conv.bias"].abs().max()) > 0
+
+
+def test_first_forward_plan_reads_no_decoder_parameter(golden_dir):
+    """TrainEngine.pack_dec_late: the decoder's weight layouts are packed at the head of fwd_b, and nothing in fwd_a - op
+    descriptors or the records of its pack tables - points into the decoder's region of the flat parameter buffer.  That is
+    what lets a data-parallel step keep the decoder's parameter all-gather in flight under the encoder forward
+    (dp.DataParallel.forward)."""
+    import ctypes as C
+    z = load(golden_dir, "ae_tiny_vqvae-ema_random.npz")
+    hps, eng = make_engine(z, "autoencoder", None)
+    base, lo, n = eng.ps.params.data_ptr(), eng.dec_grad_offset, eng.ps.numel
+    assert 0 < lo < n
+    d_lo, d_hi = base + 4 * lo, base + 4 * n
+
+    def ints(obj):
+        if isinstance(obj, (C.Structure, C.Union)):
+            return [v for f in obj._fields_ for v in ints(getattr(obj, f[0]))]
+        if isinstance(obj, C.Array):
+            return [v for e in obj for v in ints(e)]
+        return [obj] if isinstance(obj, int) else []
+
+    assert "pack weights (decoder)" in eng.fwd_b.labels and "pack weights (decoder)" not in eng.fwd_a.labels
+    for op, lab in zip(eng.fwd_a.ops, eng.fwd_a.labels):
+        hits = [v for v in ints(getattr(op.u, L.OP_FIELD[op.kind])) if d_lo <= v < d_hi]
+        assert not hits, (lab, [hex(v) for v in hits])
+    for tb in (eng.pack_first, eng.pack_tbl):
+        if tb is not None:
+            assert not [r for r in tb.recs if d_lo <= (r.src or 0) < d_hi]
+    assert eng.pack_dec.recs and all(d_lo <= r.src < d_hi for r in eng.pack_dec.recs)
