@@ -2498,10 +2498,12 @@ static int launch_gemm_tn_group(const aew_gemm_tn_group_t& p, hipStream_t st) {
     if (p.tile == 256)
         hipLaunchKernelGGL(k_gemm_tn_bf16_big_grp, dim3(p.n_blocks), dim3(TNB_THREADS), TNB_LDS_BYTES, st, p.descs, p.tile_map);
     else if (p.tile == 128) {
-        // row cursor: the caller provides one zeroed progress word per tile (64 per descriptor); off unless the tuning
-        // record switches it on (tn_cursor_epoch stages per epoch, 0 = off) - its own kernel, the default carries none of it
-        const int e = AEW_T().tn_cursor_epoch, d = AEW_T().tn_cursor_slack;
-        const bool on = p.cursors && p.cursor_stride >= 64 && e >= 3 && d >= 1;
+        // row cursor: the caller provides one zeroed progress word per tile (64 per descriptor) when it wants the launch
+        // paced; the tuning record picks epoch / slack (0: the defaults 4 / 2) or vetoes it (-1).  Its own kernel: the
+        // unpaced launch carries none of it
+        const int te = AEW_T().tn_cursor_epoch;
+        const int e = te > 0 ? te : 4, d = te > 0 ? AEW_T().tn_cursor_slack : 2;
+        const bool on = p.cursors && p.cursor_stride >= 64 && te >= 0 && e >= 3 && d >= 1;
         if (on)
             hipLaunchKernelGGL(k_gemm_tn_bf16_grp_cur, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map,
                                p.cursors, p.cursor_stride, e, d);

@@ -85,9 +85,9 @@ static std::vector<hipEvent_t> g_lane_ev;
 static size_t g_lane_ev_next = 0;
 
 extern "C" int aew_set_tn_cursor(int epoch, int slack) {
-    if (epoch != 0 && (epoch < 2 || epoch > 64 || slack < 1 || slack > 8)) return AEW_E_ARG;
-    g_tune.tn_cursor_epoch = epoch;
-    g_tune.tn_cursor_slack = epoch ? slack : 0;
+    if (epoch > 0 && (epoch < 3 || epoch > 64 || slack < 1 || slack > 8)) return AEW_E_ARG;
+    g_tune.tn_cursor_epoch = epoch < 0 ? -1 : epoch;
+    g_tune.tn_cursor_slack = epoch > 0 ? slack : 0;
     return 0;
 }
 extern "C" int aew_set_lanes(int on) { g_tune.lanes = on < 0 ? 0 : (on > 2 ? 2 : on); return 0; }   // 2: lanes 4, 5 only (independent chains)
@@ -189,7 +189,7 @@ static void tune_clamp(aew_tuning_t& t) {
     if (t.nt_wave_rows != 0 && t.nt_wave_rows != 1 && t.nt_wave_rows != 64 && t.nt_wave_rows != 128 && t.nt_wave_rows != 256)
         t.nt_wave_rows = 64;
     cl(t.nt_pipe, 0, 2); cl(t.nt_rows192, 0, 2); cl(t.nt_window, 0, 64); cl(t.nt_mem128, 0, 2); cl(t.nt_deep, 0, 3);
-    cl(t.lanes, 0, 2); if (t.tn_cursor_epoch != 0) { cl(t.tn_cursor_epoch, 2, 64); cl(t.tn_cursor_slack, 1, 8); } cl(t.nt_small_w8, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
+    cl(t.lanes, 0, 2); if (t.tn_cursor_epoch > 0) { cl(t.tn_cursor_epoch, 3, 64); cl(t.tn_cursor_slack, 1, 8); } else if (t.tn_cursor_epoch < 0) t.tn_cursor_epoch = -1; cl(t.nt_small_w8, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
     cl(t.nt_small_tiles, 0, 1 << 30); cl(t.nt_small_n64, 0, 1 << 30); cl(t.nt_small_deep, 0, 1 << 30); cl(t.nf_deep, 0, 1 << 30);
     cl(t.fn_ring3, 0, 1 << 30); cl(t.tn_big_target, 1, 1 << 30); cl(t.tn_fold_rows, 0, 1 << 30); cl(t.tn_target_blocks, 1, 1 << 30);
     cl(t.tn_small_tiles, 0, 1 << 30); cl(t.tn_small_target, 1, 1 << 30);

@@ -215,8 +215,12 @@ class DecoderPlan:
                               # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
                               # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
                               # independent blocks per CU reach 43 GB/s together
-    wgrad_cursor = False      # True: the grouped weight-gradient launches of the stack get row-cursor counters
-                              # (aew_gemm_tn_group_t.cursors; used when the tuning record switches the cursor on)
+    wgrad_cursor = None       # the grouped weight-gradient launches of the stack paced by the row cursor
+                              # (aew_gemm_tn_group_t.cursors): True / False / None = iff the launch has more tiles than
+                              # TnGroupBuilder.CURSOR_AUTO_TILES.  Measured: arch.vqvae-ema (768 tiles, one resident wave) 7.03 ->
+                              # 7.26 ms per step although the launch fetches 28 % less - it is not bound by what it fetches;
+                              # the deep decoder (30 x 512, 1450 tiles of 268 k rows) 66.5 -> 64.4 ms (weight-gradient class
+                              # 24.9 -> 23.0 ms) - there it is (profiles/r04_notes.md 21, 24)
     split_chains_bwd = False  # the backward's dz / dx chain as two half-batch chains on lanes 4 / 5 (see split_chains)
     tail_lane = 0             # 4: the LAST grouped weight-gradient launch, the speaker / gated-bias gradients that read its column
                               # sums and the decoder's gradient unpack form one side branch on this lane (lane mode 2 honours
@@ -689,7 +693,7 @@ class DecoderPlan:
             nonlocal grp
             if grp is None:
                 grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
-                grp.cursor = bool(self.wgrad_cursor)
+                grp.cursor = self.wgrad_cursor
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
             t.out, t.out_batch_stride = ptr, stride
             grp.add(t, "wgrad." + name)
@@ -880,7 +884,7 @@ class DecoderPlan:
             for name, t in tail_descs:
                 if grp is None:
                     grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
-                    grp.cursor = bool(self.wgrad_cursor)
+                    grp.cursor = self.wgrad_cursor
                 grp.add(t, "wgrad." + name)
             with plan.side(tail or self._next_lane("tng")):
                 grp.emit(plan, f"wgrad.group{n_groups} (last layers, skip, post)" if not multi else

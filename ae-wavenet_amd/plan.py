@@ -259,13 +259,15 @@ class TnGroupBuilder:
     split-K slabs).  Descriptors and tile map are uploaded to device memory at emit()."""
 
     N_XCD = 8
+    CURSOR_AUTO_TILES = 1024              # (the 256 CUs hold 768 of the 128-tile blocks at a time)
 
     def __init__(self, ws: Workspace, name: str, tile: int = 128):
         assert tile in (128, 256)
         self.ws, self.name, self.tile = ws, name, tile
         self.descs: List[L.GemmTN] = []
         self.labels: List[str] = []
-        self.cursor = False               # True: emit() provides the row-cursor counters (and the op that zeroes them)
+        self.cursor = False               # True: emit() provides the row cursor's progress words (and the op that zeroes them)
+                                          # = the launch is paced; None: iff the group has more tiles than CURSOR_AUTO_TILES
 
     def _grid(self, t: L.GemmTN) -> Tuple[int, int]:
         """(k tiles, n tiles) of a descriptor's output in this builder's tile size."""
@@ -325,6 +327,8 @@ class TnGroupBuilder:
         gp = L.GemmTNGroup()
         gp.descs, gp.tile_map, gp.n_descs, gp.n_blocks = dt.data_ptr(), mt.data_ptr(), len(self.descs), len(tm)
         gp.tile = self.tile
+        if self.cursor is None:
+            self.cursor = sum(1 for r in tm if r >= 0) > self.CURSOR_AUTO_TILES
         if self.tile == 128 and self.cursor:
             # row cursor (aew_gemm_tn_group_t.cursors): one progress word per tile of a descriptor, zeroed by an op right in
             # front of the launch; whether the kernel uses it is the tuning record's decision (aew_set_tn_cursor)

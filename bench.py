@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--tn-blocks", dest="tn_blocks", type=int, default=0, help="split-K block target of the TN ops")
     ap.add_argument("--tn-small", dest="tn_small", default="", help="max_tiles,target_blocks for small-output TN ops")
     ap.add_argument("--chains", type=int, default=1, help="1: gated stack as one full-batch chain; 2: two half-batch chains (graph branches)")
-    ap.add_argument("--wgrad-cursor", dest="wgrad_cursor", default="", help="epoch,slack: row cursor of the grouped weight-gradient launch (A/B aid)")
+    ap.add_argument("--wgrad-cursor", dest="wgrad_cursor", default="", help="epoch,slack: pace the grouped weight-gradient launch with the row cursor (default: only launches of > 1024 tiles, 4,2); 'off' = never")
     ap.add_argument("--chains-bwd", dest="chains_bwd", type=int, default=1, help="the same for the backward's dz / dx chain")
     ap.add_argument("--nt-rows192", dest="nt_rows192", type=int, default=-1, help="192-row NT tiles: 0 never, 1 cost model, 2 always")
     ap.add_argument("--nt-small", dest="nt_small", type=int, default=-1, help="tile-count threshold for 64-row NT tiles")
@@ -273,7 +273,9 @@ def main():
     from ae_wavenet_amd import engine as _E
     _E.DecoderPlan.split_chains = args.chains == 2
     _E.DecoderPlan.split_chains_bwd = args.chains_bwd == 2
-    if args.wgrad_cursor:
+    if args.wgrad_cursor == "off":
+        _E.DecoderPlan.wgrad_cursor = False
+    elif args.wgrad_cursor:
         ce, cd = (int(v) for v in args.wgrad_cursor.split(","))
         _E.DecoderPlan.wgrad_cursor = True
         L.check(lib.aew_set_tn_cursor(ce, cd), "aew_set_tn_cursor")

@@ -193,8 +193,8 @@ typedef struct {
                                          per CU; tile = nt * ((K_total / 128 + 1) / 2) + kt in 256-column units, halves
                                          beyond N_pad / K_total are skipped                                  */
     int32_t cursor_stride;       /* words per descriptor in `cursors` (>= 64)                                          */
-    /* Optional row cursor (ABI 18; tile = 128 only; on when the tuning record says so, aew_set_tn_cursor): device
-     * [n_descs][cursor_stride] uint32, ZERO before every launch; word i of a descriptor's row = the epoch tile i is
+    /* Optional row cursor (ABI 18; tile = 128 only; non-NULL = pace this launch): device
+     * [n_descs][cursor_stride] uint32, ZERO before every launch (epoch / slack: aew_set_tn_cursor); word i of a descriptor's row = the epoch tile i is
      * about to issue.  The output tiles of one descriptor share their operand columns; the cursor keeps them within
      * `slack` epochs (of `epoch` 32-row stages) of each other as they walk down the rows, so that what one tile
      * fetched is still in its XCD's L2 when its siblings read it.  Performance only: a tile whose wait times out (a
@@ -622,8 +622,9 @@ int aew_set_nt_window(int max_dist);
 /* 0 (default): ignore aew_op_t.lane - every op on the caller's stream, in plan order.  1: side-lane ops on private
  * streams (branches of a captured graph).  Same results either way (the atomically accumulated bias sums up to order). */
 int aew_set_lanes(int on);
-/* Row cursor of the grouped weight-gradient launch (aew_gemm_tn_group_t.cursors): epoch = 32-row stages per epoch (0 = off,
- * the default; else 2..64), slack = epochs a tile may run ahead of the slowest tile of its matrix (1..8). */
+/* Row cursor of the grouped weight-gradient launch: a launch whose descriptor carries progress words
+ * (aew_gemm_tn_group_t.cursors) is paced.  epoch = 32-row stages per epoch, slack = epochs a tile may run ahead of the slowest
+ * tile of its matrix: (0, -) = the defaults 4 / 2 (the process default); (3..64, 1..8) explicit; (-1, -) = never pace. */
 int aew_set_tn_cursor(int epoch, int slack);
 
 /* Number of fp32 partial slabs a TN op writes into `out` (depends on the split heuristic). */

@@ -503,8 +503,9 @@ def test_gemm_tn_group(tile):
         gb.emit(p, "group")
         assert p.labels[0].startswith("zero:") and len(p.ops) == 2
         try:
-            for epoch, slack in ((3, 1), (4, 2)):
+            for epoch, slack in ((3, 1), (4, 2), (0, 0)):                   # (0, -): the defaults 4 / 2
                 assert lib.aew_set_tn_cursor(epoch, slack) == 0
+                epoch = epoch or 4
                 p.run(stream())
                 torch.cuda.synchronize()
                 prog = ws_2.get("tngc.cursors").view(-1, 64).cpu()
@@ -514,6 +515,14 @@ def test_gemm_tn_group(tile):
                 for n in ("o1", "o2", "o3", "o4", "snap", "cs1", "cs2"):
                     assert torch.equal(ws_2.get(n), ws_g.get(n)), (n, epoch, slack)
             assert lib.aew_set_tn_cursor(1, 1) != 0 and lib.aew_set_tn_cursor(4, 9) != 0
+            assert lib.aew_set_tn_cursor(-1, 0) == 0                        # veto: the unpaced kernel, counters untouched
+            ws_2.get("tngc.cursors").fill_(7)
+            p.ops = p.ops[1:]                                               # (without the op that zeroes them)
+            p.labels = p.labels[1:]
+            p._arr = None
+            p.run(stream())
+            torch.cuda.synchronize()
+            assert int(ws_2.get("tngc.cursors").min()) == 7 and torch.equal(ws_2.get("o1"), ws_g.get("o1"))
         finally:
             lib.aew_set_tn_cursor(0, 0)
 

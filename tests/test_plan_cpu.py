@@ -244,6 +244,7 @@ def test_schedule_options_leave_the_plan_results_alone(golden_dir, monkeypatch):
         else:
             assert ops[i_grp].lane == 4 and labs[i_grp + 1] == "spk_bwd" and ops[i_grp + 1].lane == 4
             assert labs[i_grp - 1].startswith("zero:") and labs[i_grp - 1].endswith(".cursors") and ops[i_grp - 1].lane == 4
+            assert E.DecoderPlan.wgrad_cursor is True
             assert ops[i_grp].u.tng.cursor_stride == 64 and ops[i_grp].u.tng.cursors
             assert ops[labs.index("unpack grads (decoder)")].lane == 4
         run(eng, z)

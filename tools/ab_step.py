@@ -90,7 +90,7 @@ def main():
             if k == "graphs":                      # 0: plans run eagerly (real streams + events) instead of as hipGraphs
                 eng.use_graphs = bool(v)
                 continue
-            if k == "tn_cursor":                   # epoch * 10 + slack (0 = off)
+            if k == "tn_cursor":                   # epoch * 10 + slack (0 = the defaults 4 / 2 where the plan paces a launch)
                 lib.aew_set_tn_cursor(v // 10, v % 10)
                 continue
             getattr(lib, "aew_set_" + k)(v)
