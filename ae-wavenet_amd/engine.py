@@ -211,10 +211,14 @@ class DecoderPlan:
                               # against 7.68 with one launch and 7.75 with one split-K op per matrix).  0: one TN op per
                               # matrix (round 2's form)
     side_inputs_first = True  # forward: spk_bias / base_gather at the head of the plan's side lane (False: after the upsamplers)
-    wgrad_tile = 128          # output tile of the grouped wgrad launch: 128 (three 4-wave blocks per CU) | 256 (one 8-wave
-                              # block per CU, half the operand bytes staged per FLOP).  Measured: 1.66 ms with 128, 2.21
-                              # ms with 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three
-                              # independent blocks per CU reach 43 GB/s together
+    wgrad_tile = None         # output tile of the grouped wgrad launch: 128 (three 4-wave blocks per CU) | 256 (one 8-wave
+                              # block per CU, half the operand bytes staged per FLOP) | None = by the size of the launch:
+                              # 256 when the stack's matrices make more than 1024 tiles of 128 (more than the 768 block slots
+                              # hold at once), else 128.  Measured: arch.vqvae-ema (768 tiles) 1.66 ms with 128, 2.21 ms with
+                              # 256 - a lone block fills its LDS at ~26 GB/s whatever its ring depth, three independent blocks
+                              # per CU reach 43 GB/s together; the deep decoder (30 x 512: 1450 tiles, bound by what it
+                              # re-fetches) 67.1 ms per step with 128, 64.8 with 128 + row cursor, 62.9 with 256
+                              # (profiles/r04_notes.md 24, 25)
     wgrad_cursor = None       # the grouped weight-gradient launches of the stack paced by the row cursor
                               # (aew_gemm_tn_group_t.cursors): True / False / None = iff the launch has more tiles than
                               # TnGroupBuilder.CURSOR_AUTO_TILES.  Measured: arch.vqvae-ema (768 tiles, one resident wave) 7.03 ->
@@ -637,6 +641,12 @@ class DecoderPlan:
         with plan.side(self._next_lane()):
             plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
 
+    def _wgrad_tile(self) -> int:
+        if self.wgrad_tile:
+            return self.wgrad_tile
+        n128 = self.NL * ((2 * self.Dp // 128) * ((2 * self.Rp + self.Cp) // 128) + (self.Rp // 128) * (self.Dp // 128))
+        return 256 if n128 > TnGroupBuilder.CURSOR_AUTO_TILES else 128
+
     def _next_lane(self, kind: str = "") -> int:
         n = min(self.n_side_lanes, Plan.N_SIDE, 3)             # lanes 4 / 5 are for explicit branches (tail_lane, split_chains)
         self._lane_rr = getattr(self, "_lane_rr", 0) % max(1, n) + 1
@@ -692,7 +702,7 @@ class DecoderPlan:
         def group_add(name, t, tag):
             nonlocal grp
             if grp is None:
-                grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
+                grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self._wgrad_tile())
                 grp.cursor = self.wgrad_cursor
             ptr, stride = self._gslab(name, t.N_pad, t.K_total, 1)
             t.out, t.out_batch_stride = ptr, stride
@@ -883,7 +893,7 @@ class DecoderPlan:
         if grouped:
             for name, t in tail_descs:
                 if grp is None:
-                    grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self.wgrad_tile)
+                    grp = TnGroupBuilder(self.ws, p + f"tng{n_groups}", self._wgrad_tile())
                     grp.cursor = self.wgrad_cursor
                 grp.add(t, "wgrad." + name)
             with plan.side(tail or self._next_lane("tng")):

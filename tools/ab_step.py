@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
+    ap.add_argument("--arch", default="vqvae-ema", help="config.make_hps architecture (deep: --batch 4 --n-win 65536)")
     ap.add_argument("--per-op", dest="per_op", action="append", default=[])
     ap.add_argument("--out", default=None, help="directory for the per-op tables")
     ap.add_argument("--plan", default=None, help="time ONE plan of the engine (fwd_a | fwd_b | bwd | opt) instead of the step")
@@ -37,7 +38,7 @@ def main():
     from ae_wavenet_amd import _lib as L, autoencoder_model as ae, config, engine as E
     lib = L.load()
     dev = torch.device("cuda", 0)
-    hps = config.make_hps("vqvae-ema", n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=0.12)
+    hps = config.make_hps(args.arch, n_win_batch=args.n_win, n_batch=args.batch, jitter_prob=0.12)
     e_defaults = {}
 
     def parse(cfg):
