@@ -1660,7 +1660,8 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
     int c_in_b = 0, bdone = b_lo;
     // column sums of G (grouped form, first k tile, the two waves of k half 0): one more MFMA per n tile and stage with
     // an all-ones A operand - every row of the result is sum_m G[m][n]
-    const bool do_cs = SNAP && g.colsum_out != nullptr && kt == 0 && wk == 0;
+    const bool snap_cs = SNAP && g.snap_out && g.snap_k < 0;   // snap_k = -1: the running column sums of G themselves
+    const bool do_cs = SNAP && (g.colsum_out != nullptr || snap_cs) && kt == 0 && wk == 0;
     f32x4_t cs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -1747,6 +1748,11 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
                     so[j * 16] = v;
                 }
             }
+            if (snap_cs && do_cs && (lane >> 4) == 0) {          // every row of cs[j] is sum_m G[m][n] so far
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n0 + wn * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) so[j * 16] = cs[j][0];
+            }
             ++bdone;
         }
     }
@@ -1760,7 +1766,7 @@ __device__ __forceinline__ void tn_bf16_tile(const aew_gemm_tn_t& g, char* smem,
             *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
-        if (do_cs && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
+        if (do_cs && g.colsum_out && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
     }
 }
 
@@ -1938,7 +1944,8 @@ __device__ __forceinline__ void tnb_tile(const aew_gemm_tn_t& g, char* smem, int
     const bool snap_here = SNAP && g.snap_out && srel >= 0 && srel < 128;
     int c_in_b = 0, bdone = b_lo;
     // column sums of G (see tn_bf16_tile): the waves of k half 0 of the first k tile
-    const bool do_cs = SNAP && g.colsum_out != nullptr && kt == 0 && wk == 0 && comp_valid;
+    const bool snap_cs = SNAP && g.snap_out && g.snap_k < 0;   // snap_k = -1: the running column sums of G themselves
+    const bool do_cs = SNAP && (g.colsum_out != nullptr || snap_cs) && kt == 0 && wk == 0 && comp_valid;
     f32x4_t cs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -1987,6 +1994,11 @@ __device__ __forceinline__ void tnb_tile(const aew_gemm_tn_t& g, char* smem, int
                     so[j * 16] = v;
                 }
             }
+            if (snap_cs && do_cs && (lane >> 4) == 0) {
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n128 * 128 + (wn & 1) * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) so[j * 16] = cs[j][0];
+            }
             ++bdone;
         }
     }
@@ -2001,7 +2013,7 @@ __device__ __forceinline__ void tnb_tile(const aew_gemm_tn_t& g, char* smem, int
             *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
-        if (do_cs && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
+        if (do_cs && g.colsum_out && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
     }
 }
 
@@ -2483,7 +2495,7 @@ extern "C" int aew_tn_group_check(const aew_gemm_tn_t* g) {
     const int rc = check_seg(gg, 2, TN_BT);
     if (rc) return rc;
     if (ksum != g->K_total || g->N_pad % TN_BT || (g->N_pad / TN_BT) * (g->K_total / TN_BT) > 0xfff) return AEW_E_ARG;
-    if (g->snap_out && (g->snap_k < 0 || g->snap_k >= g->K_total)) return AEW_E_ARG;
+    if (g->snap_out && (g->snap_k < -1 || g->snap_k >= g->K_total)) return AEW_E_ARG;
     if (g->grp_splits < 0 || g->grp_splits * g->batch > 0x3ff) return AEW_E_ARG;
     if (g->grp_splits > 0 && (g->grp_rows <= 0 || g->grp_rows % TN_RC || (int64_t)g->grp_splits * g->grp_rows < g->Mc ||
                               g->snap_out || g->colsum_out))

@@ -685,7 +685,9 @@ class DecoderPlan:
         # the chain, together with the skip and post-network weight gradients.  With the ones channel in x the fg
         # descriptors also deliver the running per-batch column sums of dfg.
         grouped = self.wgrad_group > 0 and self.impl == 0
-        snap_ok = grouped and self.R < Rp
+        # running per-batch column sums of dfg out of the grouped launch: column R of the weight gradient where x carries
+        # the ones channel (R < Rp), else the launch's own all-ones operand (aew_gemm_tn_t.snap_k = -1)
+        snap_ok = grouped
         grp: Optional[TnGroupBuilder] = None
         n_groups = 0
         tail_descs = []                                        # (name, descriptor): join the last group
@@ -801,7 +803,7 @@ class DecoderPlan:
                     pk.rec(q + "dil_res.weight", 0, [D, 1], [R, D], None, 0, [Dp, 1], g_ptr=gp, slabs=gn, slab_stride=gs)
                 t = make_tn(BF, P_l, B, 2 * Dp, 2 * Dp, self.dfg[l].seg(2 * Dp), fg_segs)
                 if snap_ok:
-                    t.snap_out, t.snap_bs, t.snap_k = self.colsum_fg.data_ptr() + 4 * l * 2 * Dp, NL * 2 * Dp, R
+                    t.snap_out, t.snap_bs, t.snap_k = self.colsum_fg.data_ptr() + 4 * l * 2 * Dp, NL * 2 * Dp, (R if self.R < Rp else -1)
                 gp, gs, gn = group_add(f"fg{l}", t, TAG_WG_FG)
             else:
                 if not last:

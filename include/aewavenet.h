@@ -160,7 +160,9 @@ typedef struct {
      * bias / speaker-embedding gradients come out of the weight-gradient GEMM for free (aew_spk_bwd_t.colsum_running). */
     float* snap_out;
     int64_t snap_bs;
-    int32_t snap_k;              /* column of the concatenated K axis; < 0: none                */
+    int32_t snap_k;              /* column of the concatenated K axis; -1 (with snap_out): no A column - the running
+                                    column sums of G themselves, from an all-ones MFMA operand in the blocks of the
+                                    first k tile (layers without a spare pad channel for the ones: R a multiple of 128) */
     int32_t pad_;
     /* Grouped form only.  colsum_out != NULL: colsum_out[n] = sum_b sum_m G[b][m][n] for n < N - the bias gradient of
      * the layer whose weight gradient this is (its G operand is the gradient of the layer's pre-activation) - written

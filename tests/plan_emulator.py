@@ -201,8 +201,11 @@ class Emu:
                 Gm = self.seg_matrix(self._with_k(t.g, t.N_pad), b, t.Mc, t.dtype)
                 A = torch.cat([self.seg_matrix(t.seg[s], b, t.Mc, t.dtype) for s in range(t.n_segs)], dim=1)
                 dW += Gm.t() @ A
-                if t.snap_out:
+                if t.snap_out and t.snap_k >= 0:
                     self.wr(t.snap_out, b * t.snap_bs + torch.arange(t.N_pad), dW[:, t.snap_k])
+                elif t.snap_out:                               # snap_k = -1: running column sums of G
+                    run_cs = Gm.sum(0) + (run_cs if b else 0.0)
+                    self.wr(t.snap_out, b * t.snap_bs + torch.arange(t.N_pad), run_cs)
             out[ooff:ooff + t.N_pad * t.K_total] = dW.reshape(-1)
             if t.colsum_out:
                 cs = torch.zeros(t.N_pad)

@@ -422,6 +422,7 @@ def test_gemm_tn_group(tile):
         t = make_tn(BF, 650, B, 368, 384, G2.seg(384, hi=640), [Z.seg(256)])
         t.out, t.out_batch_stride = ws.get("o2").data_ptr(), 384 * 256
         t.colsum_out = ws.get("cs2").data_ptr()          # 368 real columns: entries 368.. must stay untouched
+        t.snap_out, t.snap_bs, t.snap_k = ws.get("snap2").data_ptr(), 384, -1     # running column sums of G2 itself
         descs.append(t)
         t = make_tn(BF, 33, B, 256, 256, G1.seg(256, row_off=5), [Z.seg(256, row_off=-2)])    # shorter than one stage pair
         t.out, t.out_batch_stride = ws.get("o3").data_ptr(), 256 * 256
@@ -437,7 +438,7 @@ def test_gemm_tn_group(tile):
         ws_c.alloc(n, sz, torch.bfloat16)
         _fill(ws_c, n, gen)
     ws_c.get("A1").view(-1)[:B * 740 * 384].view(B * 740, 384)[:, 368] = 1.0        # the ones channel
-    for n, sz in (("o1", 256 * 896), ("o2", 384 * 256), ("o3", 256 * 256), ("snap", B * 256)):
+    for n, sz in (("o1", 256 * 896), ("o2", 384 * 256), ("o3", 256 * 256), ("snap", B * 256), ("snap2", B * 384)):
         ws_c.alloc(n, sz, torch.float32)
         ws_c.alloc(n + ".ref", 8 * sz, torch.float32)
     ws_c.alloc("o4", 9 * 128 * 512, torch.float32)       # 3 batch elements x 3 chunks of 224 rows
@@ -465,7 +466,7 @@ def test_gemm_tn_group(tile):
         else:
             Emu(ws).run(p)
     assert torch.all(ws_g.get("cs2")[368:384].cpu() == -7.0)
-    for n in ("o1", "o2", "o3", "snap", "cs1", "cs2") + (("o4",) if tile == 128 else ()):
+    for n in ("o1", "o2", "o3", "snap", "snap2", "cs1", "cs2") + (("o4",) if tile == 128 else ()):
         ref, got = ws_c.get(n).float(), ws_g.get(n).float().cpu()
         err = (got - ref).abs().max().item()
         assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (n, err)
@@ -486,12 +487,16 @@ def test_gemm_tn_group(tile):
     g1 = ws_c.get("G1")[:B * 700 * 256].view(B, 700, 256).float()
     run_sum = torch.cumsum(g1[:, :690].sum(1), 0)
     assert (ws_g.get("snap")[:B * 256].view(B, 256).cpu() - run_sum).abs().max().item() <= 2e-3 * run_sum.abs().max().item()
+    # snap_k = -1: the same for a matrix without a ones channel (rows of G2 below its row limit 640, all 384 columns)
+    g2 = ws_c.get("G2")[:B * 650 * 384].view(B, 650, 384).float()
+    run_sum2 = torch.cumsum(g2[:, :640].sum(1), 0)
+    assert (ws_g.get("snap2")[:B * 384].view(B, 384).cpu() - run_sum2).abs().max().item() <= 2e-3 * run_sum2.abs().max().item()
     if tile == 128:
         # the same launch paced by the row cursor (aew_gemm_tn_group_t.cursors, aew_set_tn_cursor): the tiles of a matrix
         # wait for each other every few stages, which changes when a row is read and nothing about what is summed
         lib = L.load()
         ws_2 = _mirror(ws_c, DEV)
-        for n in ("o1", "o2", "o3", "o4", "snap", "cs1"):
+        for n in ("o1", "o2", "o3", "o4", "snap", "snap2", "cs1"):
             ws_2.get(n).zero_()
         gb = TnGroupBuilder(ws_2, "tngc", tile)
         gb.cursor = True
@@ -512,7 +517,7 @@ def test_gemm_tn_group(tile):
                 stages = 3 * ((690 + 31) // 32)
                 assert int(prog[0, :14].min()) == int(prog[0, :14].max()) == (stages - 1) // epoch, prog[0, :16]
                 assert int(prog[2].max()) == 0 or 3 * 2 > epoch            # the 33-row matrix has 6 stages
-                for n in ("o1", "o2", "o3", "o4", "snap", "cs1", "cs2"):
+                for n in ("o1", "o2", "o3", "o4", "snap", "snap2", "cs1", "cs2"):
                     assert torch.equal(ws_2.get(n), ws_g.get(n)), (n, epoch, slack)
             assert lib.aew_set_tn_cursor(1, 1) != 0 and lib.aew_set_tn_cursor(4, 9) != 0
             assert lib.aew_set_tn_cursor(-1, 0) == 0                        # veto: the unpaced kernel, counters untouched
