@@ -22,7 +22,8 @@ EF_OUT2_COPY = 1 << 10
 
 (OP_GEMM_NT, OP_GEMM_TN, OP_COPY_TABLE, OP_VQ_NEAREST, OP_VQ_STATS, OP_VQ_EMA, OP_VQ_BWD,
  OP_LC_GATHER, OP_LC_SCATTER, OP_SPK_BIAS, OP_SPK_BWD, OP_BASE_GATHER, OP_SOFTMAX_NLL, OP_COLSUM,
- OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC, OP_MOMENTS, OP_GEMM_TN_GROUP) = range(1, 25)
+ OP_REDUCE, OP_ADAM, OP_ZERO, OP_VAE, OP_AE_NORM, OP_JITTER, OP_VQ_DIAG, OP_MFCC, OP_MOMENTS, OP_GEMM_TN_GROUP,
+ OP_NT_CHAIN) = range(1, 26)
 
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
@@ -57,6 +58,25 @@ class GemmTN(C.Structure):
 class GemmTNGroup(C.Structure):
     _fields_ = [("descs", vp), ("tile_map", vp), ("n_descs", i32), ("n_blocks", i32), ("tile", i32), ("cursor_stride", i32),
                 ("cursors", vp)]
+
+
+CHAIN_MAXDEP = 3
+
+
+class ChainDep(C.Structure):
+    _fields_ = [("cnt_base", i32), ("n_mt", i32), ("need", i32), ("d_lo", i32), ("d_hi", i32), ("c_lo", i32), ("c_hi", i32),
+                ("bm", i32)]
+
+
+class NtStage(C.Structure):
+    """aew_nt_stage_t: one stage of a chained NT launch (filled in by aew_nt_chain_build, uploaded to device memory)."""
+    _fields_ = [("g", GemmNT), ("kind", i32), ("first_block", i32), ("n_blocks", i32), ("n_mt", i32), ("n_nt", i32),
+                ("cnt_base", i32), ("publish", i32), ("n_deps", i32), ("dep", ChainDep * CHAIN_MAXDEP)]
+
+
+class NtChain(C.Structure):
+    _fields_ = [("stages", vp), ("block_stage", vp), ("counters", vp), ("n_stages", i32), ("n_blocks", i32),
+                ("n_counters", i32), ("set", i32), ("n_ops", i32), ("spin_max", i32), ("flags", i32), ("pad_", i32)]
 
 
 class CopyRec(C.Structure):
@@ -121,7 +141,7 @@ class SpkBwd(C.Structure):
 class Tuning(C.Structure):
     """aew_tuning_t: kernel-shape choices as a record (the aew_set_* switches edit the process-wide one; Plan.run(...,
     tuning=...) / aew_run_plan_tuned apply a caller's own to one call)."""
-    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("reserved_", i32 * 8)]
+    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("nt_chain", i32), ("reserved_", i32 * 7)]
 
 
 class BaseGather(C.Structure):
@@ -199,7 +219,7 @@ class _OpU(C.Union):
                 ("lcs", LcScatter), ("spk", SpkBias), ("spkb", SpkBwd), ("base", BaseGather),
                 ("sm", SoftmaxNll), ("cs", Colsum), ("red", Reduce), ("adam", Adam),
                 ("zero", Zero), ("vae", Vae), ("aen", AeNorm), ("jit", Jitter), ("diag", VqDiag), ("mfcc", Mfcc),
-                ("mom", Moments), ("tng", GemmTNGroup)]
+                ("mom", Moments), ("tng", GemmTNGroup), ("chain", NtChain)]
 
 
 class Op(C.Structure):
@@ -211,7 +231,7 @@ OP_FIELD = {OP_GEMM_NT: "nt", OP_GEMM_TN: "tn", OP_COPY_TABLE: "copy", OP_VQ_NEA
             OP_LC_SCATTER: "lcs", OP_SPK_BIAS: "spk", OP_SPK_BWD: "spkb",
             OP_BASE_GATHER: "base", OP_SOFTMAX_NLL: "sm", OP_COLSUM: "cs", OP_REDUCE: "red",
             OP_ADAM: "adam", OP_ZERO: "zero", OP_VAE: "vae", OP_AE_NORM: "aen", OP_JITTER: "jit",
-            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc", OP_MOMENTS: "mom", OP_GEMM_TN_GROUP: "tng"}
+            OP_VQ_DIAG: "diag", OP_MFCC: "mfcc", OP_MOMENTS: "mom", OP_GEMM_TN_GROUP: "tng", OP_NT_CHAIN: "chain"}
 
 # ---- autoregressive sampler (aew_actor_t / aew_sampler_t) ----
 ACT_NONE, ACT_EARLY, ACT_LATE, ACT_RES, ACT_SKIP, ACT_POST1, ACT_POST2, ACT_SAMPLE = -1, 0, 1, 2, 3, 4, 5, 6
@@ -282,12 +302,17 @@ def load():
     lib.aew_graph_capture_tuned.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
     for fn in (lib.aew_tuning_default, lib.aew_tuning_get, lib.aew_tuning_set):
         fn.argtypes = [C.c_void_p]
-    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler), (8, Tuning)):
+    lib.aew_nt_chain_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int), C.c_int]
+    lib.aew_probe_box.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.aew_nt_chain_dep_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler), (8, Tuning),
+                       (9, NtStage), (10, NtChain)):
         want = lib.aew_sizeof(which)
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 18:
+    if lib.aew_abi_version() != 19:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -334,4 +359,4 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_set_lanes", "aew_set_tn_cursor", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nt_small_waves", "aew_set_nf_deep", "aew_set_nf_loaders", "aew_set_nt_rows192",
            "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_set_fn_ring3", "aew_set_nt_small_n64", "aew_tn_group_check", "aew_set_nt_mem128", "aew_set_nt_deep", "aew_tuning_default", "aew_tuning_get",
-           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned")
+           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned", "aew_nt_chain_build", "aew_nt_chain_dep_tiles", "aew_probe_box")

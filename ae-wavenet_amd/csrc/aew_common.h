@@ -23,7 +23,7 @@ __device__ __attribute__((aligned(128))) unsigned int aew_zero_region[2 * AEW_ZE
 // ---- tuning context (aew_tuning_t, aewavenet.h): the process-wide record the aew_set_* switches edit, and the record of
 // the call in progress when a caller passed its own (aew_run_plan_tuned): launchers read AEW_T().field
 // (field order of aew_tuning_t; the ONE place the library's defaults are written down: aew_tuning_default returns the same)
-#define AEW_TUNING_DEFAULTS {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}}
+#define AEW_TUNING_DEFAULTS {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, 0, 0, 1, {0, 0, 0, 0, 0, 0, 0}}
 static aew_tuning_t g_tune = AEW_TUNING_DEFAULTS;
 static thread_local const aew_tuning_t* t_tune = nullptr;
 static inline const aew_tuning_t& AEW_T() { return t_tune ? *t_tune : g_tune; }
@@ -89,11 +89,24 @@ __device__ __forceinline__ void row_load(const char* rp, int dtype, int n, float
     }
 }
 
-template <int W>
+// 16-byte WRITE-THROUGH store (sc1): the bytes leave the XCD's L2 for memory, where a workgroup on any XCD reads them
+// once this wave's `s_waitcnt vmcnt(0)` has passed - the payload store of an in-launch hand-off (chained NT launches;
+// MI355X_MICROARCH.md, inter-workgroup visibility).  Inline asm: there is no builtin for a scoped 16-byte global store;
+// the s_nop covers the ">8-byte store data" hazard the compiler pads only for its own stores.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ void store16_wt(void* p, u32x4_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
+// WT: write-through stores (bf16 rows of 8 channels and fp32 rows; the other forms are not produced by a chained stage)
+template <int W, bool WT = false>
 __device__ __forceinline__ void row_store(char* rp, int dtype, int n, const float v[W]) {
     if (!rp) return;
     if (dtype == AEW_BF16) {
-        if (W == 8) {
+        if (W == 8 && WT) {
+            store16_wt(rp + n * 2, (u32x4_t){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
+                                             pack2_bf16(v[W - 4], v[W - 3]), pack2_bf16(v[W - 2], v[W - 1])});
+        } else if (W == 8) {
             *reinterpret_cast<uint4*>(rp + n * 2) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]),
                                                                pack2_bf16(v[W - 4], v[W - 3]), pack2_bf16(v[W - 2], v[W - 1]));
         } else {
@@ -101,8 +114,11 @@ __device__ __forceinline__ void row_store(char* rp, int dtype, int n, const floa
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < W / 4; ++q)
-            *reinterpret_cast<float4*>(rp + (n + 4 * q) * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int q = 0; q < W / 4; ++q) {
+            if (WT) store16_wt(rp + (n + 4 * q) * 4, (u32x4_t){__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]),
+                                                               __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3])});
+            else *reinterpret_cast<float4*>(rp + (n + 4 * q) * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
     }
 }
 

@@ -102,7 +102,7 @@ __device__ __forceinline__ void gated_math(float f, float gt, float& z, float& p
 // filt / gate values of the same W channels ch..ch+W-1; np_f = packed column of filt channel ch
 // (the W channels lie inside one 16-channel group, so their packed columns are contiguous)
 // fbias / gbias: the W filt / gate biases of channels ch..ch+W-1 (loaded once per wave by the caller)
-template <int W, bool ABL = false>
+template <int W, bool ABL = false, bool WT = false>
 __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& R, int ch, const float f[W],
                                           const float gt[W], const float fbias[W], const float gbias[W]) {
     float z[W], pf[W], pg[W];
@@ -122,7 +122,7 @@ __device__ __forceinline__ void epi_gated(const aew_gemm_nt_t& g, const EpiRow& 
         asm volatile("" ::"v"(t));
         return;
     }
-    row_store<W>(R.o0, AEW_BF16, ch, z);
+    row_store<W, WT>(R.o0, AEW_BF16, ch, z);             // WT: z is handed to a later stage of the same launch
     row_store<W>(R.o1, AEW_BF16, ch, pf);
     row_store<W>(R.o2, AEW_BF16, ch, pg);
 }
@@ -330,6 +330,7 @@ __device__ __forceinline__ void unpack8_bf16(const uint4& r, float o[8]) {
     }
 }
 
+template <bool WT = false>
 __device__ __forceinline__ void epi_store8_pf(const EpiUni& U, const EpiRow& R, int n, float v[8], unsigned& zero_count,
                                               unsigned fl, const uint4& a0raw, const uint4& a1raw) {
     if (fl & AEW_EF_RELU) {
@@ -362,9 +363,10 @@ __device__ __forceinline__ void epi_store8_pf(const EpiUni& U, const EpiRow& R, 
 #pragma unroll
         for (int r = 0; r < 8; ++r) zero_count += (n + r < U.N && v[r] == 0.f) ? 1u : 0u;
     }
-    row_store<8>(R.o0, U.dt_o0, n, v);
+    row_store<8, WT>(R.o0, U.dt_o0, n, v);
 }
 
+template <bool WT = false>
 __device__ __forceinline__ void epi_dfg8_pf(const EpiUni& U, const EpiRow& R, int n, const float dz[8],
                                             const uint4& pfraw, const uint4& pgraw) {
     float pf[8], pg[8], df[8], dg[8];
@@ -376,8 +378,8 @@ __device__ __forceinline__ void epi_dfg8_pf(const EpiUni& U, const EpiRow& R, in
         dg[r] = dz[r] * pg[r];
     }
     const int np = (n >> 4) * 32 + (n & 15);           // 8 channels stay inside one 16-group
-    row_store<8>(R.o0, U.dt_o0, np, df);
-    row_store<8>(R.o0, U.dt_o0, np + 16, dg);
+    row_store<8, WT>(R.o0, U.dt_o0, np, df);
+    row_store<8, WT>(R.o0, U.dt_o0, np + 16, dg);
 }
 
 // ---- epilogue of the bf16 NT kernels.  With the staging permutation nt_wperm, lane (fi, fg) holds
@@ -422,7 +424,7 @@ __device__ __forceinline__ char* epi_view_row(const EpiViewCtx& c, int j) {
 // stores into a sink, flags as selects: counted waits only, no store ever waited for; commit ae1bb12) changed nothing:
 // 6.995 vs 6.968 ms per step.  The epilogue is bound by what it moves, not by how its instructions wait:
 // tools/phase_clock.py, tools/overlap_probe.py, profiles/r04_notes.md.)
-template <int EPI, bool ABL, int MT>
+template <int EPI, bool ABL, int MT, bool WT = false>       // WT: out0 stored write-through (stage of a chained launch)
 __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&acc)[4][MT], int b, int m0, int n0,
                                             int wm, int wn, int lane) {
     const int fi = lane & 15, fg = lane >> 4;
@@ -502,7 +504,7 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
                                 acc[1][j][0], acc[1][j][1], acc[1][j][2], acc[1][j][3]};
             const float q[8] = {acc[2][j][0], acc[2][j][1], acc[2][j][2], acc[2][j][3],
                                 acc[3][j][0], acc[3][j][1], acc[3][j][2], acc[3][j][3]};
-            if (row_ok && ch < U.N) epi_gated<8, ABL>(g, R, ch, f, q, bias_a, bias_b);
+            if (row_ok && ch < U.N) epi_gated<8, ABL, WT>(g, R, ch, f, q, bias_a, bias_b);
         } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -517,10 +519,10 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
                             const char* p1 = epi_view_row(ca1, j);
                             a1 = p1 ? *reinterpret_cast<const uint4*>(p1 + n * 2) : make_uint4(0, 0, 0, 0);
                         }
-                        epi_store8_pf(U, R, n, v, zc, fl, raw0[2 * j + u], a1);
+                        epi_store8_pf<WT>(U, R, n, v, zc, fl, raw0[2 * j + u], a1);
                     }
                     else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(U, R, n, v);
-                    else epi_dfg8_pf(U, R, n, v, raw0[2 * j + u], raw1[2 * j + u]);
+                    else epi_dfg8_pf<WT>(U, R, n, v, raw0[2 * j + u], raw1[2 * j + u]);
                 }
             }
         }
@@ -539,7 +541,7 @@ template <int N>
 __device__ __forceinline__ void nt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // one output tile: block index L of the launch's tile order
-template <int EPI, bool ABL, int MT, int NB, int BMV, int ST>
+template <int EPI, bool ABL, int MT, int NB, int BMV, int ST, bool WT = false>
 __device__ __forceinline__ void nt_tile(const aew_gemm_nt_t& g, char* smem, const int L_) {
     typedef NtCfg<MT, NB, BMV> Cfg;
     static_assert(ST >= 3 && (ST - 2) * (Cfg::XP + Cfg::WP) <= 63 && ST * Cfg::STAGE_BYTES <= 160 * 1024, "ring depth");
@@ -763,7 +765,7 @@ __device__ __forceinline__ void nt_tile(const aew_gemm_nt_t& g, char* smem, cons
             for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    nt_epilogue<EPI, ABL, MT>(g, acc, b, m0, n0, wm, wn, lane);
+    nt_epilogue<EPI, ABL, MT, WT>(g, acc, b, m0, n0, wm, wn, lane);
 }
 
 template <int EPI, bool ABL = false, int MT = 8, int NB = 1, int BMV = NT_BM, int ST = NT_STAGES>
@@ -2157,6 +2159,7 @@ __global__ void k_gemm_tn_check(const aew_gemm_tn_t g, int splits, int rows_per_
 }
 
 #include "aew_win.hip"                                // k_gemm_nt_bf16_win: one LDS window for both dilation taps
+#include "aew_chain.hip"                              // k_nt_chain: a run of dependent NT GEMMs as one launch
 
 #ifndef AEW_DEV_KERNELS_ONLY   /* a development TU (ISA inspection of single kernels) stops here */
 // =============================================================================================
@@ -2216,6 +2219,8 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16_grp, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_grp_cur, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_big_grp, TNB_LDS_BYTES)
+    AEW_SET_LDS((k_nt_chain<0>), CHAIN_LDS_BYTES)
+    AEW_SET_LDS((k_nt_chain<1>), CHAIN_LDS_BYTES)
 #undef AEW_SET_LDS
     done.fetch_or(dev_bit, std::memory_order_release);
     return 0;

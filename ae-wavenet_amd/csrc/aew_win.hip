@@ -114,15 +114,15 @@ __device__ __forceinline__ const char* win_src(const aew_seg_t& sref, int b, int
 // Measured and dropped (profiles/r03_notes.md): touching the window's L2 lines four K steps ahead (+10 us per launch:
 // the loop is not waiting on latency), starting the blocks in odd thread-group slots of a CU a few us late so that the
 // two resident blocks run out of phase (null to slightly worse).
-template <int EPI, int MT, int DWP>
-__global__ __launch_bounds__(512, 4) void k_gemm_nt_bf16_win(const aew_gemm_nt_t g) {
+// one output tile: block index L of the launch's tile order (WT: out0 stored write-through, see nt_epilogue)
+template <int EPI, int MT, int DWP, bool WT = false>
+__device__ __forceinline__ void win_tile(const aew_gemm_nt_t& g, char* smem, const int L) {
     typedef WinCfg<MT, DWP> Cfg;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
     // tile order as in k_gemm_nt_bf16: the N tiles of one (batch, row tile) are consecutive on one XCD
     const int n_mt = (g.M + Cfg::BM - 1) / Cfg::BM, n_nt = g.N_pad / NT_BN;
-    const int L = blockIdx.x, seq = L >> 3;
+    const int seq = L >> 3;
     const int rt = (seq / n_nt) * 8 + (L & 7);
     if (rt >= n_mt * g.batch) return;
     const int b = rt / n_mt;
@@ -239,7 +239,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt_bf16_win(const aew_gemm_nt_t
         win_advance<MT>(g, b, m0, wave, lane, klen, P);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the idle-tail LDS-DMA must land before the LDS is released
-    nt_epilogue<EPI, false, MT>(g, acc, b, m0, n0, wm, wn, lane);
+    nt_epilogue<EPI, false, MT, WT>(g, acc, b, m0, n0, wm, wn, lane);
+}
+
+template <int EPI, int MT, int DWP>
+__global__ __launch_bounds__(512, 4) void k_gemm_nt_bf16_win(const aew_gemm_nt_t g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    win_tile<EPI, MT, DWP>(g, smem, blockIdx.x);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------

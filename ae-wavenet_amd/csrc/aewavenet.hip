@@ -52,6 +52,7 @@ static int dispatch(const aew_op_t& op, hipStream_t st) {
         case AEW_OP_MFCC: return launch_mfcc(op.u.mfcc, st);
         case AEW_OP_MOMENTS: return launch_moments(op.u.mom, st);
         case AEW_OP_GEMM_TN_GROUP: return launch_gemm_tn_group(op.u.tng, st);
+        case AEW_OP_NT_CHAIN: return 0;      // chaining off / timing mode: the stage ops that follow run one by one (run_ops)
         default: return AEW_E_UNSUP;
     }
 }
@@ -69,6 +70,8 @@ extern "C" int aew_sizeof(int which) {
         case 6: return (int)sizeof(aew_actor_t);
         case 7: return (int)sizeof(aew_sampler_t);
         case 8: return (int)sizeof(aew_tuning_t);
+        case 9: return (int)sizeof(aew_nt_stage_t);
+        case 10: return (int)sizeof(aew_nt_chain_t);
         default: return -1;
     }
 }
@@ -118,7 +121,7 @@ static int edge(hipStream_t from, hipStream_t to) {          // `to` continues a
 #define AEW_MAX_SIDE 5
 static hipStream_t g_side[AEW_MAX_SIDE + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [1..AEW_MAX_SIDE]
 
-static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, bool timing) {
+static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, int timing) {   // timing: g_timing
     const bool lanes = AEW_T().lanes && !timing;
     bool main_ahead[AEW_MAX_SIDE + 1];   // main has work side stream k has not been ordered after
     bool open[AEW_MAX_SIDE + 1];         // side stream k has work that main (or a joining side op) has not waited for
@@ -156,7 +159,22 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
             if (!e0 || !e1) return (int)hipErrorOutOfMemory;
             (void)hipEventRecord(e0, st);
         }
-        rc = dispatch(ops[i], target);
+        int skip = 0;
+        if (ops[i].kind == AEW_OP_NT_CHAIN) {
+            // the chain's stage ops follow it in the plan: launched as ONE kernel here (and skipped), or - chaining off,
+            // per-op timing - left to run one by one
+            const aew_nt_chain_t& c = ops[i].u.chain;
+            if (c.n_ops < 1 || i + c.n_ops > n - 1) { rc = AEW_E_ARG; if (fail_index) *fail_index = i; break; }
+            for (int k = 1; k <= c.n_ops && rc == 0; ++k)
+                if (ops[i + k].kind != AEW_OP_GEMM_NT || ops[i + k].lane != lane || (k > 1 && ops[i + k].join)) rc = AEW_E_ARG;
+            if (rc != 0) { if (fail_index) *fail_index = i; break; }
+            if (timing != 1 && AEW_T().nt_chain && c.stages) {           // (timing 2: the chain is timed as ONE op)
+                rc = ensure_big_lds();
+                if (rc == 0) rc = launch_nt_chain(c, target);
+                skip = c.n_ops;
+            }
+        } else
+            rc = dispatch(ops[i], target);
         if (timing) {
             (void)hipEventRecord(e1, st);
             if (g_ev_tag.size() <= g_ev_used) g_ev_tag.resize(g_ev_used + 1);
@@ -164,6 +182,16 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
             ++g_ev_used;
         }
         if (rc != 0 && fail_index) *fail_index = i;
+        for (int k = 0; k < skip && timing; ++k) {            // the chain's stage ops: empty intervals, so that event index = op index
+            hipEvent_t a = ev_get(2 * g_ev_used), b2 = ev_get(2 * g_ev_used + 1);
+            if (!a || !b2) return (int)hipErrorOutOfMemory;
+            (void)hipEventRecord(a, st);
+            (void)hipEventRecord(b2, st);
+            if (g_ev_tag.size() <= g_ev_used) g_ev_tag.resize(g_ev_used + 1);
+            g_ev_tag[g_ev_used] = ops[i + 1 + k].tag;
+            ++g_ev_used;
+        }
+        i += skip;
     }
     for (int k = 1; k <= AEW_MAX_SIDE; ++k)                  // implicit join (also on the error path,
         if (open[k]) {                                       // so a capture is never left forked)
@@ -175,7 +203,7 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
 
 extern "C" int aew_run_plan(const aew_op_t* ops, int n, void* stream, int* fail_index) {
     if (!ops || n < 0) return AEW_E_ARG;
-    return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing != 0);
+    return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing);
 }
 
 // ---- tuning context: a caller's own record for the duration of one call (thread-local), see aewavenet.h
@@ -189,7 +217,7 @@ static void tune_clamp(aew_tuning_t& t) {
     if (t.nt_wave_rows != 0 && t.nt_wave_rows != 1 && t.nt_wave_rows != 64 && t.nt_wave_rows != 128 && t.nt_wave_rows != 256)
         t.nt_wave_rows = 64;
     cl(t.nt_pipe, 0, 2); cl(t.nt_rows192, 0, 2); cl(t.nt_window, 0, 64); cl(t.nt_mem128, 0, 2); cl(t.nt_deep, 0, 3);
-    cl(t.lanes, 0, 2); if (t.tn_cursor_epoch > 0) { cl(t.tn_cursor_epoch, 3, 64); cl(t.tn_cursor_slack, 1, 8); } else if (t.tn_cursor_epoch < 0) t.tn_cursor_epoch = -1; cl(t.nt_small_w8, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
+    cl(t.lanes, 0, 2); if (t.tn_cursor_epoch > 0) { cl(t.tn_cursor_epoch, 3, 64); cl(t.tn_cursor_slack, 1, 8); } else if (t.tn_cursor_epoch < 0) t.tn_cursor_epoch = -1; cl(t.nt_small_w8, 0, 1); cl(t.nt_chain, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
     cl(t.nt_small_tiles, 0, 1 << 30); cl(t.nt_small_n64, 0, 1 << 30); cl(t.nt_small_deep, 0, 1 << 30); cl(t.nf_deep, 0, 1 << 30);
     cl(t.fn_ring3, 0, 1 << 30); cl(t.tn_big_target, 1, 1 << 30); cl(t.tn_fold_rows, 0, 1 << 30); cl(t.tn_target_blocks, 1, 1 << 30);
     cl(t.tn_small_tiles, 0, 1 << 30); cl(t.tn_small_target, 1, 1 << 30);
@@ -217,7 +245,7 @@ extern "C" int aew_run_plan_tuned(const aew_op_t* ops, int n, void* stream, int*
     aew_tuning_t t;
     if (tuning) { t = *tuning; tune_clamp(t); }
     TuneScope scope(tuning ? &t : nullptr);
-    return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing != 0);
+    return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing);
 }
 extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, int* fail_index);
 extern "C" int aew_graph_capture_tuned(const aew_op_t* ops, int n, void** exec_out, int* fail_index, const aew_tuning_t* tuning) {
@@ -244,7 +272,7 @@ extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, in
     }
     e = hipStreamBeginCapture(g_cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return (int)e;
-    rc = run_ops(ops, n, g_cap_stream, fail_index, false);
+    rc = run_ops(ops, n, g_cap_stream, fail_index, 0);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(g_cap_stream, &graph);
     if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -268,7 +296,7 @@ extern "C" int aew_graph_destroy(void* exec) {
 }
 
 extern "C" int aew_timing_enable(int on) {
-    g_timing = on ? 1 : 0;
+    g_timing = on == 2 ? 2 : (on ? 1 : 0);       // 2: chained launches (AEW_OP_NT_CHAIN) are timed as ONE op instead of stage by stage
     g_ev_used = 0;
     return 0;
 }
@@ -437,6 +465,63 @@ __global__ void k_selftest(int32_t* detail, float* scratch) {
             if (t[4 * lane + e] != (float)(4 * (63 - lane) + e)) bad = 1;
         if (__any(bad) && lane == 0) detail[4] = 1;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// box fingerprint (bench.py's `box` record): what THIS device sustains on two primitives, measured with HIP events on the
+// caller's stream right before a benchmark, so that two bench lines from two boxes of the pool can be told apart from
+// two builds (the pool's boxes differ by +-0.15 ms per step on one binary; profiles/r02_notes.md).
+//   out[0] TFLOP/s of a pure v_mfma_f32_16x16x32_bf16 loop (512 blocks x 512 threads, 16 accumulators: the NT kernels' wave shape)
+//   out[1] TB/s (read + written) of a device-to-device copy of `copy_bytes` with 16-byte accesses
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_probe_mfma(float* out, int iters) {
+    f32x4_t acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x & 3); b[e] = (__bf16)1.0f; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int aew_probe_box(void* scratch, int64_t scratch_bytes, int64_t copy_bytes, void* stream, float* out) {
+    if (!scratch || !out || copy_bytes < (1 << 20) || (copy_bytes & 15) || scratch_bytes < 2 * copy_bytes ||
+        scratch_bytes < 512 * 512 * 4 || ((uintptr_t)scratch & 15))
+        return AEW_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipErrorOutOfMemory;
+    float ms = 0.f;
+    int rc = 0;
+    const int iters = 2000, reps = 5;
+    hipLaunchKernelGGL(k_probe_mfma, dim3(512), dim3(512), 0, st, reinterpret_cast<float*>(scratch), iters);       // warm-up
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_mfma, dim3(512), dim3(512), 0, st, reinterpret_cast<float*>(scratch), iters);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = (int)hipGetLastError();
+    out[0] = ms > 0.f ? (float)((double)512 * 8 * iters * 16 * reps * (16.0 * 16 * 32 * 2) / (ms * 1e-3) / 1e12) : 0.f;
+    const uint4* src = reinterpret_cast<const uint4*>(scratch);
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(scratch) + copy_bytes);
+    const int64_t n16 = copy_bytes / 16;
+    hipLaunchKernelGGL(k_probe_copy, dim3(4096), dim3(256), 0, st, src, dst, n16);
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_copy, dim3(4096), dim3(256), 0, st, src, dst, n16);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = (int)hipGetLastError();
+    out[1] = ms > 0.f ? (float)(2.0 * (double)copy_bytes * reps / (ms * 1e-3) / 1e12) : 0.f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == 0) rc = (int)hipGetLastError();
+    return rc;
 }
 
 extern "C" int aew_selftest(void* scratch, int64_t scratch_bytes, void* stream, int32_t* detail) {

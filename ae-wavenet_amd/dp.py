@@ -38,10 +38,14 @@ def shard_indices(n: int, rank: int, world: int, epoch: int) -> List[int]:
 
 
 class DataParallel:
-    def __init__(self, bucket_mb: float = 32.0, group=None):
+    def __init__(self, bucket_mb: float = 32.0, group=None, force_collectives: bool = False):
+        """force_collectives: issue every collective also in a process group of ONE rank (they are identities there).  A
+        one-GPU box can then put RCCL under the product's exact calls - views, dtypes, stream ordering against graph
+        replays - which the world == 1 short cuts below would otherwise skip (tests/test_dp_gpu.py)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
+        self.force_collectives = bool(force_collectives)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
@@ -51,6 +55,10 @@ class DataParallel:
         self.moments_step = -1              # engine step count for which every rank holds ALL Adam moments
         self.timing = False                 # True: bracket every wait with events (exposed_ms())
         self._tev = []
+
+    def _solo(self) -> bool:
+        """One rank and no request to run the collectives anyway: every exchange is skipped."""
+        return self.world == 1 and not self.force_collectives
 
     # ---- measurement: how long the compute stream actually stalls on collectives ---------------------------------
     def _wait(self, work, what: str):
@@ -103,12 +111,12 @@ class DataParallel:
 
     def allreduce_kl(self, eng):
         """Sum the KL value the backward's clamp gate reads (loss_buf[2]) over the ranks (VAE only)."""
-        if eng.bn_type == "vae" and self.world > 1:
+        if eng.bn_type == "vae" and not self._solo():
             dist.all_reduce(eng.loss_buf[2:3], op=dist.ReduceOp.SUM, group=self.group)
 
     def allreduce_grads(self, eng):
         flat = eng.ps.grads[:eng.ps.numel]
-        if self.world == 1:
+        if self._solo():
             return
         n = flat.numel()
         for s in range(0, n, self.bucket_elems):
@@ -121,7 +129,7 @@ class DataParallel:
         (async, on the collective's own stream) and runs under the bottleneck / encoder backward.
         The head of the buffer follows when the backward is complete.  Numerically identical to
         backward() + allreduce_grads()."""
-        if self.world == 1:
+        if self._solo():
             eng.backward()
             return
         n, lo = eng.ps.numel, eng.dec_grad_offset
@@ -143,7 +151,7 @@ class DataParallel:
             (deferred) EMA accumulation after the backward;
           * decoder gradients: async all-reduce between the two backward plans (under the encoder backward);
           * encoder gradients: all-reduce after the backward, under the Adam update of the decoder range."""
-        if self.world == 1:
+        if self._solo():
             eng.forward()
             eng.backward()
             eng.adam_step(lr, grad_scale, **adam_kw)
@@ -304,7 +312,7 @@ class DataParallel:
         parameters as train_step() gives (fp32 transport: up to summation order; bf16 transport: the summed gradient
         is rounded to bf16 once per hop).  The Adam MOMENTS of a rank are valid for its own shards only (ZeRO-1): use
         gather_moments() before reading them (checkpoints)."""
-        if self.world == 1:
+        if self._solo():
             eng.forward()
             eng.backward()
             eng.adam_step(lr, grad_scale, **adam_kw)
@@ -323,7 +331,7 @@ class DataParallel:
     def gather_moments(self, eng):
         """All-gather the Adam moments (each rank holds valid moments for its own shards only under the sharded step).
         COLLECTIVE: every rank must call it."""
-        if self.world == 1:
+        if self._solo():
             return
         for a, b in self._regions(eng):
             s, rem = self._split(a, b)
@@ -336,7 +344,7 @@ class DataParallel:
     def moments_complete(self, eng) -> bool:
         """Does this rank hold the Adam moments of ALL parameters for the engine's current step?  (Always under the
         all-reduce schedule; under the sharded one only right after gather_moments().)"""
-        return self.world == 1 or not self.sharded or eng.step_count == 0 or self.moments_step == eng.step_count
+        return self._solo() or not self.sharded or eng.step_count == 0 or self.moments_step == eng.step_count
 
     def sync_optimizer_state(self, model):
         """Make model / optimizer state readable on every rank: waits for the parameter all-gathers in flight and
@@ -344,12 +352,12 @@ class DataParallel:
         optimizer.state_dict() / checkpoint.save() (checkpoint.save does it when the model is attached)."""
         self.finish()
         eng = getattr(model, "_engine", None)
-        if eng is not None and self.sharded and self.world > 1 and not self.moments_complete(eng):
+        if eng is not None and self.sharded and not self._solo() and not self.moments_complete(eng):
             self.gather_moments(eng)
 
     def allreduce_ema_async(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
         """Like allreduce_ema but returns the work handle (the engine then defers the EMA accumulation)."""
-        if self.world == 1:
+        if self._solo():
             return None
         both = self._ema_flat(z_sum, n_sum)
         if both is None:
@@ -366,7 +374,7 @@ class DataParallel:
         return None
 
     def allreduce_ema(self, z_sum: torch.Tensor, n_sum: torch.Tensor):
-        if self.world == 1:
+        if self._solo():
             return
         # the engine allocates n_sum right behind z_sum: one collective instead of two
         both = self._ema_flat(z_sum, n_sum)

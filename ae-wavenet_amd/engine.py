@@ -239,6 +239,10 @@ class DecoderPlan:
                               # under the dgrad chain and fill its tile-wave tails), the rest go to the grouped launch
     ups_split_rows = 1024     # upsampler / lc-conv weight gradients (few output tiles): contractions longer than this many
                               # rows x batch are cut into 512-row chunks (one block and one slab each) in the grouped launch
+    split_one_lane = False    # with split_chains / split_chains_bwd: both half-batch chains on the MAIN lane, interleaved stage by
+                              # stage - no graph branches; meant for the chained launch (TrainEngine.nt_chain), where the stages of
+                              # the two halves then alternate inside ONE launch and each half's tiles run while the other half's
+                              # wait for their producers
     split_chains = False      # True: gated stack as two half-batch chains on lanes 4 / 5 (build_forward); split_chains_bwd: the
                               # same for the backward's dz / dx chain.  Captured as graph branches (TrainEngine.graph_lanes) both
                               # together return 0.07-0.125 ms per step (five boxes, interleaved: 6.95 -> 6.85, 6.97 -> 6.905,
@@ -546,7 +550,7 @@ class DecoderPlan:
                 # two chains: BOTH on side lanes (4 and 5: the ones aew_set_lanes(2) honours alone).  A side op is ordered after every main-lane op emitted before
                 # it, so a chain left on the main lane would hold the other one back at every layer; with no main-lane op
                 # between the first layer and the skip sum the two lanes run free
-                plan.lane = (4 + c) if n_chains > 1 else 0
+                plan.lane = (4 + c) if (n_chains > 1 and not self.split_one_lane) else 0
                 segs = [x.seg(Rp, b0=b0), x.seg(Rp, row_off=lg.dil, b0=b0),
                         self.cond.seg(Cp, row_off=lg.cond_lead, b0=b0)]
                 sfx = f".c{c}" if n_chains > 1 else ""
@@ -563,7 +567,8 @@ class DecoderPlan:
                 plan.add(L.OP_GEMM_NT, make_nt(
                     BF, P_l, Dp, 2 * Dp, nb, segs, self.Wfg[l].ptr, impl=self._impl("G1"), **gkw),
                     f"G1.{l}" + sfx, TAG_G1,
-                    join=(True if n_chains > 1 else g1_join) if l == 0 else False)   # x[0] and the gated biases come from the side lane
+                    join=((g1_join if c == 0 else False) if self.split_one_lane else (True if n_chains > 1 else g1_join))
+                    if l == 0 else False)                              # x[0] and the gated biases come from the side lane
                 if not last:
                     # residual 1x1 + add (wavenet.py:108-109); the final layer has no residual output
                     plan.add(L.OP_GEMM_NT, make_nt(
@@ -781,7 +786,7 @@ class DecoderPlan:
             segs.append(self.dskp.seg(Sp, row_off=-lg.skip_lead))
             for c in range(n_chains):
                 b0 = c * nb
-                plan.lane = (4 + c) if n_chains > 1 else 0
+                plan.lane = (4 + c) if (n_chains > 1 and not self.split_one_lane) else 0
                 csegs = segs if n_chains == 1 else \
                     ([] if last else [dx_next.seg(Rp, hi=P_l, b0=b0)]) + [self.dskp.seg(Sp, row_off=-lg.skip_lead, b0=b0)]
                 plan.add(L.OP_GEMM_NT, make_nt(BF, P_l, Dp, Dp, nb, csegs, self.WrsT[l].ptr, epi=L.EPI_DFG,
@@ -858,7 +863,7 @@ class DecoderPlan:
             dx = self.dx[l]
             for c in range(n_chains):
                 b0 = c * nb
-                plan.lane = (4 + c) if n_chains > 1 else 0
+                plan.lane = (4 + c) if (n_chains > 1 and not self.split_one_lane) else 0
                 segs = [self.dfg[l].seg(2 * Dp, b0=b0), self.dfg[l].seg(2 * Dp, row_off=-d, b0=b0)]
                 plan.add(L.OP_GEMM_NT, make_nt(
                     BF, lg.in_len, Rp, Rp, nb, segs, self.WfgT[l].ptr,

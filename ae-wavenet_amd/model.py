@@ -19,7 +19,7 @@ from . import geometry as G
 from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC,
                      TAG_LOSS, TAG_MISC, TAG_PACK, TAG_VQ, bottleneck_param_specs,
                      decoder_param_specs, encoder_param_specs)
-from .plan import CopyTableBuilder, Mat, Plan, Workspace, make_nt, make_tn, null_view, ru
+from .plan import CopyTableBuilder, Mat, Plan, Workspace, insert_nt_chains, make_nt, make_tn, null_view, ru
 
 MEAN_LOSS = {"none": True, "ae": True, "vae": True, "vqvae": False, "vqvae-ema": False}
 
@@ -46,6 +46,18 @@ class TrainEngine:
     LANE_PACK_LATE = 2        # ... and of the backward-layout pack at the head of fwd_b (joined by its end).  4 / 5: the lanes
                               # aew_set_lanes(2) honours alone (A/B: each a single fork / join, profiles/r04_notes.md §16)
     PACK_LANE = 2             # side lane of the forward-layout weight pack (layers 1.. of the encoder, biases, bottleneck)
+    nt_chain = 64             # chained NT launches (AEW_OP_NT_CHAIN, csrc/aew_chain.hip): runs of dependent NT ops of the decoder
+                              # FORWARD - the gated stack's G1 / G2 ops (wavenet.py:354-357), the post network's pair - as
+                              # launches of up to this many stages with tile-granular hand-off (64: the whole stack is ONE
+                              # launch of 27 856 tiles instead of 39; 2: the pair of a layer; 0: one launch per op).  Bit-identical
+                              # results; per-op timing (aew_timing_enable(1)) always runs the ops one by one.  Measured,
+                              # interleaved on one box: fwd_b plan 2.089 -> 1.911 ms, step 6.865 -> 6.748 ms (profiles/r05_notes.md)
+    nt_chain_bwd = 0          # the same for the BACKWARD's d.post / dz / dx run.  Measured neutral to slightly negative (bwd plan
+                              # 4.085 -> 4.134 ms): a dz stage is 320-448 tiles - fewer than the 512 resident slots - so its
+                              # consumers (dx) are resident before it has finished and 11 000 of the launch's 20 432 tiles spin
+                              # on a counter, where the forward's stages (640-896 tiles) leave 900 of 27 856 waiting.  Option
+    nt_chain_force = False    # tests: chain also the sizes the stand-alone launcher runs on its small-launch shapes
+    nt_chain_flags = 0        # aew_nt_chain_t.flags (measurement aids)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
                               # forward plan; A/B: 8.02 -> 7.99 ms per step)
 
@@ -317,6 +329,17 @@ class TrainEngine:
         else:                                                  # A/B: all of them after the plan's last main-lane op
             self.dec.build_forward(fb)
             self._diag_tail = (after_logits, after_nll)
+        # AEW_NT_CHAIN = "f" or "f,b": stages per chained launch of the forward / backward (A/B and bisecting aid)
+        env = os.environ.get("AEW_NT_CHAIN")
+        n_f, n_b = int(self.nt_chain), int(self.nt_chain_bwd)
+        if env is not None:
+            v = [int(x) for x in env.split(",")]
+            n_f, n_b = v[0], (v[1] if len(v) > 1 else 0)
+        self.nt_chain_used = n_f if impl == 0 else 0
+        self.nt_chain_bwd_used = n_b if impl == 0 else 0
+        ckw = dict(force=bool(self.nt_chain_force), flags=int(self.nt_chain_flags))
+        if self.nt_chain_used >= 2:
+            insert_nt_chains(fb, ws, "chain.fwd", lambda lab: lab.startswith(("G1.", "G2.", "post1", "post2")), max_len=self.nt_chain_used, **ckw)
         red = L.Reduce()
         nll_ptr = self.dec.nll.data_ptr()
         terms = []
@@ -351,6 +374,9 @@ class TrainEngine:
         if bn == "vqvae-ema" and self.loss_mode == "head":
             nll_scale = 0.0
         self.dec.build_backward(bw, nll_scale)
+        if self.nt_chain_bwd_used >= 2:
+            insert_nt_chains(bw, ws, "chain.bwd", lambda lab: lab.startswith(("d.post2", "d.post1", "dz.", "dx.")),
+                             max_len=self.nt_chain_bwd_used, **ckw)
         # gradient statistics of run() (autoencoder_model.py:252-257 mel_grad_sd / bn_grad_sd; mfcc_inverter.py:100-106
         # mel_grad_sd / mel_grad_mean): by-products of this backward, reduced on a side lane as soon as their input is
         # final (d(loss)/d(code) here, under the encoder backward)
@@ -604,7 +630,8 @@ class TrainEngine:
             fb = self.fwd_b
             stop = fb.labels.index("G1.0") if "G1.0" in fb.labels else next(
                 i for i, l in enumerate(fb.labels) if l.startswith("G1.0"))
-            self._cond_plan = self._sub_plan("conditioning", fb, lambda i, lab: i < stop and lab != "vq.ema")
+            self._cond_plan = self._sub_plan("conditioning", fb, lambda i, lab: i < stop and lab != "vq.ema" and
+                                             not lab.startswith("chain["))
             self._cond_plan_a = self._sub_plan("conditioning_a", self.fwd_a, lambda i, lab: lab != "vq.stats")
         self._run(self._cond_plan_a, False)
         self._run(self._cond_plan, False)

@@ -29,7 +29,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("FusedAdam.step() before the first model.run()")
         g = self.param_groups[0]
         dp = getattr(self.model, "_dp", None)
-        if dp is not None and dp.sharded and dp.world > 1:
+        if dp is not None and dp.sharded and not dp._solo():
             # data parallel, sharded: Adam on this rank's shards of the reduce-scattered gradient, then all-gather
             dp.optimizer_step(eng, g["lr"], self.grad_scale, betas=g["betas"], eps=g["eps"])
         else:

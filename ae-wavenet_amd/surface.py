@@ -32,7 +32,7 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, anchor, owner):
         ctx.owner = owner
         dp = owner._dp
-        if dp is not None and dp.sharded and dp.world > 1:
+        if dp is not None and dp.sharded and not dp._solo():
             loss = dp.forward(owner._engine)                 # the decoder's parameter all-gather stays in flight under the encoder
         else:
             loss = owner._engine.forward(owner._ema_allreduce)
@@ -50,7 +50,7 @@ class _StepFn(torch.autograd.Function):
         owner._engine.set_upstream_grad(g)
         dp = owner._dp
         prev = owner._grads_carried()
-        if dp is not None and dp.sharded and dp.world > 1:
+        if dp is not None and dp.sharded and not dp._solo():
             dp.backward_exchange(owner._engine, dp.bf16_grads)   # reduce-scatter issued under the encoder backward
         else:
             if dp is not None:
@@ -378,7 +378,7 @@ class HipModelBase(nn.Module):
         (B, w-1), loss scalar with a grad_fn whose backward fills every parameter's .grad."""
         B = wav.shape[0]
         eng = self._ensure_engine(B)
-        if self._dp is not None and not (self._dp.sharded and self._dp.world > 1):
+        if self._dp is not None and not (self._dp.sharded and not self._dp._solo()):
             self._dp.finish()                                # (sharded: _StepFn.forward waits region by region)
         eng.set_inputs(wav, mel, voice, jitter, eps=eps)
         loss = _StepFn.apply(self._anchor, self)
@@ -443,7 +443,7 @@ class HipModelBase(nn.Module):
         grads = [(name, self._parameters[pname].grad) for name, pname in self._pnames]
         if all(gr is None for _, gr in grads):
             return None
-        if self._dp is not None and self._dp.sharded and self._dp.world > 1:
+        if self._dp is not None and self._dp.sharded and not self._dp._solo():
             raise L.AewError("backward() onto existing gradients (no zero_grad() since the last backward) is not supported "
                              "under the sharded data-parallel schedule: each rank holds the reduced gradient of its own "
                              "shards only")

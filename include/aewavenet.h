@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 18
+#define AEW_ABI_VERSION 19
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -472,6 +472,76 @@ typedef struct {                 /* time-jitter indices on the device (jitter.py
 } aew_jitter_t;
 
 /* ---------------------------------------------------------------------------------------
+ * Chained NT launch (ABI 19): a run of DEPENDENT bf16 NT ops - the gated stack's G1 / G2 pairs (wavenet.py:100-109,
+ * 354-357: the layer loop) or its backward's dz / dx pairs - as ONE kernel launch.  The tiles of all stages form one
+ * grid in stage order; a tile of stage s starts once the tiles of earlier stages that produce the rows it reads have
+ * published them (tile-granular hand-off through device-scope counters), so a stage's first tiles run in the slots
+ * its predecessor's last tiles leave free and the launch pays the fill / drain of a dependent launch once instead of
+ * once per op (profiles/r04_notes.md 13: ~10 us each, 84 times per step).
+ *   producer tile : out0 stored write-through (sc1), every wave drains its stores, one lane adds 1 to the counter of
+ *                   its (stage, batch element, row tile) - device scope
+ *   consumer tile : one wave polls the counters of the producer row tiles it reads (relaxed device-scope loads, bounded
+ *                   spin), one agent-scope acquire, workgroup barrier, then plain loads
+ * No assumption on workgroup -> XCD placement.  The bounded spin relies on workgroups being dispatched in index
+ * order (every producer of a resident tile has been dispatched): a wait that times out sets *err and the tile runs on.
+ * Same kernel bodies, tile shape (256 x 128) and summation order as the stand-alone launches of the default shape
+ * (k_gemm_nt_bf16<.., 4> / k_gemm_nt_bf16_win), so results are bit-identical to the serial plan.
+ *
+ * In a plan the chain op sits IN FRONT of its n_ops stage ops (plain AEW_OP_GEMM_NT records).  When chaining is on
+ * (aew_tuning_t.nt_chain, default 1) and the call is not in per-op timing mode, aew_run_plan launches the chain and
+ * skips the n_ops records; otherwise the chain op does nothing and the records run as stand-alone launches (what the
+ * timing pass and the CPU plan interpreter execute) - the two forms read and write the same buffers.
+ * The stage table is built on the HOST by aew_nt_chain_build from the same n_ops descriptors (dependencies derived
+ * from the segment / view records; anything it cannot prove safe is refused) and uploaded by the caller.
+ * ------------------------------------------------------------------------------------- */
+#define AEW_CHAIN_MAXDEP 3
+typedef struct {
+    int32_t cnt_base;            /* first counter of the producer stage                                       */
+    int32_t n_mt;                /* its row tiles per batch element                                           */
+    int32_t need;                /* arrivals per row tile = its N tiles                                       */
+    int32_t d_lo, d_hi;          /* consumer rows [m_first, m_last] read producer rows [m_first + d_lo, m_last + d_hi] ... */
+    int32_t c_lo, c_hi;          /* ... clipped to [c_lo, c_hi] (rows the producer writes and the consumer can read) */
+    int32_t bm;                  /* producer tile rows                                                        */
+} aew_chain_dep_t;
+
+typedef struct {
+    aew_gemm_nt_t g;
+    int32_t kind;                /* kernel body: 0 plain K loop, 1 one-window (d <= 16), 2 one-window (d <= 64)   */
+    int32_t first_block;         /* multiple of 8                                                             */
+    int32_t n_blocks;
+    int32_t n_mt, n_nt;
+    int32_t cnt_base;            /* counters [batch][n_mt] of this stage                                      */
+    int32_t publish;             /* a later stage waits for this one                                          */
+    int32_t n_deps;
+    aew_chain_dep_t dep[AEW_CHAIN_MAXDEP];
+} aew_nt_stage_t;
+
+typedef struct {
+    const aew_nt_stage_t* stages;    /* device                                                                */
+    const uint16_t* block_stage;     /* device: stage of blocks [8 i, 8 i + 8)                                */
+    uint32_t* counters;              /* device, 16-byte aligned, n_counters + 8 words rounded up to 16 bytes, zeroed by the launch:
+                                        the counters, then [n_counters] timeout flag (stage + 1 of a wait that gave up),
+                                        [+1] tiles that found a producer unfinished, [+2] the longest wait in polls */
+    int32_t n_stages, n_blocks, n_counters;
+    int32_t set;                     /* 0: GATED / STORE bodies (forward), 1: DFG / STORE bodies (backward)    */
+    int32_t n_ops;                   /* stage ops that follow this op in the plan                              */
+    int32_t spin_max;                /* polls before a wait gives up (0: default 1 << 18)                      */
+    int32_t flags;                   /* measurement aids, 0 in the product: 1 = consumers skip the agent-scope acquire */
+    int32_t pad_;
+} aew_nt_chain_t;
+
+/* Host logic only.  descs[0..n): the stage descriptors in execution order.  Fills stages_out[n] (host memory; `g` copied
+ * in), block_stage_out[cap_blocks / 8] and *n_blocks / *n_counters / *set.  force != 0: chain also launches the stand-alone
+ * launcher would run on its small-launch shapes (tests).  Returns 0, AEW_E_UNSUP if the run cannot be chained (a
+ * descriptor outside the default bf16 shapes, a dependency the builder cannot express, a buffer reused inside the run),
+ * AEW_E_ARG on malformed input. */
+int aew_nt_chain_build(const aew_gemm_nt_t* descs, int n, aew_nt_stage_t* stages_out, uint16_t* block_stage_out,
+                       int cap_blocks, int* n_blocks, int* n_counters, int* set, int force);
+/* Producer row tiles consumer tile (first row m0 of the 256-row tile) of `stage` waits for through dependency `dep`:
+ * [*t_lo, *t_hi] (empty if *t_lo > *t_hi).  The kernel uses the same arithmetic; exported for tests. */
+int aew_nt_chain_dep_tiles(const aew_nt_stage_t* stage, int dep, int m0, int* t_lo, int* t_hi);
+
+/* ---------------------------------------------------------------------------------------
  * plan
  * ------------------------------------------------------------------------------------- */
 enum {
@@ -479,7 +549,7 @@ enum {
     AEW_OP_VQ_EMA, AEW_OP_VQ_BWD, AEW_OP_LC_GATHER, AEW_OP_LC_SCATTER, AEW_OP_SPK_BIAS,
     AEW_OP_SPK_BWD, AEW_OP_BASE_GATHER, AEW_OP_SOFTMAX_NLL, AEW_OP_COLSUM, AEW_OP_REDUCE,
     AEW_OP_ADAM, AEW_OP_ZERO, AEW_OP_VAE, AEW_OP_AE_NORM, AEW_OP_JITTER, AEW_OP_VQ_DIAG, AEW_OP_MFCC,
-    AEW_OP_MOMENTS, AEW_OP_GEMM_TN_GROUP
+    AEW_OP_MOMENTS, AEW_OP_GEMM_TN_GROUP, AEW_OP_NT_CHAIN
 };
 
 /* Lanes.  A plan is a sequential program; `lane` lets the caller mark ops that are OFF the
@@ -504,14 +574,14 @@ typedef struct {
         aew_lc_scatter_t lcs; aew_spk_bias_t spk; aew_spk_bwd_t spkb; aew_base_gather_t base;
         aew_softmax_nll_t sm; aew_colsum_t cs; aew_reduce_t red; aew_adam_t adam; aew_zero_t zero;
         aew_vae_t vae; aew_ae_norm_t aen; aew_jitter_t jit; aew_vq_diag_t diag; aew_mfcc_t mfcc;
-        aew_moments_t mom; aew_gemm_tn_group_t tng;
+        aew_moments_t mom; aew_gemm_tn_group_t tng; aew_nt_chain_t chain;
     } u;
 } aew_op_t;
 
 /* Library / build identification. */
 int aew_abi_version(void);
 /* sizeof(aew_op_t) etc. so the binding can verify its struct mirrors. */
-int aew_sizeof(int which);      /* 0 op, 1 gemm_nt, 2 gemm_tn, 3 seg, 4 view, 5 copy_rec, 6 actor, 7 sampler */
+int aew_sizeof(int which);      /* 0 op, 1 gemm_nt, 2 gemm_tn, 3 seg, 4 view, 5 copy_rec, 6 actor, 7 sampler, 8 tuning, 9 nt_stage, 10 nt_chain */
 
 /* Execute ops[0..n) in order on `stream` (a hipStream_t).  Returns at the first error and
  * writes the failing index to *fail_index if non-NULL. */
@@ -525,7 +595,9 @@ int aew_graph_destroy(void* exec);
 
 /* Per-op timing: while enabled, aew_run_plan brackets every op with HIP events on `stream`;
  * aew_timing_read synchronises the stream and returns elapsed ms per executed op (in
- * execution order since the last enable) and its tag. */
+ * execution order since the last enable) and its tag.  aew_timing_enable(1): every op is its own launch (the stage ops of
+ * an AEW_OP_NT_CHAIN run one by one, the chain op itself is an empty interval); (2): a chain runs as the ONE launch it
+ * is in the untimed plan and carries the time, its stage ops are empty intervals.  One interval per op either way. */
 /* =======================================================================================
  * Tuning context (ABI 17).  Every aew_set_* switch below edits ONE process-wide instance of this record; a caller that
  * wants its own settings - two engines with different shapes in one process, an A/B that must not leak - passes a record
@@ -559,13 +631,19 @@ typedef struct {
     int32_t lanes;
     int32_t tn_cursor_epoch;     /* ABI 18: aew_set_tn_cursor */
     int32_t tn_cursor_slack;
-    int32_t reserved_[8];
+    int32_t nt_chain;            /* ABI 19: 1 (default) AEW_OP_NT_CHAIN ops launch their chain, 0 their stage ops run one by one */
+    int32_t reserved_[7];
 } aew_tuning_t;
 int aew_tuning_default(aew_tuning_t* out);
 int aew_tuning_get(aew_tuning_t* out);
 int aew_tuning_set(const aew_tuning_t* in);          /* replaces the process-wide instance (values are clamped like the setters') */
 int aew_run_plan_tuned(const aew_op_t* ops, int n, void* stream, int* fail_index, const aew_tuning_t* tuning);
 int aew_graph_capture_tuned(const aew_op_t* ops, int n, void** exec_out, int* fail_index, const aew_tuning_t* tuning);
+
+/* Box fingerprint (measurement aid): sustained rate of THIS device on a pure bf16 MFMA loop (out[0], TFLOP/s) and on a
+ * device-to-device copy of copy_bytes (out[1], TB/s read + written), HIP events on `stream`.  scratch: device memory,
+ * 16-byte aligned, >= 2 * copy_bytes (>= 1 MiB each; contents are overwritten).  Synchronises the stream. */
+int aew_probe_box(void* scratch, int64_t scratch_bytes, int64_t copy_bytes, void* stream, float* out);
 
 int aew_timing_enable(int on);
 int aew_timing_read(float* ms, int32_t* tags, int capacity, int* count);

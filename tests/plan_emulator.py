@@ -170,6 +170,9 @@ class Emu:
             o = ooff + sl * t.out_batch_stride
             out[o:o + t.N_pad * t.K_total] += dW.reshape(-1)
 
+    def op_25(self, p):  # NT_CHAIN: the stage ops that follow it in the plan are the chain (aewavenet.h) - they run one by one
+        pass
+
     def op_24(self, p):  # GEMM_TN_GROUP: every descriptor contracted over all rows of all batch elements, one result
         rt, roff = self.flat(p.descs)
         nbytes = p.n_descs * C.sizeof(L.GemmTN)
