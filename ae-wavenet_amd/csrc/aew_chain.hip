@@ -344,9 +344,11 @@ static int launch_nt_chain(const aew_nt_chain_t& c, hipStream_t st) {
         return AEW_E_ARG;
     // counters + [n_counters] timeout flag, [+1] tiles that waited, [+2] longest wait in polls: zeroed by a kernel of this
     // library in front of every launch (the caller's buffer holds n_counters + 8 words, rounded up to 16 bytes)
-    const aew_zero_t z = {c.counters, (int64_t)(((size_t)c.n_counters + 8 + 3) / 4 * 16)};
-    const int zr = launch_zero(z, st);
-    if (zr) return zr;
+    if (!(c.flags & 2)) {                                  // (flags & 2: the caller's plan clears them - one op for all its chains)
+        const aew_zero_t z = {c.counters, (int64_t)(((size_t)c.n_counters + 8 + 3) / 4 * 16)};
+        const int zr = launch_zero(z, st);
+        if (zr) return zr;
+    }
     const int spin = c.spin_max > 0 ? c.spin_max : (1 << 18);
     if (c.set == 0)
         hipLaunchKernelGGL((k_nt_chain<0>), dim3(c.n_blocks), dim3(CHAIN_THREADS), CHAIN_LDS_BYTES, st, c.stages, c.block_stage,

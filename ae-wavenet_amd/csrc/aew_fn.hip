@@ -644,14 +644,17 @@ int g_fn_enable_flag() { return AEW_T().fn_enable; }
 
 template <int NTW, int EPI, int NTW2, int NST = 2, int MTCAP = 0>
 static int fn_launch(const aew_gemm_nt_t& g, hipStream_t st) {
-    static int attr_done = 0;
+    static std::atomic<unsigned long long> attr_done{0};          // one bit per device (function attributes are per device)
     constexpr int lds = fn_lds_bytes<NTW, EPI, NTW2, NST, MTCAP>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!attr_done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {      // (racing threads both set it: harmless)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fn<NTW, EPI, NTW2, NST, MTCAP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = 1;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     const FnSched s = fn_sched(g.M, g.batch);
     hipLaunchKernelGGL((k_fn<NTW, EPI, NTW2, NST, MTCAP>), dim3(s.n_chunks), dim3(FN_THREADS), lds, st, g);

@@ -240,17 +240,26 @@ extern "C" int aew_tuning_set(const aew_tuning_t* in) {
     g_tune = t;
     return 0;
 }
+// The split-K plan of a TN op (slabs, rows per split, batch fold) is fixed when a PLAN IS BUILT: aew_tn_slabs() sizes the slab
+// buffers and the unpack tables under the process-wide record.  A caller's per-call record must therefore not change it at
+// launch time - more slabs than allocated would be written out of bounds, fewer would leave stale ones in the sum - so the
+// fields that feed tn_plan() always come from the process-wide record.
+static void tune_pin_tn_plan(aew_tuning_t& t) {
+    t.tn_fold_rows = g_tune.tn_fold_rows; t.tn_target_blocks = g_tune.tn_target_blocks;
+    t.tn_small_tiles = g_tune.tn_small_tiles; t.tn_small_target = g_tune.tn_small_target;
+    t.tn_big = g_tune.tn_big; t.tn_big_target = g_tune.tn_big_target;
+}
 extern "C" int aew_run_plan_tuned(const aew_op_t* ops, int n, void* stream, int* fail_index, const aew_tuning_t* tuning) {
     if (!ops || n < 0) return AEW_E_ARG;
     aew_tuning_t t;
-    if (tuning) { t = *tuning; tune_clamp(t); }
+    if (tuning) { t = *tuning; tune_clamp(t); tune_pin_tn_plan(t); }
     TuneScope scope(tuning ? &t : nullptr);
     return run_ops(ops, n, (hipStream_t)stream, fail_index, g_timing);
 }
 extern "C" int aew_graph_capture(const aew_op_t* ops, int n, void** exec_out, int* fail_index);
 extern "C" int aew_graph_capture_tuned(const aew_op_t* ops, int n, void** exec_out, int* fail_index, const aew_tuning_t* tuning) {
     aew_tuning_t t;
-    if (tuning) { t = *tuning; tune_clamp(t); }
+    if (tuning) { t = *tuning; tune_clamp(t); tune_pin_tn_plan(t); }
     TuneScope scope(tuning ? &t : nullptr);
     return aew_graph_capture(ops, n, exec_out, fail_index);
 }

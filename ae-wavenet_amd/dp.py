@@ -244,10 +244,19 @@ class DataParallel:
                 keep.append((tag, w))
         self._pending = keep
 
+    @staticmethod
+    def _late(eng) -> bool:
+        """May the decoder's parameter all-gather stay in flight under the first forward plan?  Only if that plan reads no
+        decoder parameter: the engine packs the decoder's layouts at the head of fwd_b (pack_dec_late, no merged pack) and
+        there IS a head region.  ONE predicate for optimizer_step (issue order) and forward (wait points).  Engine-level
+        readers of the parameters between steps (eng.conditioning(), eng.encode(), tools) must call finish() first - the
+        module surface does."""
+        return eng.dec_grad_offset > 0 and bool(getattr(eng, "pack_dec_late", False)) and not getattr(eng, "merge_packs", False)
+
     def forward(self, eng):
         """The forward of a sharded step: the encoder part starts as soon as ITS parameters are complete, the decoder's
         all-gather is waited for between the two forward plans."""
-        late = bool(getattr(eng, "pack_dec_late", False)) and not getattr(eng, "merge_packs", False)
+        late = self._late(eng)
         self.finish("head" if late else None)
         return eng.forward(self.allreduce_ema_async, before_decoder=self.finish if late else None)
 
@@ -283,7 +292,7 @@ class DataParallel:
         # late: the next forward waits for the head's parameters first and for the decoder's only between its two plans
         # (forward()); collectives complete in issue order, so the head's all-gather goes out first and the decoder's
         # right behind it.  Otherwise the decoder's all-gather is issued at once and runs under the head's Adam.
-        late = lo > 0 and bool(getattr(eng, "pack_dec_late", False)) and not getattr(eng, "merge_packs", False)
+        late = self._late(eng)
         dec_gathers = [] if late else None
         if "dec_hi" in st:                               # the upper layers' region: reduced under the rest of the chain
             for w in st["dec_hi"][0]:

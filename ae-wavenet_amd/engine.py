@@ -702,6 +702,9 @@ class DecoderPlan:
         # `hi_first_layer`) is then final right after "unpack grads (decoder, upper layers)": a data-parallel caller
         # starts its reduce-scatter there, under the second half of the chain (TrainEngine.bwd_a1 / bwd_a2).
         multi = grouped and self.wgrad_group < NL
+        if multi and self.wgrad_split_layers > 0:
+            # (the upper-layers spk_bwd differences RUNNING column sums; layers kept as split-K ops deliver per-batch sums)
+            raise ValueError("wgrad_split_layers > 0 cannot be combined with several grouped weight-gradient launches (wgrad_group < layers)")
         self.hi_first_layer = NL - self.wgrad_group if (multi and early_tbl is not None and snap_ok) else None
         self._spk_hi_from = None
         layers_in_grp = 0

@@ -39,7 +39,10 @@ class TrainEngine:
     DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
     LANE_PACK_DEC = 1         # side lane of the decoder's forward-layout weight pack (joined by the end of fwd_a) ...
     pack_dec_late = True      # the decoder's weight pack at the head of fwd_b instead of fwd_a (see build: data-parallel overlap)
-    merge_packs = False       # True: all weight-layout packs of a step as one copy-table launch at the head of fwd_a
+    merge_packs = None        # True: all weight-layout packs of a step as ONE copy-table launch at the head of fwd_a (three launches
+                              # fewer: 6.837 -> 6.802 ms per step interleaved, r05).  None = on unless the process is a rank of a
+                              # data-parallel group: there the decoder's pack stays at the head of fwd_b (pack_dec_late), so that
+                              # the decoder's parameter all-gather can run under the encoder forward (dp.DataParallel.forward)
     graph_lanes = 2           # lane mode of graph captures when the process-wide mode is 0 (aew_set_lanes): 2 = lanes 4 / 5 are
                               # branches, everything else in plan order.  Eager runs stay serial (one cross-stream edge costs
                               # more there than the branch returns: 7.27 vs 6.90 ms per step).  0: never
@@ -56,6 +59,8 @@ class TrainEngine:
                               # 4.085 -> 4.134 ms): a dz stage is 320-448 tiles - fewer than the 512 resident slots - so its
                               # consumers (dx) are resident before it has finished and 11 000 of the launch's 20 432 tiles spin
                               # on a counter, where the forward's stages (640-896 tiles) leave 900 of 27 856 waiting.  Option
+    nt_chain_bwd_phase = 0    # with nt_chain_bwd = 2: 0 pairs (dz.l, dx.l); 1 pairs (dx.l, dz.l-1) - the dependency whose producer stage is
+                              # larger than the 512 resident tiles, so that its consumers find it finished
     nt_chain_force = False    # tests: chain also the sizes the stand-alone launcher runs on its small-launch shapes
     nt_chain_flags = 0        # aew_nt_chain_t.flags (measurement aids)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
@@ -80,6 +85,9 @@ class TrainEngine:
                 else DecoderPlan.wgrad_group
         self.wgrad_group = int(wgrad_group)
         self.tuning = tuning              # _lib.Tuning (aew_tuning_t) for this engine's launches, or None
+        if self.merge_packs is None:
+            import torch.distributed as _dist
+            self.merge_packs = not (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1)
         self.kind = hps.global_model
         self.bn_type = hps.bn_type if self.kind == "autoencoder" else "none"
         self.loss_mode, self.take_compat = loss_mode, take_compat
@@ -375,7 +383,8 @@ class TrainEngine:
             nll_scale = 0.0
         self.dec.build_backward(bw, nll_scale)
         if self.nt_chain_bwd_used >= 2:
-            insert_nt_chains(bw, ws, "chain.bwd", lambda lab: lab.startswith(("d.post2", "d.post1", "dz.", "dx.")),
+            heads = ("d.post2", "d.post1")[int(self.nt_chain_bwd_phase):]    # (phase 1: pairs are (dx.l, dz.l-1), not (dz.l, dx.l))
+            insert_nt_chains(bw, ws, "chain.bwd", lambda lab: lab.startswith(heads + ("dz.", "dx.")),
                              max_len=self.nt_chain_bwd_used, **ckw)
         # gradient statistics of run() (autoencoder_model.py:252-257 mel_grad_sd / bn_grad_sd; mfcc_inverter.py:100-106
         # mel_grad_sd / mel_grad_mean): by-products of this backward, reduced on a side lane as soon as their input is

@@ -346,16 +346,18 @@ class TnGroupBuilder:
 
 def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: int = 0, force: bool = False,
                      spin_max: int = 0, flags: int = 0) -> List[Tuple[int, int]]:
-    """Chained NT launches (AEW_OP_NT_CHAIN, aewavenet.h): runs of consecutive bf16 NT ops of `plan` whose label passes
-    `select` - same lane, no join except at the head of the run - get a chain op in front of them that launches the
-    whole run as ONE kernel with tile-granular hand-off between the stages (wavenet.py:354-357: the layer loop; its
-    backward).  The stage ops stay in the plan: per-op timing, the CPU plan interpreter and aew_tuning_t.nt_chain = 0
-    execute them one by one, with the same result bit for bit.  max_len: stages per launch (0 = the whole run; 2 = the
-    G1 + G2 / dz + dx pair of a layer).  Runs the host-side builder (aew_nt_chain_build) refuses - shapes outside the
-    default kernels, dependencies it cannot express - stay as they are.  Returns [(index of the chain op, stages)]."""
+    """Chained NT launches (AEW_OP_NT_CHAIN, aewavenet.h): runs of consecutive main-lane bf16 NT ops of `plan` whose label
+    passes `select` - no join except at the head of the run - get a chain op in front of them that launches the whole
+    run as ONE kernel with tile-granular hand-off between the stages (wavenet.py:354-357: the layer loop; its backward).
+    The stage ops stay in the plan: per-op timing, the CPU plan interpreter and aew_tuning_t.nt_chain = 0 execute them
+    one by one, with the same result bit for bit.  max_len: stages per launch (0 = the whole run; 2 = pairs).  Runs the
+    host-side builder (aew_nt_chain_build) refuses - shapes outside the default kernels, dependencies it cannot express
+    - stay as they are.  The counters of all chains of one call share ONE buffer that a single zero op in front of the
+    first chain clears (the chain launches then skip their own clearing: aew_nt_chain_t.flags & 2).
+    Returns [(index of the chain op, stages)]."""
     lib = L.load()
-    out: List[Tuple[int, int]] = []
-    i, k = 0, 0
+    made = []                                              # (first stage index in the ORIGINAL plan, n, stages, bmap, nb, nc, set)
+    i = 0
     while i < len(plan.ops):
         op = plan.ops[i]
         if not (op.kind == L.OP_GEMM_NT and op.lane == 0 and select(plan.labels[i])):   # (main lane only: side-lane chains -
@@ -366,42 +368,57 @@ def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: in
                 plan.ops[j].lane == op.lane and plan.ops[j].join == 0 and (max_len <= 0 or j - i < max_len):
             j += 1
         n = j - i
-        if n < 2:
-            i = j
-            continue
-        descs = (L.GemmNT * n)(*[plan.ops[q].u.nt for q in range(i, j)])
-        stages = (L.NtStage * n)()
-        cap = sum(((-(-d.M // 256) * d.batch + 7) // 8) * 8 * (d.N_pad // 128) for d in descs)
-        bmap = (C.c_uint16 * (cap // 8))()
-        nb, nc, st = C.c_int(0), C.c_int(0), C.c_int(0)
-        rc = lib.aew_nt_chain_build(C.byref(descs), n, C.byref(stages), C.byref(bmap), cap, C.byref(nb), C.byref(nc), C.byref(st),
-                                    int(force))
-        if rc == L.E_UNSUP:
-            i = j
-            continue
-        L.check(rc, f"aew_nt_chain_build ({plan.labels[i]} .. {plan.labels[j - 1]})")
+        if n >= 2:
+            descs = (L.GemmNT * n)(*[plan.ops[q].u.nt for q in range(i, j)])
+            stages = (L.NtStage * n)()
+            cap = sum(((-(-d.M // 256) * d.batch + 7) // 8) * 8 * (d.N_pad // 128) for d in descs)
+            bmap = (C.c_uint16 * (cap // 8))()
+            nb, nc, st = C.c_int(0), C.c_int(0), C.c_int(0)
+            rc = lib.aew_nt_chain_build(C.byref(descs), n, C.byref(stages), C.byref(bmap), cap, C.byref(nb), C.byref(nc),
+                                        C.byref(st), int(force))
+            if rc != L.E_UNSUP:
+                L.check(rc, f"aew_nt_chain_build ({plan.labels[i]} .. {plan.labels[j - 1]})")
+                made.append((i, n, stages, bmap, nb.value, nc.value, st.value))
+        i = j
+    if not made:
+        return []
+    # one counter buffer: per chain its counters + 8 words (timeout flag, wait statistics), 16-byte aligned slices
+    sizes = [((m[5] + 8 + 3) // 4) * 4 for m in made]
+    cd = ws.alloc(f"{name}.counters", sum(sizes), torch.int32, zero=True)
+    out: List[Tuple[int, int]] = []
+    if not hasattr(plan, "nt_chains"):
+        plan.nt_chains = {}
+    shift, off = 0, 0
+    z = L.Zero()
+    z.ptr, z.bytes = cd.data_ptr(), 4 * sum(sizes)
+    zop = L.Op()
+    zop.kind, zop.tag, zop.lane, zop.join = L.OP_ZERO, 0, 0, 0
+    zop.u.zero = z
+    plan.ops.insert(made[0][0], zop)
+    plan.labels.insert(made[0][0], f"zero:{name}.counters")
+    shift += 1
+    for k, (i0, n, stages, bmap, nb, nc, st) in enumerate(made):
+        i = i0 + shift
         raw = bytes(stages)
         sd = ws.alloc(f"{name}.{k}.stages", (len(raw) + 7) // 8, torch.int64, zero=True)
         sd[:(len(raw) + 7) // 8].copy_(torch.frombuffer(bytearray(raw + b"\0" * (-len(raw) % 8)), dtype=torch.int64))
         md = ws.alloc(f"{name}.{k}.map", len(bmap), torch.int16, zero=True)
         md[:len(bmap)].copy_(torch.frombuffer(bytearray(bytes(bmap)), dtype=torch.int16))
-        cd = ws.alloc(f"{name}.{k}.counters", nc.value + 16, torch.int32, zero=True)
         ch = L.NtChain()
-        ch.stages, ch.block_stage, ch.counters = sd.data_ptr(), md.data_ptr(), cd.data_ptr()
-        ch.n_stages, ch.n_blocks, ch.n_counters, ch.set, ch.n_ops, ch.spin_max = n, nb.value, nc.value, st.value, n, spin_max
-        ch.flags = flags
+        ch.stages, ch.block_stage, ch.counters = sd.data_ptr(), md.data_ptr(), cd.data_ptr() + 4 * off
+        ch.n_stages, ch.n_blocks, ch.n_counters, ch.set, ch.n_ops, ch.spin_max = n, nb, nc, st, n, spin_max
+        ch.flags = flags | 2
+        first = plan.ops[i]
         cop = L.Op()
-        cop.kind, cop.tag, cop.lane, cop.join = L.OP_NT_CHAIN, 0, op.lane, op.join
+        cop.kind, cop.tag, cop.lane, cop.join = L.OP_NT_CHAIN, 0, first.lane, first.join
         cop.u.chain = ch
         plan.ops.insert(i, cop)
-        plan.labels.insert(i, f"chain[{plan.labels[i]}..{plan.labels[j - 1]}]")
-        plan._arr = None
-        if not hasattr(plan, "nt_chains"):
-            plan.nt_chains = {}
-        plan.nt_chains[plan.labels[i]] = (list(stages), cd)      # host copy of the stage table + the counters (tests, tools)
+        plan.labels.insert(i, f"chain[{plan.labels[i]}..{plan.labels[i + n - 1]}]")
+        plan.nt_chains[plan.labels[i]] = (list(stages), cd[off:off + sizes[k]])   # host copy of the stage table + its counters
         out.append((i, n))
-        k += 1
-        i = j + 1
+        shift += 1
+        off += sizes[k]
+    plan._arr = None
     return out
 
 

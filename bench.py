@@ -128,7 +128,7 @@ def cpu_baseline(hps, eng, seconds_budget=75.0, full_batch=True):
     """The oracle (torch fp32 CPU restatement of the reference) as the best the CPU path does on this host, on a bounded
     sample of the same workload.  One training step = forward, the reference's diagnostic autograd.grad over (mel,
     encoding) (autoencoder_model.py:252-257: what its run() does), backward, Adam over all parameters
-    (chassis.py:151-171).  (1) one window of the batch, one timed step at each of {16, 32, 64, all} threads (after an
+    (chassis.py:151-171).  (1) one window of the batch, one timed step at each of {4, 8, 16, 32, 64, all} threads (after an
     untimed warm-up step); (2) one step on the FULL batch of 8 windows at the fastest thread count of (1) - batched
     convolutions use the cores better than one window does (the unmodified reference, 8 cores, B = 8: 1 570
     samples/s).  `value` is the fastest samples/s seen, `cores` the thread count that produced it; everything measured is
@@ -161,7 +161,7 @@ def cpu_baseline(hps, eng, seconds_budget=75.0, full_batch=True):
     one = batch(1)
     step(one, False)                                       # warm-up (allocator, thread pool, first touch of 95 MB of moments)
     sweep = []
-    cands = sorted({t for t in (16, 32, 64, n_all) if 1 <= t <= n_all})
+    cands = sorted({t for t in (4, 8, 16, 32, 64, n_all) if 1 <= t <= n_all})
     try:
         for t in cands:
             torch.set_num_threads(t)
@@ -660,8 +660,10 @@ def main():
             "value": samples / dt, "unit": "samples/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "VQ-VAE-EMA (arch.vqvae-ema shape: 2x10 gated layers, 368 res / 256 dil "
-                                   "/ 256 skip, K=4096 d=32) fwd+bwd+Adam",
+            "config": {"workload": ("VQ-VAE-EMA (arch.vqvae-ema shape: 2x10 gated layers, 368 res / 256 dil "
+                                    "/ 256 skip, K=4096 d=32) fwd+bwd+Adam") if args.arch == "vqvae-ema" else
+                                   f"SIDE MEASUREMENT, not the bench line: --arch {args.arch} fwd+bwd+Adam",
+                       "headline_config": args.arch == "vqvae-ema" and args.batch == 8 and args.n_win == 5000,
                        "timed_region": {"boundary": "AutoEncoder.run(device tensors) -> loss.backward() -> FusedAdam.step(), batches resident in HBM",
                                         "engine": "TrainEngine.forward / backward / adam_step on one resident batch"}[names[0]],
                        "global_batch": n_ranks * args.batch, "n_win_batch": args.n_win, "jitter_prob": args.jitter_prob,

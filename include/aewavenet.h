@@ -526,7 +526,9 @@ typedef struct {
     int32_t set;                     /* 0: GATED / STORE bodies (forward), 1: DFG / STORE bodies (backward)    */
     int32_t n_ops;                   /* stage ops that follow this op in the plan                              */
     int32_t spin_max;                /* polls before a wait gives up (0: default 1 << 18)                      */
-    int32_t flags;                   /* measurement aids, 0 in the product: 1 = consumers skip the agent-scope acquire */
+    int32_t flags;                   /* 1 = consumers skip the agent-scope acquire (measurement aid, never in the product);
+                                        2 = the caller zeroes `counters` itself before the launch (a plan with several chains:
+                                        one AEW_OP_ZERO for all of them) */
     int32_t pad_;
 } aew_nt_chain_t;
 
@@ -605,6 +607,10 @@ int aew_graph_destroy(void* exec);
  * a captured graph keeps the settings it was captured under).  aew_tuning_default fills in the library defaults,
  * aew_tuning_get the current process-wide values.  None of the fields changes a result beyond what the individual
  * switch documents (bit-identical shapes; the one-window kernel's summation order).
+ * The tn_* fields that decide a TN op's split-K plan (tn_fold_rows, tn_target_blocks, tn_small_tiles, tn_small_target,
+ * tn_big, tn_big_target) are read from the PROCESS-WIDE record also inside a *_tuned call: plan construction
+ * (aew_tn_slabs) sized the slab buffers under it, and a launch must write exactly those slabs.  Set them with
+ * aew_tuning_set / the aew_set_tn_* calls BEFORE building a plan.
  * ======================================================================================= */
 typedef struct {
     int32_t nt_wave_rows;

@@ -135,8 +135,8 @@ def test_chain_timeout_is_reported_not_hung():
     for op in sub.ops:
         op.join = 0
     made = PLN.insert_nt_chains(sub, eng.ws, "chain.stuck", lambda lab: True, force=True, spin_max=2000)
-    assert made == [(0, 4)]
-    stages, cd = sub.nt_chains[sub.labels[0]]
+    assert made == [(1, 4)] and sub.labels[0].startswith("zero:")      # (one zero op for the counters, then the chain)
+    stages, cd = sub.nt_chains[sub.labels[1]]
     # break the table on the device: stage 0 does not publish
     raw = eng.ws.get("chain.stuck.0.stages")
     host = (L.NtStage * 4).from_buffer_copy(bytes(raw[:(C.sizeof(L.NtStage) * 4 + 7) // 8].cpu().numpy().tobytes())[:C.sizeof(L.NtStage) * 4])
@@ -145,4 +145,4 @@ def test_chain_timeout_is_reported_not_hung():
     raw[:(len(b) + 7) // 8].copy_(torch.frombuffer(bytearray(b + b"\0" * (-len(b) % 8)), dtype=torch.int64))
     sub.run(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert PLN.chain_timeouts(sub) == [sub.labels[0]]
+    assert PLN.chain_timeouts(sub) == [sub.labels[1]]

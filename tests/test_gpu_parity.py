@@ -398,6 +398,41 @@ def test_gemm_tn(dtype, safe, Mc):
         assert err <= (2e-3 if dtype == BF else 2e-5) * scale, ("impl", impl, "safe", safe, err, scale)
 
 
+def test_tuned_record_cannot_change_a_built_split_k_plan():
+    """the slab buffers of a TN op are sized at plan build time under the process-wide record (aew_tn_slabs).  A
+    caller's per-call record (aew_run_plan_tuned) with other split-K fields must not make the launch write a different
+    number of slabs: those fields are pinned to the process-wide values, so the tuned run writes exactly the slabs the
+    untuned one does - bit for bit, guard region untouched."""
+    gen = torch.Generator().manual_seed(4)
+    B, Np, K1, Mc = 2, 256, 256, 5000
+    R0 = Mc + 8
+    ws = Workspace(DEV)
+    for n, cols in (("G", Np), ("A1", K1)):
+        ws.alloc(n, B * R0 * cols, torch.bfloat16)
+        ws.get(n)[:B * R0 * cols].copy_(torch.randn(B * R0 * cols, generator=gen).to(torch.bfloat16))
+    Gm, A1 = Mat(ws, "G", B, R0, Np, BF), Mat(ws, "A1", B, R0, K1, BF)
+    t = make_tn(BF, Mc, B, Np, Np, Gm.seg(Np), [A1.seg(K1)])
+    slabs = L.tn_slabs(t)
+    assert slabs > B                                       # a split-K plan (not the folded single slab)
+    n_out = slabs * Np * t.K_total
+    guard = 4 * Np * t.K_total
+    out = ws.alloc("out", n_out + guard, torch.float32)
+    t.out, t.out_batch_stride = out.data_ptr(), Np * t.K_total
+    p = Plan("tn")
+    p.add(L.OP_GEMM_TN, t, "tn")
+    res = []
+    for over in (None, dict(tn_target_blocks=4 * 512, tn_fold_rows=1 << 20), dict(tn_target_blocks=8, tn_small_tiles=64, tn_small_target=8),
+                 dict(tn_big=1, tn_big_target=64)):
+        out.fill_(-7.0)
+        p.run(stream(), tuning=L.default_tuning(**over) if over else None)
+        torch.cuda.synchronize()
+        assert bool((out[n_out:n_out + guard] == -7.0).all()), over        # nothing beyond the planned slabs
+        assert bool((out[:n_out] != -7.0).all()), over                     # every planned slab written
+        res.append(out[:n_out].clone())
+    for r in res[1:]:
+        assert torch.equal(r, res[0])
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 def test_gemm_tn_group(tile):
     """AEW_OP_GEMM_TN_GROUP: several weight-gradient descriptors in one launch, each output tile contracted over all

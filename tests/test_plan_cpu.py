@@ -401,12 +401,14 @@ def test_split_grouped_descriptor_keeps_its_bias_gradient(monkeypatch):
     assert float(grads[64]["wavenet.lc_conv.bias"].abs().max()) > 0
 
 
-def test_first_forward_plan_reads_no_decoder_parameter(golden_dir):
+def test_first_forward_plan_reads_no_decoder_parameter(golden_dir, monkeypatch):
     """TrainEngine.pack_dec_late: the decoder's weight layouts are packed at the head of fwd_b, and nothing in fwd_a - op
     descriptors or the records of its pack tables - points into the decoder's region of the flat parameter buffer.  That is
     what lets a data-parallel step keep the decoder's parameter all-gather in flight under the encoder forward
-    (dp.DataParallel.forward)."""
+    (dp.DataParallel.forward).  (A data-parallel rank's form of the plans: merge_packs off - a lone process packs every
+    layout in one launch at the head of fwd_a instead.)"""
     import ctypes as C
+    monkeypatch.setattr(M.TrainEngine, "merge_packs", False)
     z = load(golden_dir, "ae_tiny_vqvae-ema_random.npz")
     hps, eng = make_engine(z, "autoencoder", None)
     base, lo, n = eng.ps.params.data_ptr(), eng.dec_grad_offset, eng.ps.numel

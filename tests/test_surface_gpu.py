@@ -104,6 +104,19 @@ def test_upstream_gradient_reaches_every_grad(bn):
     want = 3.0 * g1
     want[o:o + k] = 2.0 * g1[o:o + k]
     assert first.grad is not None and torch.allclose(g3, want, rtol=3e-4, atol=2e-7 * float(g1.abs().max()))
+    # FusedAdam.zero_grad(set_to_none=False): .grad reads as zeros at once (torch's contract), and the next backward starts
+    # from them; the default (set_to_none=True) detaches the views instead
+    from ae_wavenet_amd import optim
+    opt = optim.FusedAdam(m, lr=1e-4)
+    opt.zero_grad(set_to_none=False)
+    torch.cuda.synchronize()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in m.parameters())
+    _, _, loss = m.run(*batch, eps=eps)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(m._engine.ps.grads[:n], g1, rtol=2e-4, atol=1e-7 * float(g1.abs().max()))
+    opt.zero_grad()
+    assert all(p.grad is None for p in m.parameters())
 
 
 @pytest.mark.parametrize("kind", ["vqvae-ema", "vae", "mfcc"])
