@@ -61,6 +61,10 @@ class TrainEngine:
                               # on a counter, where the forward's stages (640-896 tiles) leave 900 of 27 856 waiting.  Option
     nt_chain_bwd_phase = 0    # with nt_chain_bwd = 2: 0 pairs (dz.l, dx.l); 1 pairs (dx.l, dz.l-1) - the dependency whose producer stage is
                               # larger than the 512 resident tiles, so that its consumers find it finished
+    nt_chain_max_stage_tiles = 2048   # runs whose stages average more tiles than this (four waves of the 512 resident slots) stay
+                              # stand-alone launches: the deep decoder (30 x 512, 64k windows: 8 224 tiles per gated stage) loses
+                              # 1 % to chaining (62.9 vs 62.2 ms per step) - nothing to gain at 16 tile waves per launch, and the
+                              # hand-off (write-through stores, one acquire per tile) is not free.  0 = no limit
     nt_chain_force = False    # tests: chain also the sizes the stand-alone launcher runs on its small-launch shapes
     nt_chain_flags = 0        # aew_nt_chain_t.flags (measurement aids)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
@@ -345,7 +349,7 @@ class TrainEngine:
             n_f, n_b = v[0], (v[1] if len(v) > 1 else 0)
         self.nt_chain_used = n_f if impl == 0 else 0
         self.nt_chain_bwd_used = n_b if impl == 0 else 0
-        ckw = dict(force=bool(self.nt_chain_force), flags=int(self.nt_chain_flags))
+        ckw = dict(force=bool(self.nt_chain_force), flags=int(self.nt_chain_flags), max_stage_tiles=int(self.nt_chain_max_stage_tiles))
         if self.nt_chain_used >= 2:
             insert_nt_chains(fb, ws, "chain.fwd", lambda lab: lab.startswith(("G1.", "G2.", "post1", "post2")), max_len=self.nt_chain_used, **ckw)
         red = L.Reduce()

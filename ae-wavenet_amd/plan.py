@@ -345,7 +345,7 @@ class TnGroupBuilder:
 
 
 def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: int = 0, force: bool = False,
-                     spin_max: int = 0, flags: int = 0) -> List[Tuple[int, int]]:
+                     spin_max: int = 0, flags: int = 0, max_stage_tiles: int = 0) -> List[Tuple[int, int]]:
     """Chained NT launches (AEW_OP_NT_CHAIN, aewavenet.h): runs of consecutive main-lane bf16 NT ops of `plan` whose label
     passes `select` - no join except at the head of the run - get a chain op in front of them that launches the whole
     run as ONE kernel with tile-granular hand-off between the stages (wavenet.py:354-357: the layer loop; its backward).
@@ -354,6 +354,7 @@ def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: in
     host-side builder (aew_nt_chain_build) refuses - shapes outside the default kernels, dependencies it cannot express
     - stay as they are.  The counters of all chains of one call share ONE buffer that a single zero op in front of the
     first chain clears (the chain launches then skip their own clearing: aew_nt_chain_t.flags & 2).
+    max_stage_tiles > 0: runs whose stages average more 256 x 128 tiles than this stay unchained.
     Returns [(index of the chain op, stages)]."""
     lib = L.load()
     made = []                                              # (first stage index in the ORIGINAL plan, n, stages, bmap, nb, nc, set)
@@ -368,6 +369,12 @@ def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: in
                 plan.ops[j].lane == op.lane and plan.ops[j].join == 0 and (max_len <= 0 or j - i < max_len):
             j += 1
         n = j - i
+        if n >= 2 and max_stage_tiles > 0:
+            # a run whose stages are many tile waves each gains nothing from chaining (the fill / drain of a launch is a few
+            # us against hundreds) and pays the hand-off: left as stand-alone launches
+            tiles = sum(-(-plan.ops[q].u.nt.M // 256) * plan.ops[q].u.nt.batch * (plan.ops[q].u.nt.N_pad // 128) for q in range(i, j))
+            if tiles > max_stage_tiles * n:
+                n = 0
         if n >= 2:
             descs = (L.GemmNT * n)(*[plan.ops[q].u.nt for q in range(i, j)])
             stages = (L.NtStage * n)()

@@ -535,6 +535,11 @@ def main():
             return byk
 
         ms2, tags2 = timing_pass(2)
+        from ae_wavenet_amd import plan as _PLN
+        torch.cuda.synchronize()                                 # (read before the serial pass: its zero op clears them)
+        chain_waits = {pl.name: {lab: dict(zip(("timeout_flag", "tiles_that_waited", "longest_wait_polls"), v))
+                                 for lab, v in _PLN.chain_stats(pl).items()} for pl in (eng.fwd_b, eng.bwd)
+                       if getattr(pl, "nt_chains", None)}
         ms1, tags1 = timing_pass(1)
         cls_ms, cls_n = {}, {}
         for i in range(len(ms2)):
@@ -626,10 +631,7 @@ def main():
         if roof["traffic"]:
             tbps = roof["traffic"] / (nt_ms / n_launch * 1e-3) / 1e12
             roof["hbm_view"] = {"achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
-        from ae_wavenet_amd import plan as _PLN
-        roof["chain_waits"] = {pl.name: {lab: dict(zip(("timeout_flag", "tiles_that_waited", "longest_wait_polls"), v))
-                                         for lab, v in _PLN.chain_stats(pl).items()} for pl in (eng.fwd_b, eng.bwd)
-                               if getattr(pl, "nt_chains", None)}
+        roof["chain_waits"] = chain_waits
         return roof, kern
 
     roof, kern = None, {}

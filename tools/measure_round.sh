@@ -10,6 +10,8 @@ cd $R
 python bench.py --steps 30 --warmup 5 --per-op $O/per_op_ms.txt > $O/bench.json 2> $O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 0 > $O/stats.log 2>&1
+# the same with every GEMM as its own launch (chained launches off): the per-kernel durations of rounds 1-4, for continuity
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_serial -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 0 --nt-chain 0 > $O/stats_serial.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --lanes 0 > $O/pmc_sq.log 2>&1
@@ -18,6 +20,8 @@ import csv, glob, collections, shutil
 O = "$O"
 st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
 if st: shutil.copy(st[0], O + "/kernel_stats.csv")
+st = glob.glob(O + "/stats_serial/**/*kernel_stats.csv", recursive=True)
+if st: shutil.copy(st[0], O + "/kernel_stats_serial.csv")
 def pmc(d, name):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True):
