@@ -13,8 +13,9 @@
 //     WRITE-THROUGH (sc1, store16_wt) - have drained (`s_waitcnt vmcnt(0)` in every wave, workgroup barrier, one
 //     device-scope atomic);
 //   * a consumer tile polls the counters it needs with one wave (one lane per counter, relaxed device-scope loads,
-//     s_sleep between polls, bounded), then ONE agent-scope acquire (its CU's L1 may hold nothing older than that),
-//     a workgroup barrier, and the unchanged kernel body with plain loads.
+//     s_sleep between polls, bounded), a workgroup barrier, and the kernel body - which, as a stage of a chain, reads its
+//     activation pieces (LDS-DMA) and epilogue operands DEVICE-SCOPE (sc1: never from the CU's L1), the form that stands
+//     in for an agent-scope acquire when the producer stored sc1 (the acquire itself: +0.05 ms per step, flags & 4).
 //
 // This is the guide's publish / consume recipe (cdna_hip_programming.md Guideline 16, form R1): nothing depends on
 // which XCD a workgroup lands on.  What the bounded spin relies on is that workgroups are dispatched in index order:
@@ -90,7 +91,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 4) void k_nt_chain(const aew_nt_stag
                     __hip_atomic_fetch_add(counters + n_counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_max(counters + n_counters + 2, (unsigned)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (!(flags & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // No acquire fence: everything a stage reads that an earlier stage of this launch may have written - the
+                // activation pieces of the K loop and the epilogue's aux operands - is loaded device-scope (sc1: never from
+                // this CU's L1), and the producer stored it write-through and drained before raising the counter
+                // (Guideline 16: sc1 loads stand in for the acquire when the producer stored sc1).  flags & 4 adds the
+                // fence back (A/B: 0.05 ms per step over both directions).
+                if (flags & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
         __syncthreads();

@@ -165,6 +165,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(AEW_GLB_PTR(gsrc), AEW_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// glds16 with device-scope (sc1) reads: never served from this CU's L1 - the operand load of a chained launch's consumer
+// stage, whose producer stored the rows write-through (store16_wt) and raised its counter after they had drained
+// (cdna_hip_programming.md Guideline 16: sc1 loads may stand in for the acquire when the producer stored sc1).
+__device__ __forceinline__ void glds16_sc1(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(AEW_GLB_PTR(gsrc), AEW_LDS_PTR(lds_wave_base), 16, 0, 16);
+}
+template <bool SC1>
+__device__ __forceinline__ void glds16_x(const void* gsrc, void* lds_wave_base) {
+    if (SC1) glds16_sc1(gsrc, lds_wave_base);
+    else glds16(gsrc, lds_wave_base);
+}
+// 16-byte sc1 load through a raw buffer resource (compiler-tracked, unlike inline asm): base + off; an offset beyond the
+// resource's range (AEW_BUF_OOB) reads zeros - the masked rows of an epilogue operand need no zero page
+#define AEW_BUF_OOB 0xfffffff0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Same LDS-DMA as glds16 but opaque to the compiler.  Needed where the LDS tile is read back with
 // ds_read_b64_tr_b16: that builtin carries no alias information, so after a builtin LDS-DMA the
 // compiler inserts s_waitcnt vmcnt(0) in front of it, i.e. it drains the prefetch it was just given

@@ -297,12 +297,12 @@ __device__ __forceinline__ void nt_setup_w(const aew_gemm_nt_t& g, int n0, int w
     }
 }
 
-template <int MT, int NB, int BMV>
+template <int MT, int NB, int BMV, bool SC1X = false>       // SC1X: the activation pieces are read device-scope (chained stage)
 __device__ __forceinline__ void nt_issue_bf16(char* stage, int wave, NtPtrs<MT, NB, BMV>& P) {
 #pragma unroll
     for (int j = 0; j < NtCfg<MT, NB, BMV>::XP; ++j) {
         const int piece = wave * NtCfg<MT, NB, BMV>::XP + j;
-        glds16(P.x[j], stage + (piece < NtCfg<MT, NB, BMV>::NXP ? piece * 1024 : NtCfg<MT, NB, BMV>::PAD_OFF));
+        glds16_x<SC1X>(P.x[j], stage + (piece < NtCfg<MT, NB, BMV>::NXP ? piece * 1024 : NtCfg<MT, NB, BMV>::PAD_OFF));
         P.x[j] += P.xinc[j];
     }
 #pragma unroll
@@ -392,6 +392,7 @@ __device__ __forceinline__ void epi_dfg8_pf(const EpiUni& U, const EpiRow& R, in
 // clock, profiles/r02_notes.md).  Row j's pointer is then base + j * (16-row stride), and the
 // biases of the lane's 8 (GATED: 8 + 8) channels are registers.
 struct EpiViewCtx {
+    const char* base;            // the view's buffer (wave-uniform)
     char* p;                     // lane's pointer for j = 0, nullptr if the view is absent
     int row;                     // lane's view row for j = 0
     int64_t inc;                 // bytes per 16 GEMM rows           (wave-uniform)
@@ -406,6 +407,7 @@ __device__ __forceinline__ EpiViewCtx epi_view_ctx(const aew_view_t& vref, int b
     c.row = (int)row;
     char* q = reinterpret_cast<char*>(v.ptr) + ((int64_t)b * v.batch_stride + row * v.row_pitch) * es;
     c.p = v.ptr ? q : nullptr;
+    c.base = reinterpret_cast<const char*>(v.ptr);
     c.inc = (int64_t)16 * v.row_step * v.row_pitch * es;
     c.dstep = 16 * v.row_step;
     c.lo = (int)v.row_lo;
@@ -478,15 +480,23 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
     // it is used, else aux1; with both in use aux1 is loaded in step.  DFG prefetches both.
     const bool pf1 = need1 && (EPI == AEW_EPI_DFG || !need0);
     uint4 raw0[2 * MT], raw1[2 * MT];
+    // chained stage (WT): the aux operands may be rows an earlier stage of the SAME launch stored write-through (the residual
+    // addend x_l of G2, dx of the layer above in dx): device-scope loads, masked rows through an out-of-range offset
+    const __amdgpu_buffer_rsrc_t rs0 = buf_rsrc(WT ? ca0.base : nullptr), rs1 = buf_rsrc(WT ? ca1.base : nullptr);
+    auto aux_get = [&](const EpiViewCtx& c, const __amdgpu_buffer_rsrc_t& rs, int j, int n) -> uint4 {
+        const char* p = epi_view_row(c, j);
+        if (WT) return ld16_sc1(rs, p ? (uint32_t)(p - c.base) + (uint32_t)(n * 2) : AEW_BUF_OOB);
+        const char* z = reinterpret_cast<const char*>(aew_zero_region);
+        return *reinterpret_cast<const uint4*>((p ? p : z) + n * 2);
+    };
     auto aux_load = [&](int sidx) {
         const int j = sidx >> 1, u = sidx & 1;
-        const char* z = reinterpret_cast<const char*>(aew_zero_region);
         const int n = n0 + wn * 64 + u * 32 + 8 * fg;
         raw0[sidx] = make_uint4(0, 0, 0, 0);
         raw1[sidx] = make_uint4(0, 0, 0, 0);
-        if (need0) { const char* p0 = epi_view_row(ca0, j); raw0[sidx] = *reinterpret_cast<const uint4*>((p0 ? p0 : z) + n * 2); }
-        if (EPI == AEW_EPI_DFG) { const char* p1 = epi_view_row(ca1, j); raw1[sidx] = *reinterpret_cast<const uint4*>((p1 ? p1 : z) + n * 2); }
-        else if (pf1) { const char* p1 = epi_view_row(ca1, j); raw0[sidx] = *reinterpret_cast<const uint4*>((p1 ? p1 : z) + n * 2); }
+        if (need0) raw0[sidx] = aux_get(ca0, rs0, j, n);
+        if (EPI == AEW_EPI_DFG) raw1[sidx] = aux_get(ca1, rs1, j, n);
+        else if (pf1) raw0[sidx] = aux_get(ca1, rs1, j, n);
     };
     if (PF) aux_load(0);
 #pragma unroll
@@ -515,10 +525,7 @@ __device__ __forceinline__ void nt_epilogue(const aew_gemm_nt_t& g, f32x4_t (&ac
                 if (row_ok && n < U.N) {
                     if (EPI == AEW_EPI_STORE) {
                         uint4 a1 = raw0[2 * j + u];                       // aux1 rode in raw0 (pf1) ...
-                        if (need1 && !pf1) {                              // ... or is fetched now (both operands in use)
-                            const char* p1 = epi_view_row(ca1, j);
-                            a1 = p1 ? *reinterpret_cast<const uint4*>(p1 + n * 2) : make_uint4(0, 0, 0, 0);
-                        }
+                        if (need1 && !pf1) a1 = aux_get(ca1, rs1, j, n);   // ... or is fetched now (both operands in use)
                         epi_store8_pf<WT>(U, R, n, v, zc, fl, raw0[2 * j + u], a1);
                     }
                     else if (EPI == AEW_EPI_RES_SKIP) epi_res_skip<8>(U, R, n, v);
@@ -616,7 +623,7 @@ __device__ __forceinline__ void nt_tile(const aew_gemm_nt_t& g, char* smem, cons
     if (abl & 16) return;                              // launch + pointer setup
 #pragma unroll
     for (int q = 0; q < ST - 1; ++q) {                 // tiles 0 .. ST-2 in flight
-        if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + q * Cfg::STAGE_BYTES, wave, P);
+        if (!(abl & 4)) nt_issue_bf16<MT, NB, BMV, WT>(smem + q * Cfg::STAGE_BYTES, wave, P);
         advance();
     }
     const int fi = lane & 15, fg = lane >> 4;
@@ -675,7 +682,7 @@ __device__ __forceinline__ void nt_tile(const aew_gemm_nt_t& g, char* smem, cons
                 lap(3);
             }
             // tile t+ST-1 goes into the stage that was computed at step t-1 (every wave is past it: barrier)
-            if (!COUNTED && !(abl & 4)) nt_issue_bf16<MT, NB, BMV>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
+            if (!COUNTED && !(abl & 4)) nt_issue_bf16<MT, NB, BMV, WT>(smem + is.slot * Cfg::STAGE_BYTES, wave, P);
             if constexpr (COUNTED) {
                 // hand-placed: wait for what the group needs, 4 MFMAs, one LDS-DMA piece of tile t+2
                 // (asm MFMAs with a memory clobber so that neither they nor the DMA builtins move)

@@ -44,21 +44,22 @@ struct WinPtrs {
 // One step's operand tiles go out as the pieces every wave issues (main) plus the piece only the first REM waves
 // have (tail: a wave-uniform branch, kept out of the K loop's main basic block so that the scheduler directives there
 // can thread the other pieces between the MFMAs).
-template <int MT, int DWP, bool WINDOW>
+// (SC1X: the activation pieces are read device-scope - stage of a chained launch, see glds16_sc1)
+template <int MT, int DWP, bool WINDOW, bool SC1X = false>
 __device__ __forceinline__ void win_issue_tail(char* stage, int wave, WinPtrs& P) {
     typedef WinCfg<MT, DWP> Cfg;
     constexpr int nfull = WINDOW ? Cfg::NFULL : Cfg::PFULL, rem = WINDOW ? Cfg::REM : Cfg::PREM;
     if (rem > 0 && wave < rem) {
-        if (nfull == 1) { glds16(P.x1, stage + (wave + 8) * 1024); P.x1 += NT_BK * 2; }
-        else { glds16(P.x2, stage + (wave + 16) * 1024); P.x2 += NT_BK * 2; }
+        if (nfull == 1) { glds16_x<SC1X>(P.x1, stage + (wave + 8) * 1024); P.x1 += NT_BK * 2; }
+        else { glds16_x<SC1X>(P.x2, stage + (wave + 16) * 1024); P.x2 += NT_BK * 2; }
     }
 }
-template <int MT, int DWP, bool WINDOW>
+template <int MT, int DWP, bool WINDOW, bool SC1X = false>
 __device__ __forceinline__ void win_issue_main(char* stage, int wave, WinPtrs& P) {
     typedef WinCfg<MT, DWP> Cfg;
     constexpr int nfull = WINDOW ? Cfg::NFULL : Cfg::PFULL;
-    glds16(P.x0, stage + wave * 1024);
-    if (nfull == 2) glds16(P.x1, stage + (wave + 8) * 1024);
+    glds16_x<SC1X>(P.x0, stage + wave * 1024);
+    if (nfull == 2) glds16_x<SC1X>(P.x1, stage + (wave + 8) * 1024);
     glds16(P.w, stage + Cfg::W_OFF + wave * 1024);
     if (WINDOW) glds16(P.w + P.wdelta, stage + Cfg::W_OFF + NT_BN * NT_ROWB + wave * 1024);
     P.x0 += NT_BK * 2; P.w += NT_BK * 2;
@@ -163,8 +164,8 @@ __device__ __forceinline__ void win_tile(const aew_gemm_nt_t& g, char* smem, con
     const int xoff1 = (rx + sh1) * NT_ROWB + (nt_swz64(rx + sh1, fg) << 4);
     const int xoffs = rx * NT_ROWB + (nt_swz64(rx, fg) << 4);
 
-    win_issue_tail<MT, DWP, true>(smem, wave, P);
-    win_issue_main<MT, DWP, true>(smem, wave, P);
+    win_issue_tail<MT, DWP, true, WT>(smem, wave, P);
+    win_issue_main<MT, DWP, true, WT>(smem, wave, P);
     win_advance<MT>(g, b, m0, wave, lane, klen, P);
     int t = 0;
     for (; t < kw; ++t) {
@@ -173,14 +174,14 @@ __device__ __forceinline__ void win_tile(const aew_gemm_nt_t& g, char* smem, con
         asm volatile("" ::: "memory");
         const char* st = smem + (t & 1) * Cfg::STAGE_BYTES;
         char* nst = smem + ((t + 1) & 1) * Cfg::STAGE_BYTES;
-        win_issue_tail<MT, DWP, true>(nst, wave, P);
+        win_issue_tail<MT, DWP, true, WT>(nst, wave, P);
         {
             bf16x8_t wf[4], xf[MT], wg[4], xg[MT];
 #pragma unroll
             for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff + i * 1024);
 #pragma unroll
             for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoff0 + j * 1024);
-            win_issue_main<MT, DWP, true>(nst, wave, P);
+            win_issue_main<MT, DWP, true, WT>(nst, wave, P);
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -216,13 +217,13 @@ __device__ __forceinline__ void win_tile(const aew_gemm_nt_t& g, char* smem, con
         asm volatile("" ::: "memory");
         const char* st = smem + (t & 1) * Cfg::STAGE_BYTES;
         char* nst = smem + ((t + 1) & 1) * Cfg::STAGE_BYTES;
-        win_issue_tail<MT, DWP, false>(nst, wave, P);
+        win_issue_tail<MT, DWP, false, WT>(nst, wave, P);
         bf16x8_t wf[4], xf[MT];
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(st + woff + i * 1024);
 #pragma unroll
         for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8_t*>(st + xoffs + j * 1024);
-        win_issue_main<MT, DWP, false>(nst, wave, P);
+        win_issue_main<MT, DWP, false, WT>(nst, wave, P);
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll

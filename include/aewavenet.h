@@ -481,7 +481,7 @@ typedef struct {                 /* time-jitter indices on the device (jitter.py
  *   producer tile : out0 stored write-through (sc1), every wave drains its stores, one lane adds 1 to the counter of
  *                   its (stage, batch element, row tile) - device scope
  *   consumer tile : one wave polls the counters of the producer row tiles it reads (relaxed device-scope loads, bounded
- *                   spin), one agent-scope acquire, workgroup barrier, then plain loads
+ *                   spin), workgroup barrier, then its activation and epilogue operands with device-scope (sc1) loads
  * No assumption on workgroup -> XCD placement.  The bounded spin relies on workgroups being dispatched in index
  * order (every producer of a resident tile has been dispatched): a wait that times out sets *err and the tile runs on.
  * Same kernel bodies, tile shape (256 x 128) and summation order as the stand-alone launches of the default shape
@@ -526,7 +526,7 @@ typedef struct {
     int32_t set;                     /* 0: GATED / STORE bodies (forward), 1: DFG / STORE bodies (backward)    */
     int32_t n_ops;                   /* stage ops that follow this op in the plan                              */
     int32_t spin_max;                /* polls before a wait gives up (0: default 1 << 18)                      */
-    int32_t flags;                   /* 1 = consumers skip the agent-scope acquire (measurement aid, never in the product);
+    int32_t flags;                   /* 4 = consumers also issue an agent-scope acquire fence (A/B; the sc1 loads make it redundant);
                                         2 = the caller zeroes `counters` itself before the launch (a plan with several chains:
                                         one AEW_OP_ZERO for all of them) */
     int32_t pad_;
