@@ -120,6 +120,39 @@ def test_chained_stack_with_waiting_tiles(monkeypatch, B, w):
         lib.aew_set_nt_window(64)
 
 
+def test_chained_stack_under_uneven_load(monkeypatch):
+    """The guide's rule for every in-launch hand-off: test it under UNEVEN load.  While the chained forward and backward run,
+    a second stream keeps the chip busy with work of its own (large device copies and fp32 matrix products in bursts of
+    different length), so that tiles of the chain are delayed unevenly, producers and consumers drift apart, and more waits
+    are real.  Results must stay bit-identical to the quiet run, no wait may give up."""
+    monkeypatch.setattr(M.TrainEngine, "nt_chain", 64)
+    monkeypatch.setattr(M.TrainEngine, "nt_chain_bwd", 64)
+    monkeypatch.delenv("AEW_NT_CHAIN", raising=False)
+    hps, eng, wts, emb, inp = seeded_full_engine(B=8, w=5000, seed=11)
+    eng.set_inputs(*[t.to(DEV) for t in inp])
+    assert len(_chains(eng)) == 3
+    l_ref, lg_ref, g_ref = _step(eng)
+    _no_timeouts(eng)
+    mask = _mask(eng)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    waited = []
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for k in range(6 + 5 * rep):                      # bursts of different length per replay
+                if k % 3 == 0:
+                    big[:32 << 20].copy_(big[32 << 20:])
+                else:
+                    a = (a @ a).clamp_(-1, 1)
+        l, lg, g = _step(eng)                                 # (synchronises the device at its end)
+        _no_timeouts(eng)
+        waited.append([v[1] for pl in (eng.fwd_b, eng.bwd) for v in PLN.chain_stats(pl).values()])
+        assert l == l_ref and torch.equal(lg, lg_ref), rep
+        assert torch.equal(g[mask], g_ref[mask]), rep
+    print("tiles that waited per chained launch, by replay under load:", waited)
+
+
 def test_chain_timeout_is_reported_not_hung():
     """A stage table whose first stage never publishes: every consumer's wait gives up after spin_max polls, the launch
     ends, and the timeout flag names a stage."""
