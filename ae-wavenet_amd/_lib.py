@@ -44,7 +44,8 @@ class GemmNT(C.Structure):
                 ("W", vp), ("epi", i32), ("flags", u32), ("out0", View), ("out1", View),
                 ("out2", View), ("aux0", View), ("aux1", View), ("bias", vp), ("bias_bs", i64),
                 ("n_split", i32), ("reserved", i32), ("counter", vp),
-                ("W2", vp), ("N2", i32), ("N2_pad", i32), ("out3", View)]
+                ("W2", vp), ("N2", i32), ("N2_pad", i32), ("out3", View),
+                ("k_split", i32), ("pad2_", i32), ("ksplit_ws", vp), ("ksplit_tickets", vp)]
 
 
 class GemmTN(C.Structure):

@@ -1306,9 +1306,13 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
     const int wave = wv & 3;
     const bool loader = LW && wv >= 4, stages_own = !LW;       // stages_own: this wave issues its own LDS-DMA
     const int rows = g.M * g.batch, n_rt = (rows + Cfg::BM - 1) / Cfg::BM;
-    const int nt_i = blockIdx.x / n_rt;
-    const int R0 = (blockIdx.x - nt_i * n_rt) * Cfg::BM, n0 = nt_i * NF_BN;
-    const int nkt = g.K_total / NF_BK;
+    // split-K (aew_gemm_nt_t.k_split): workgroup = (k range sp, tile); range sp is K tiles [kt0, kt0 + nkt)
+    const int ks = g.k_split > 1 ? g.k_split : 1;
+    const int tiles = n_rt * (g.N_pad / NF_BN);
+    const int sp = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - sp * tiles;
+    const int nt_i = tile / n_rt;
+    const int R0 = (tile - nt_i * n_rt) * Cfg::BM, n0 = nt_i * NF_BN;
+    const int nkt = g.K_total / NF_BK / ks, kt0 = sp * nkt;
     f32x4_t acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -1319,7 +1323,7 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = (wave + 4 * j) * 8 + lr;
-            P.w[j] = wbase + (int64_t)(n0 + r) * g.K_total * 4 + (nt_swz(r, pc) << 4);
+            P.w[j] = wbase + ((int64_t)(n0 + r) * g.K_total + (int64_t)kt0 * NF_BK) * 4 + (nt_swz(r, pc) << 4);
         }
         P.winc = NF_BK * 4;
     }
@@ -1327,7 +1331,13 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
                no_tr = NF_ABL(g, 32), no_issue = NF_ABL(g, 64), no_wait = NF_ABL(g, 128);
     int seg = 0, left = g.seg[0].k_len / NF_BK, issued = 0;      // left = K tiles still to issue from `seg`
     uint32_t slot = 0;                                           // byte offset of the stage the next tile goes to
-    nf_setup_x<RT>(g, 0, R0, wave, lane, P);
+    {   // the segment and the K tile inside it where this workgroup's range starts (wave-uniform; kt0 = 0 without split-K)
+        int skip = kt0;
+        while (skip >= left) { skip -= left; ++seg; left = g.seg[seg].k_len / NF_BK; }
+        nf_setup_x<RT>(g, seg, R0, wave, lane, P);
+        P.x += (int64_t)skip * P.xinc;
+        left -= skip;
+    }
     auto issue_next = [&]() {
         if (__builtin_expect(left == 0, 0)) {                  // the only scalar loads of the K loop
             if (issued >= nkt) {                               // K exhausted: keep the ring (and vmcnt) uniform
@@ -1390,6 +1400,46 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
     }
     if (nkt & 1) step(A, B);
     if (stages_own) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the top-up loads still target this block's LDS
+    if (ks > 1) {
+        // Split-K seam, per WAVE (a wave owns 16 channels of the tile's rows: no workgroup barrier, the loader waves
+        // have left).  The partial sums go to slab sp with write-through stores; once they have drained one lane takes a
+        // ticket (device-scope atomic).  The wave that draws the LAST ticket of its sub-tile reads all S partials back
+        // device-scope and adds them in the fixed order (p0 + p1) + (p2 + p3) - arrival order does not enter the result -
+        // then runs the epilogue; the others are done.  Nobody waits for anybody.
+        const int rows_pad = (rows + 31) & ~31;
+        const int64_t slab = (int64_t)rows_pad * g.N_pad;
+        const int ncol = n0 + wave * 16 + 4 * kq;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int R = R0 + 16 * r + fi;
+            if (R < rows_pad)
+                store16_wt(g.ksplit_ws + sp * slab + (int64_t)R * g.N_pad + ncol,
+                           (u32x4_t){__float_as_uint(acc[r][0]), __float_as_uint(acc[r][1]), __float_as_uint(acc[r][2]),
+                                     __float_as_uint(acc[r][3])});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* tk = g.ksplit_tickets + (int64_t)tile * 4 + wave;
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t != (unsigned)(ks - 1)) return;
+        if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc(g.ksplit_ws);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int R = R0 + 16 * r + fi;
+            f32x4_t p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = (q < ks && R < rows_pad) ? ld16_sc1(rs, (uint32_t)(((int64_t)q * slab + (int64_t)R * g.N_pad + ncol) * 4))
+                                                         : make_uint4(0, 0, 0, 0);
+                p[q] = (f32x4_t){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[r][e] = ks == 2 ? p[0][e] + p[1][e] : (p[0][e] + p[1][e]) + (p[2][e] + p[3][e]);
+        }
+    }
     unsigned zc = 0;
     const EpiUni U = epi_uni(g);
     if (NF_ABL(g, 8)) {
@@ -2419,7 +2469,14 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         // is that small - 16-row tiles first (more, shorter chains), else 32-row tiles - and the 3-blocks-per-CU shape
         // for anything larger
         const int rows = g.M * g.batch, n_nt = g.N_pad / NF_BN;
-        const int tiles1 = ((rows + 15) / 16) * n_nt, tiles2 = ((rows + 31) / 32) * n_nt;
+        const int ksp = g.k_split > 1 ? g.k_split : 1;
+        if (ksp > 1) {
+            if ((ksp != 2 && ksp != 4) || g.impl != 0 || g.epi != AEW_EPI_STORE || !g.ksplit_ws || !g.ksplit_tickets ||
+                g.K_total % (NF_BK * ksp) || ((uintptr_t)g.ksplit_ws & 15) || (int64_t)ksp * ((rows + 31) & ~31) * g.N_pad * 4 > 0x7fffffff)
+                return AEW_E_ARG;
+        }
+        // (workgroups: tiles x k ranges; the shape thresholds see the whole grid)
+        const int tiles1 = ((rows + 15) / 16) * n_nt * ksp, tiles2 = ((rows + 31) / 32) * n_nt * ksp;
 #define AEW_NF_GO(RT, S, GRID)                                                                                       \
     do {                                                                                                             \
         if (AEW_T().nf_loaders) hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 1>), dim3(GRID), dim3(512), (NfCfg<RT, S>::LDS_BYTES), st, g); \

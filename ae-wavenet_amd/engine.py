@@ -1014,6 +1014,19 @@ class DecoderPlan:
 # ------------------------------------------------------------------------------------------
 # encoder + bottleneck (fp32 exact chain)
 # ------------------------------------------------------------------------------------------
+def exact_split_args(ws: Workspace, name: str, S: int, cin: int, k_total: int, rows: int, n_pad: int) -> dict:
+    """make_nt keywords for the split-K form of an exact fp32 GEMM (aew_gemm_nt_t.k_split): S contiguous k-ranges on
+    separate workgroups, combined in a fixed order - the canonical summation order of the op, oracle/exact.py ksplit_for
+    states the same rule: the input channels need no padding (cin a multiple of 64) and the K axis is a multiple of 32 * S.
+    Allocates the partial-sum slabs and the (self-resetting) tickets.  {} = not split."""
+    if S not in (2, 4) or cin % 64 or k_total % (32 * S):
+        return {}
+    rows_pad = ru(rows, 32)
+    wsb = ws.alloc(name + ".ws", S * rows_pad * n_pad, torch.float32)
+    tk = ws.alloc(name + ".tickets", (rows_pad // 16) * (n_pad // 64) * 4, torch.int32)
+    return dict(k_split=S, ksplit_ws_ptr=wsb.data_ptr(), ksplit_tickets_ptr=tk.data_ptr())
+
+
 class EncoderPlan:
     """Encoder (wave_encoder.py:34-103).  Forward: fp32, exact k-ascending chains (bit-exact code indices against
     oracle/exact_chain.c).  Backward: bf16 operands, fp32 accumulation on the bf16 MFMA kernels - the forward's
@@ -1021,6 +1034,14 @@ class EncoderPlan:
     step for 0.3 % of its FLOPs: one serial chain per output, every 16-row tile re-streaming the weight matrix).  The
     forward's epilogue writes what the backward reads as bf16: the activations (wgrad operand), the pre-activation
     (relu mask)."""
+
+    k_split = 0               # 2 | 4: the exact fp32 GEMMs (encoder layers, bottleneck linear) as S contiguous k-ranges on separate
+                              # workgroups with a fixed-order combine (aew_gemm_nt_t.k_split) - a DIFFERENT canonical summation
+                              # order, which oracle/exact.py's KSPLIT must then state too (the GPU test sets both).  Built for
+                              # the round-4 review's item 5 and measured: enc.# 0.266 ms unsplit, 0.291 ms with S = 4 (720
+                              # workgroups instead of 180: the serial K loop per workgroup is a quarter, the launch is not
+                              # faster - these layers are bound by what a workgroup streams per K tile, profiles/r04_notes.md
+                              # 9), fwd_a 0.379 / 0.370 / 0.387 ms for S = 0 / 2 / 4.  Off: the order stays one chain per output
 
     def __init__(self, ws: Workspace, ps: ParamStore, hps, geom: G.ModelGeom, B: int, n_mel: int,
                  mel_cl: Mat, packer: Packer, impl: int = 0, in_tbl: Optional[CopyTableBuilder] = None,
@@ -1083,11 +1104,13 @@ class EncoderPlan:
             X, Y, Rm = self.y[i], self.y[i + 1], self.r[i + 1]
             segs = [X.seg(cinp, row_step=s, row_off=k) for k in range(f)]
             flags = L.EF_BIAS | L.EF_RELU | L.EF_OUT1_PRE | L.EF_COUNT_ZERO | L.EF_OUT2_COPY | (L.EF_ADD_AUX0 if res else 0)
+            cin = self.n_mel if i == 0 else self.E
+            skw = exact_split_args(self.ws, f"enc.ks{i}", self.k_split if impl == 0 else 0, cin, f * cinp, Y.rows * B, Ep)
             plan.add(L.OP_GEMM_NT, make_nt(
                 F3, Y.rows, self.E, Ep, B, segs, self.W[i].ptr, flags=flags, out0=Y.view(), out1=Rm.view(),
                 out2=self.yb[i + 1].view(),
                 aux0=X.view(row_off=(f - 1) // 2) if res else null_view(), bias_ptr=self.bias[i].data_ptr(),
-                counter_ptr=self.zero_cnt.data_ptr() + 8 * i, impl=impl), f"enc.{i}", TAG_ENC,
+                counter_ptr=self.zero_cnt.data_ptr() + 8 * i, impl=impl, **skw), f"enc.{i}", TAG_ENC,
                 join=join_before_layer1 if i == 1 else False)
             cinp = Ep
 

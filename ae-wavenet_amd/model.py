@@ -16,7 +16,7 @@ import torch
 
 from . import _lib as L
 from . import geometry as G
-from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC,
+from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC, exact_split_args,
                      TAG_LOSS, TAG_MISC, TAG_PACK, TAG_VQ, bottleneck_param_specs,
                      decoder_param_specs, encoder_param_specs)
 from .plan import CopyTableBuilder, Mat, Plan, Workspace, insert_nt_chains, make_nt, make_tn, null_view, ru
@@ -225,9 +225,10 @@ class TrainEngine:
             E, Ep = hps.enc_n_out, ru(hps.enc_n_out, 64)
             y9 = self.enc.y[9]
             flags = L.EF_BIAS if bn == "ae" else 0
+            skw = exact_split_args(ws, "bn.ks", EncoderPlan.k_split if impl == 0 else 0, E, Ep, g.embed_len * B, self.nlin_p)
             fa.add(L.OP_GEMM_NT, make_nt(F3, g.embed_len, ru(self.nlin, 4), self.nlin_p, B, [y9.seg(Ep)],
                                          self.Wl.ptr, flags=flags, out0=self.lin.view(),
-                                         bias_ptr=self.lin_bias.data_ptr() if bn == "ae" else 0, impl=impl),
+                                         bias_ptr=self.lin_bias.data_ptr() if bn == "ae" else 0, impl=impl, **skw),
                    "bn.linear", TAG_VQ)
             if bn in ("vqvae-ema", "vqvae"):
                 vq = L.VqNearest()

@@ -216,7 +216,8 @@ def make_nt(dtype: int, M: int, N: int, N_pad: int, batch: int, segs: Sequence[L
             out1: Optional[L.View] = None, out2: Optional[L.View] = None,
             aux0: Optional[L.View] = None, aux1: Optional[L.View] = None, bias_ptr: int = 0,
             bias_bs: int = 0, n_split: int = 0, counter_ptr: int = 0, impl: int = 0,
-            W2_ptr: int = 0, N2: int = 0, N2_pad: int = 0, out3: Optional[L.View] = None) -> L.GemmNT:
+            W2_ptr: int = 0, N2: int = 0, N2_pad: int = 0, out3: Optional[L.View] = None,
+            k_split: int = 0, ksplit_ws_ptr: int = 0, ksplit_tickets_ptr: int = 0) -> L.GemmNT:
     g = L.GemmNT()
     g.dtype, g.impl, g.M, g.N, g.N_pad, g.batch = dtype, impl, M, N, N_pad, batch
     if not 1 <= len(segs) <= L.MAX_SEGS:
@@ -232,6 +233,8 @@ def make_nt(dtype: int, M: int, N: int, N_pad: int, batch: int, segs: Sequence[L
             setattr(g, nm, v)
     g.bias, g.bias_bs, g.n_split = bias_ptr or None, bias_bs, n_split
     g.counter = counter_ptr or None
+    if k_split > 1:                  # exact fp32 kernel: S contiguous k-ranges, fixed-order combine (aewavenet.h)
+        g.k_split, g.ksplit_ws, g.ksplit_tickets = k_split, ksplit_ws_ptr, ksplit_tickets_ptr
     if W2_ptr:                       # fused gated layer: residual 1x1 over the z tile (aewavenet.h)
         g.W2, g.N2, g.N2_pad = W2_ptr, N2, N2_pad
         g.out3 = out3

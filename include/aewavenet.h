@@ -138,6 +138,19 @@ typedef struct {
     const void* W2;              /* packed [N2_pad][N_pad / 2] bf16                                          */
     int32_t N2, N2_pad;          /* N2 multiple of 8, N2_pad multiple of 128                                 */
     aew_view_t out3;
+    /* Split-K of the exact fp32 kernel (ABI 19; AEW_F32, impl 0, AEW_EPI_STORE only; wave_encoder.py:39, vqema_bn.py:131).
+     * k_split = S in {2, 4}: the concatenated K axis is cut into S contiguous ranges of K_total / S channels (a multiple of
+     * 32), each a k-ascending fmaf chain of its own on its own workgroup; the partial sums meet in the FIXED order
+     *     S = 2: p0 + p1          S = 4: (p0 + p1) + (p2 + p3)         (plain fp32 adds, then bias / relu / ...)
+     * whichever workgroup arrives last does the combine and the epilogue - the order of arrival does not enter the result.
+     * This IS the canonical summation order of the op (oracle/exact_chain.c: aewo_conv_cl ksplit), chosen so that the
+     * 180-block launches of the encoder (232-560 rows in all) become 720 blocks with a quarter of the serial K loop each.
+     * ksplit_ws: device fp32 [S][rows_pad][N_pad], rows_pad = M * batch rounded up to 32; ksplit_tickets: device uint32
+     * [tiles of 16 rows x 16 channels rounded up], ZERO before the first launch (the combine resets them).  0 / 1 = off. */
+    int32_t k_split;
+    int32_t pad2_;
+    float* ksplit_ws;
+    uint32_t* ksplit_tickets;
 } aew_gemm_nt_t;
 
 typedef struct {

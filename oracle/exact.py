@@ -30,8 +30,21 @@ def _f(a):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
-def conv_cl(x, W, bias, stride=1, relu=True, res_lw=-1):
-    """x (B, L, Cin) channels-last; W (Cout, Cin, f) reference layout; -> (B, Lout, Cout)."""
+KSPLIT = 1          # the canonical order of the exact chains: 1 = one ascending chain per output (the product's default);
+                    # 2 | 4 = the split form of aew_gemm_nt_t.k_split - must equal EncoderPlan.k_split (0 / 1 = off) of the engine
+                    # it is compared with (tests/test_gpu_parity.py::test_encoder_split_k_is_exact_in_its_own_order sets both)
+
+
+def ksplit_for(k_total_padded: int, S: int = None) -> int:
+    """S if the op's K axis (taps x input channels PADDED to the kernel's 64-channel granule) is a multiple of 32 * S and the
+    input channels need no padding, else 1 - the rule the engine applies to every exact fp32 GEMM (encoder layers,
+    bottleneck linear)."""
+    S = KSPLIT if S is None else S
+    return S if (S > 1 and k_total_padded % (32 * S) == 0) else 1
+
+
+def conv_cl(x, W, bias, stride=1, relu=True, res_lw=-1, ksplit=1):
+    """x (B, L, Cin) channels-last; W (Cout, Cin, f) reference layout; -> (B, Lout, Cout).  ksplit: see exact_chain.c."""
     x, xp = _f(x)
     W, wp = _f(W)
     B, L, Cin = x.shape
@@ -42,9 +55,9 @@ def conv_cl(x, W, bias, stride=1, relu=True, res_lw=-1):
     bp = None
     if bias is not None:
         bias, bp = _f(bias)
-    rc = lib().aewo_conv_cl(xp, B, L, Cin, wp, bp, Cout, f, stride, int(relu), int(res_lw),
-                            y.ctypes.data_as(ctypes.c_void_p))
-    assert rc == 0
+    rc = lib().aewo_conv_cl_split(xp, B, L, Cin, wp, bp, Cout, f, stride, int(relu), int(res_lw),
+                                  y.ctypes.data_as(ctypes.c_void_p), int(ksplit))
+    assert rc == 0, rc
     return y
 
 
@@ -57,14 +70,20 @@ def encoder_cl(sd, pre, mel_cl):
     """Encoder stack on channels-last mel (B, F, n_in) -> (B, N_e, n_out)."""
     x = np.ascontiguousarray(mel_cl, np.float32)
     for i, (f, s, r) in enumerate(zip(ENC_FILTERS, ENC_STRIDES, ENC_RESIDUAL)):
-        x = conv_cl(x, np.asarray(sd[f"{pre}net.{i}.conv.weight"]),
-                    np.asarray(sd[f"{pre}net.{i}.conv.bias"]), s, True, (f - 1) // 2 if r else -1)
+        W = np.asarray(sd[f"{pre}net.{i}.conv.weight"])
+        cin = W.shape[1]
+        # (input channels that the kernel pads - the 39 mel channels of layer 0, reduced-width test models - are not split:
+        # the padded k axis would cut elsewhere than the unpadded one)
+        ks = ksplit_for(f * cin) if cin % 64 == 0 else 1
+        x = conv_cl(x, W, np.asarray(sd[f"{pre}net.{i}.conv.bias"]), s, True, (f - 1) // 2 if r else -1, ksplit=ks)
     return x
 
 
 def linear_cl(x_cl, W):
     """1x1 conv without bias: (B, N, Cin) x (Cout, Cin, 1)."""
-    return conv_cl(x_cl, W, None, 1, False, -1)
+    W = np.asarray(W)
+    ks = ksplit_for(W.shape[1] * W.shape[2]) if W.shape[1] % 64 == 0 else 1
+    return conv_cl(x_cl, W, None, 1, False, -1, ksplit=ks)
 
 
 def vq_nearest(ze_q, emb, metric="scaled_l2"):

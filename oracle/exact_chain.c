@@ -8,6 +8,11 @@
  *   conv  : acc = 0; for tap in 0..f-1: for ci in 0..Cin-1:
  *               acc = fmaf(x[t*stride+tap][ci], W[co][ci][tap], acc)
  *           y = relu(acc + bias[co]) (+ x[t+lw][co] if residual) (wave_encoder.py:39-43)
+ *           ksplit = S in {2, 4} (round 5; the product's aew_gemm_nt_t.k_split): the k axis (k = tap * Cin + ci, f * Cin a
+ *           multiple of 32 * S) is cut into S contiguous ranges, each its own ascending fmaf chain from 0, and
+ *               acc = p0 + p1  (S = 2)        acc = (p0 + p1) + (p2 + p3)  (S = 4)       (plain fp32 adds)
+ *           - the canonical order of every encoder layer and of the bottleneck's linear map whose k axis divides
+ *           that way (oracle/exact.py: ksplit_for), so that the MI355X kernel can run the ranges on separate workgroups
  *   dist  : dd = fma-chain_j (z_j-q_j)^2 ; zz = fma-chain_j z_j^2 ; qq = fma-chain_j q_j^2
  *           scaled_l2 = sqrtf(dd) / (sqrtf(zz) + sqrtf(qq))    (vqema_bn.py:67-76)
  *           sq_l2     = dd                                      (vq_bn.py:39)
@@ -25,11 +30,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+int aewo_conv_cl_split(const float* x, int B, int L, int Cin, const float* W, const float* bias,
+                       int Cout, int f, int stride, int relu, int res_lw, float* y, int ksplit);
+
 int aewo_conv_cl(const float* x, int B, int L, int Cin, const float* W, const float* bias,
                  int Cout, int f, int stride, int relu, int res_lw, float* y)
 {
+    return aewo_conv_cl_split(x, B, L, Cin, W, bias, Cout, f, stride, relu, res_lw, y, 1);
+}
+
+int aewo_conv_cl_split(const float* x, int B, int L, int Cin, const float* W, const float* bias,
+                       int Cout, int f, int stride, int relu, int res_lw, float* y, int ksplit)
+{
     const int Lout = (L - f) / stride + 1;
     if (Lout <= 0) return 1;
+    if (ksplit != 1 && ksplit != 2 && ksplit != 4) return 3;
+    if (ksplit > 1 && (f * Cin) % (32 * ksplit)) return 4;
+    const int krange = f * Cin / ksplit;                     /* k = tap * Cin + ci */
     /* re-lay weights as Wt[tap][ci][co] so the inner loop over co is contiguous */
     float* Wt = (float*)malloc(sizeof(float) * (size_t)f * Cin * Cout);
     if (!Wt) return 2;
@@ -41,14 +58,32 @@ int aewo_conv_cl(const float* x, int B, int L, int Cin, const float* W, const fl
     for (int b = 0; b < B; ++b)
         for (int t = 0; t < Lout; ++t) {
             float* acc = y + ((size_t)b * Lout + t) * Cout;
-            for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
-            for (int k = 0; k < f; ++k) {
-                const float* xr = x + ((size_t)b * L + (size_t)t * stride + k) * Cin;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float xv = xr[ci];
-                    const float* wr = Wt + ((size_t)k * Cin + ci) * Cout;
-                    for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+            if (ksplit == 1) {
+                for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
+                for (int k = 0; k < f; ++k) {
+                    const float* xr = x + ((size_t)b * L + (size_t)t * stride + k) * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float xv = xr[ci];
+                        const float* wr = Wt + ((size_t)k * Cin + ci) * Cout;
+                        for (int co = 0; co < Cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                    }
                 }
+            } else {
+                float* part = (float*)malloc(sizeof(float) * (size_t)ksplit * Cout);
+                for (int sp = 0; sp < ksplit; ++sp) {
+                    float* p = part + (size_t)sp * Cout;
+                    for (int co = 0; co < Cout; ++co) p[co] = 0.0f;
+                    for (int kk = sp * krange; kk < (sp + 1) * krange; ++kk) {
+                        const int k = kk / Cin, ci = kk - k * Cin;
+                        const float xv = x[((size_t)b * L + (size_t)t * stride + k) * Cin + ci];
+                        const float* wr = Wt + (size_t)kk * Cout;
+                        for (int co = 0; co < Cout; ++co) p[co] = fmaf(xv, wr[co], p[co]);
+                    }
+                }
+                for (int co = 0; co < Cout; ++co)
+                    acc[co] = ksplit == 2 ? part[co] + part[Cout + co]
+                                          : (part[co] + part[Cout + co]) + (part[2 * Cout + co] + part[3 * Cout + co]);
+                free(part);
             }
             if (bias)
                 for (int co = 0; co < Cout; ++co) acc[co] = acc[co] + bias[co];

@@ -954,6 +954,35 @@ def test_encoder_vq_bit_exact_full_width():
     print(f"min top-2 margin (relative): {((sec - dist) / dist).min():.3e}")
 
 
+@pytest.mark.parametrize("S", [2, 4])
+def test_encoder_split_k_is_exact_in_its_own_order(monkeypatch, S):
+    """aew_gemm_nt_t.k_split: the exact fp32 GEMMs as S contiguous k-ranges on separate workgroups, combined in the fixed
+    order (p0 + p1) + (p2 + p3) by whichever arrives last.  Bit-identical to the C oracle restating THAT order
+    (aewo_conv_cl_split), replay after replay (the arrival order must not enter the result), and the code indices still
+    equal the torch oracle's on this input.  (Measured no faster than the single chain: off by default.)"""
+    from oracle import exact
+    from ae_wavenet_amd import engine as E
+    monkeypatch.setattr(E.EncoderPlan, "k_split", S)
+    monkeypatch.setattr(exact, "KSPLIT", S)
+    hps, eng, wts, emb, inp = seeded_full_engine(B=2, w=100)
+    assert eng.fwd_a.ops[[i for i, lab in enumerate(eng.fwd_a.labels) if lab == "enc.1"][0]].u.nt.k_split == S
+    assert eng.fwd_a.ops[eng.fwd_a.labels.index("enc.0")].u.nt.k_split == 0          # 39 mel channels: padded, not split
+    eng.set_inputs(*[t.to(DEV) for t in inp])
+    mel_cl = inp[1].permute(0, 2, 1).contiguous().numpy()
+    enc = exact.encoder_cl(wts, "encoder.", mel_cl)
+    ze = exact.linear_cl(enc, wts["bottleneck.linear.weight"])
+    ind, dist, sec = exact.vq_nearest(ze.reshape(-1, 32), emb, "scaled_l2")
+    for rep in range(3):
+        eng.init_ema_from_emb()
+        eng.fwd_a.run(stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.enc.y[9].tensor()[:, :, :768].cpu().numpy(), enc), rep
+        assert np.array_equal(eng.lin.tensor()[:, :, :32].cpu().numpy(), ze), rep
+        assert np.array_equal(eng.ind[:eng.Q].cpu().numpy(), ind), rep
+    monkeypatch.setattr(exact, "KSPLIT", 1)
+    assert not np.array_equal(exact.encoder_cl(wts, "encoder.", mel_cl), enc)          # (the orders do differ)
+
+
 # ----------------------------------------------------------------------------------------------
 # full-width training step vs the torch fp32 oracle
 # ----------------------------------------------------------------------------------------------

@@ -59,6 +59,8 @@ def main():
         if k.startswith("LANE_") or k in ("merge_packs", "graph_lanes", "pack_dec_late", "nt_chain", "nt_chain_bwd", "nt_chain_bwd_phase", "nt_chain_force", "nt_chain_flags"):
             from ae_wavenet_amd import model as MDL
             return MDL.TrainEngine
+        if k == "k_split":                         # (timing only: the oracle's canonical order is EncoderPlan.k_split's default)
+            return E.EncoderPlan
         return PLN.CopyTableBuilder if k in ("tiled", "interleave") else E.DecoderPlan
 
     def engine_for(ekey):
