@@ -1171,13 +1171,17 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
 template <int RT, int S>
 struct NfCfg {
     static constexpr int BM = 16 * RT, STAGE_BYTES = (BM + NF_BN) * 128, LDS_BYTES = S * STAGE_BYTES;
-    static_assert(S >= 4 && (S - 2) * 3 <= 63 && LDS_BYTES <= 160 * 1024, "ring depth");
+    static constexpr int XPW = RT == 4 ? 2 : 1;              // X pieces (8 rows each) a wave stages per K tile
+    static constexpr int PW = XPW + 2;                       // LDS-DMA instructions per wave and K tile
+    static_assert(S >= 4 && (S - 2) * PW <= 63 && LDS_BYTES <= 160 * 1024, "ring depth");
+    static_assert(RT == 1 || RT == 2 || RT == 4, "16-, 32- or 64-row tiles");
 };
 
 struct NfPtrs {
     const char* x;
+    const char* x2;                                          // RT = 4: the wave's second X piece (piece wave + 4)
     const char* w[2];
-    int xinc, winc;
+    int xinc, x2inc, winc;
 };
 
 template <int RT>
@@ -1186,20 +1190,35 @@ __device__ __forceinline__ void nf_setup_x(const aew_gemm_nt_t& g, int seg, int 
     // (RT = 1: waves 2, 3 write pieces 0, 1 a second time - same bytes, same place): all waves then run the same
     // instruction stream with the same vmcnt, and a taken branch costs this loop ~40 cycles (tools/f32_ablate.py)
     const int lr = lane >> 3, pc = lane & 7;
-    const int r = (wave & (2 * RT - 1)) * 8 + lr;
-    const int R = R0 + r, bb = min(R / g.M, g.batch - 1);
     const aew_seg_t s = g.seg[seg];
-    bool ok;
-    const char* src = seg_row_ptr_sel(s, bb, R - bb * g.M, 4, ok) + (nt_swz(r, pc) << 4);
-    ok = ok && R < g.M * g.batch;
-    P.x = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
-    P.xinc = ok ? NF_BK * 4 : 0;
+    {
+        const int r = (wave & (2 * RT - 1)) * 8 + lr;
+        const int R = R0 + r, bb = min(R / g.M, g.batch - 1);
+        bool ok;
+        const char* src = seg_row_ptr_sel(s, bb, R - bb * g.M, 4, ok) + (nt_swz(r, pc) << 4);
+        ok = ok && R < g.M * g.batch;
+        P.x = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
+        P.xinc = ok ? NF_BK * 4 : 0;
+    }
+    if constexpr (RT == 4) {                                  // 8 pieces, 4 staging waves: pieces wave and wave + 4
+        const int r = (wave + 4) * 8 + lr;
+        const int R = R0 + r, bb = min(R / g.M, g.batch - 1);
+        bool ok;
+        const char* src = seg_row_ptr_sel(s, bb, R - bb * g.M, 4, ok) + (nt_swz(r, pc) << 4);
+        ok = ok && R < g.M * g.batch;
+        P.x2 = ok ? src : reinterpret_cast<const char*>(aew_zero_page);
+        P.x2inc = ok ? NF_BK * 4 : 0;
+    }
 }
 
 template <int RT>
 __device__ __forceinline__ void nf_issue(char* stage, int wave, NfPtrs& P) {
     glds16(P.x, stage + (wave & (2 * RT - 1)) * 1024);
     P.x += P.xinc;
+    if constexpr (RT == 4) {
+        glds16(P.x2, stage + (wave + 4) * 1024);
+        P.x2 += P.x2inc;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         glds16(P.w[j], stage + 16 * RT * 128 + (wave + 4 * j) * 1024);
@@ -1241,15 +1260,20 @@ template <int RT>
 __device__ __forceinline__ void nf_read(NfFrag<RT>& F, uint32_t wl, uint32_t xl) {
     NF_DS_READ16(F.w[0], wl);
     NF_DS_READ16(F.x[0][0], xl);
-    if constexpr (RT == 2) NF_DS_READ16(F.x[1][0], xl + 2048u);
+    if constexpr (RT >= 2) NF_DS_READ16(F.x[1][0], xl + 2048u);
+    if constexpr (RT == 4) { NF_DS_READ16(F.x[2][0], xl + 4096u); NF_DS_READ16(F.x[3][0], xl + 6144u); }
     NF_DS_READ16(F.w[1], wl ^ 64u);
     NF_DS_READ16(F.x[0][1], xl ^ 64u);
-    if constexpr (RT == 2) NF_DS_READ16(F.x[1][1], (xl + 2048u) ^ 64u);
+    if constexpr (RT >= 2) NF_DS_READ16(F.x[1][1], (xl + 2048u) ^ 64u);
+    if constexpr (RT == 4) { NF_DS_READ16(F.x[2][1], (xl + 4096u) ^ 64u); NF_DS_READ16(F.x[3][1], (xl + 6144u) ^ 64u); }
 }
 
 template <int RT>
 __device__ __forceinline__ void nf_ready(NfFrag<RT>& F) {
-    if constexpr (RT == 2)
+    if constexpr (RT == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F.w[0]), "+v"(F.w[1]), "+v"(F.x[0][0]), "+v"(F.x[0][1]), "+v"(F.x[1][0]), "+v"(F.x[1][1]),
+                     "+v"(F.x[2][0]), "+v"(F.x[2][1]), "+v"(F.x[3][0]), "+v"(F.x[3][1]));
+    else if constexpr (RT == 2)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F.w[0]), "+v"(F.w[1]), "+v"(F.x[0][0]), "+v"(F.x[0][1]), "+v"(F.x[1][0]), "+v"(F.x[1][1]));
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F.w[0]), "+v"(F.w[1]), "+v"(F.x[0][0]), "+v"(F.x[0][1]));
@@ -1289,6 +1313,19 @@ __device__ __forceinline__ void nf_chain(NfFrag<RT>& F, f32x4_t (&acc)[RT], bool
     if (skip_mfma) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) asm volatile("" ::"v"(F.w[0]), "v"(F.w[1]), "v"(F.x[r][0]), "v"(F.x[r][1]));
+        return;
+    }
+    if constexpr (RT == 4) {
+        // four INDEPENDENT chains (one per 16-row sub-tile), interleaved step by step: the three other chains' MFMAs fill
+        // the ~33 cycles a dependent MFMA waits for its accumulator, so the compiler may schedule freely here.  Every
+        // accumulator still sees its own products in ascending k: the same chain as the single-tile form, bit for bit.
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.w[j][e], F.x[r][j][e], acc[r], 0, 0, 0);
         return;
     }
 #pragma unroll
@@ -1336,13 +1373,14 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
         while (skip >= left) { skip -= left; ++seg; left = g.seg[seg].k_len / NF_BK; }
         nf_setup_x<RT>(g, seg, R0, wave, lane, P);
         P.x += (int64_t)skip * P.xinc;
+        if constexpr (RT == 4) P.x2 += (int64_t)skip * P.x2inc;
         left -= skip;
     }
     auto issue_next = [&]() {
         if (__builtin_expect(left == 0, 0)) {                  // the only scalar loads of the K loop
             if (issued >= nkt) {                               // K exhausted: keep the ring (and vmcnt) uniform
-                P.x = P.w[0] = P.w[1] = reinterpret_cast<const char*>(aew_zero_page);
-                P.xinc = P.winc = 0;
+                P.x = P.x2 = P.w[0] = P.w[1] = reinterpret_cast<const char*>(aew_zero_page);
+                P.xinc = P.x2inc = P.winc = 0;
                 left = 1 << 30;
             } else {
                 ++seg;
@@ -1358,10 +1396,10 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
     if (loader || stages_own)
         for (int i = 0; i < S - 1; ++i) issue_next();            // tiles 0 .. S-2
     if (loader) {                                                // the consumers' schedule, minus everything but the DMA
-        p64_wait_vm<(S - 2) * 3>();
+        p64_wait_vm<(S - 2) * Cfg::PW>();
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nkt; ++t) {
-            p64_wait_vm<(S - 3) * 3>();
+            p64_wait_vm<(S - 3) * Cfg::PW>();
             __builtin_amdgcn_s_barrier();
             issue_next();
         }
@@ -1374,7 +1412,7 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
     const uint32_t xlane = lds0 + fi * 128 + (nt_swz(fi, kq) << 4);
     const uint32_t wlane = lds0 + Cfg::BM * 128 + (wave * 16 + fi) * 128 + (nt_swz(fi, kq) << 4);
     NfFrag<RT> A, B;
-    if (stages_own) p64_wait_vm<(S - 2) * 3>();
+    if (stages_own) p64_wait_vm<(S - 2) * Cfg::PW>();
     __builtin_amdgcn_s_barrier();
     nf_read<RT>(A, wlane, xlane);
     nf_ready<RT>(A);
@@ -1385,7 +1423,7 @@ __global__ __launch_bounds__(256 * (1 + LW)) void k_gemm_nt_f32(const aew_gemm_n
     // (the wait closes the step: registers an asm read is still filling must not be live across the loop's back
     // edge, where the compiler is free to copy them)
     auto step = [&](NfFrag<RT>& F, NfFrag<RT>& Nx) {
-        if (stages_own && !no_wait) p64_wait_vm<(S - 3) * 3>();
+        if (stages_own && !no_wait) p64_wait_vm<(S - 3) * Cfg::PW>();
         if (!no_barrier) __builtin_amdgcn_s_barrier();
         if (stages_own && !no_issue) issue_next();
         cur = (cur + Cfg::STAGE_BYTES == (uint32_t)Cfg::LDS_BYTES) ? 0u : cur + Cfg::STAGE_BYTES;
@@ -2270,6 +2308,8 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_f32<1, 7, 1>), (NfCfg<1, 7>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_f32<1, 14, 1>), (NfCfg<1, 14>::LDS_BYTES))
     AEW_SET_LDS((k_gemm_nt_f32<2, 12, 1>), (NfCfg<2, 12>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<4, 4, 0>), (NfCfg<4, 4>::LDS_BYTES))
+    AEW_SET_LDS((k_gemm_nt_f32<4, 4, 1>), (NfCfg<4, 4>::LDS_BYTES))
     AEW_SET_LDS(k_gemm_tn_bf16_big, TNB_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<0>, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16<1>, TN_LDS_BYTES)
@@ -2482,7 +2522,10 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         if (AEW_T().nf_loaders) hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 1>), dim3(GRID), dim3(512), (NfCfg<RT, S>::LDS_BYTES), st, g); \
         else hipLaunchKernelGGL((k_gemm_nt_f32<RT, S, 0>), dim3(GRID), dim3(256), (NfCfg<RT, S>::LDS_BYTES), st, g);  \
     } while (0)
-        if (AEW_T().nf_deep && tiles1 <= AEW_T().nf_deep) AEW_NF_GO(1, 14, tiles1);
+        // split-K launches: 64-row tiles (four chains per wave share one W fragment: four times the MFMAs per weight byte
+        // staged; the k ranges restore the workgroup count), two workgroups per CU on a 4-stage ring
+        if (ksp > 1 && rows >= 64) AEW_NF_GO(4, 4, ((rows + 63) / 64) * n_nt * ksp);
+        else if (AEW_T().nf_deep && tiles1 <= AEW_T().nf_deep) AEW_NF_GO(1, 14, tiles1);
         else if (AEW_T().nf_deep && tiles2 <= AEW_T().nf_deep) AEW_NF_GO(2, 12, tiles2);
         else AEW_NF_GO(1, 7, tiles1);
 #undef AEW_NF_GO
