@@ -652,6 +652,45 @@ class TrainEngine:
         d = self.dec
         return d.cond.tensor(), d.bias_bl[:self.B * d.NL * 2 * d.Dp].view(self.B, d.NL, 2 * d.Dp)
 
+    # ---- chained launches: a hand-off wait that gave up must not pass silently --------------------------------------
+    def _chain_flags(self):
+        """[(label, 1-element int32 view of the launch's timeout flag)] over the engine's chained launches."""
+        if getattr(self, "_chain_flag_views", None) is None:
+            v = []
+            for pl in (self.fwd_b, self.bwd):
+                for lab, (stages, cd) in getattr(pl, "nt_chains", {}).items():
+                    n = sum(s.n_mt * s.g.batch for s in stages)
+                    v.append((lab, cd[n:n + 1]))
+            self._chain_flag_views = v
+        return self._chain_flag_views
+
+    def _chain_watch(self, after: str):
+        """The bounded spin of a chained launch (csrc/aew_chain.hip) ends a wait whose producer never arrives by setting a
+        flag and letting the tile run on - with operands that may be incomplete.  The flags are copied to pinned host
+        memory asynchronously behind the plan that ran the launches (`after` = "fwd" | "bwd") and looked at before the
+        NEXT forward: no synchronisation, and a launch that gave up raises instead of training on."""
+        flags = self._chain_flags()
+        if not flags or self.device.type != "cuda":
+            return
+        st = getattr(self, "_chain_host", None)
+        if st is None:
+            st = self._chain_host = {"buf": torch.zeros(len(flags), dtype=torch.int32).pin_memory(), "ev": torch.cuda.Event(),
+                                     "pending": False}
+        if after == "check":
+            if st["pending"] and st["ev"].query():
+                st["pending"] = False
+                bad = [flags[i][0] for i in range(len(flags)) if int(st["buf"][i]) != 0]
+                if bad:
+                    raise L.AewError(f"chained launch(es) {bad}: a tile's wait for its producers gave up (aew_nt_chain_t spin "
+                                     "limit) - results of that step are not trustworthy; AEW_NT_CHAIN=0 runs one launch per GEMM")
+            return
+        sel = [i for i, (lab, _) in enumerate(flags) if (lab in getattr(self.bwd, "nt_chains", {})) == (after == "bwd")]
+        for i in sel:
+            st["buf"][i:i + 1].copy_(flags[i][1], non_blocking=True)
+        if sel:
+            st["ev"].record()
+            st["pending"] = True
+
     def forward(self, ema_allreduce=None, timing=False, before_decoder=None):
         """timing=True forces eager launches (the per-op event timing needs them).
         before_decoder(): called between the two forward plans - the first point at which a decoder parameter is read
@@ -659,6 +698,7 @@ class TrainEngine:
         ema_allreduce(z_sum, n_sum): cross-rank sum of the EMA statistics.  If it returns a work handle
         (async collective) the EMA accumulation is deferred to finish_ema(), called by backward() - or by the next
         forward() if no backward came in between (forward-only use: the accumulation must not be lost)."""
+        self._chain_watch("check")
         self.finish_ema(timing)
         self._run(self.fwd_a, timing)
         if before_decoder is not None:
@@ -668,8 +708,12 @@ class TrainEngine:
             if work is not None and self.ema_plan is not None:
                 self._ema_work = work
                 self._run(self.fwd_b_noema, timing)
+                if not timing:
+                    self._chain_watch("fwd")
                 return self.loss_buf[0]
         self._run(self.fwd_b, timing)
+        if not timing:
+            self._chain_watch("fwd")
         return self.loss_buf[0]
 
     def finish_ema(self, timing=False):
@@ -706,6 +750,8 @@ class TrainEngine:
                 self._run(self.bwd_a, timing)
             after_decoder()
             self._run(self.bwd_b, timing)
+        if not timing and self.nt_chain_bwd_used >= 2:
+            self._chain_watch("bwd")
         self.finish_ema(timing)
         if self.bn_type == "vqvae-ema" and self.update_codebook_every_step:
             self._run(self.cb, timing)

@@ -81,6 +81,15 @@ def test_chained_stack_is_bit_identical_to_one_launch_per_op(monkeypatch, n_chai
     eng.tuning = t
     l, lg, g = _step(eng)
     assert l == l_ref and torch.equal(lg, lg_ref) and torch.equal(g[mask], g_ref[mask])
+    # the engine watches the launches' timeout flags (copied to pinned host memory behind each plan, looked at before the
+    # next forward): a wait that gave up raises instead of training on
+    eng._chain_watch("check")                                   # nothing pending / nothing set: silent
+    lab, flag = eng._chain_flags()[0]
+    flag.fill_(7)
+    eng._chain_watch("fwd")
+    torch.cuda.synchronize()
+    with pytest.raises(L.AewError, match="gave up"):
+        eng._chain_watch("check")
 
 
 @pytest.mark.parametrize("B,w", [(3, 700), (2, 100)])
