@@ -129,7 +129,7 @@ def cpu_baseline(hps, eng, seconds_budget=75.0, full_batch=True):
     sample of the same workload.  One training step = forward, the reference's diagnostic autograd.grad over (mel,
     encoding) (autoencoder_model.py:252-257: what its run() does), backward, Adam over all parameters
     (chassis.py:151-171).  (1) one window of the batch, one timed step at each of {4, 8, 16, 32, 64, all} threads (after an
-    untimed warm-up step); (2) one step on the FULL batch of 8 windows at the fastest thread count of (1) - batched
+    untimed warm-up step; the sweep stops once two counts in a row are slower than the best); (2) one step on the FULL batch of 8 windows at the fastest thread count of (1) - batched
     convolutions use the cores better than one window does (the unmodified reference, 8 cores, B = 8: 1 570
     samples/s).  `value` is the fastest samples/s seen, `cores` the thread count that produced it; everything measured is
     listed in `sweep`.  Round 4's method (one window, all threads, median of three) is entry `all threads` of the sweep."""
@@ -168,6 +168,10 @@ def cpu_baseline(hps, eng, seconds_budget=75.0, full_batch=True):
             dt = step(one, True)
             sweep.append({"threads": t, "windows": 1, "seconds": round(dt, 3), "samples_per_s": round(g.n_win / dt, 1)})
             if time.time() - t_start > seconds_budget * 0.5 and len(sweep) >= 2:
+                break
+            # past the optimum more threads only cost time (128 threads: 8 s per step against 0.6 s at 16): stop once two
+            # counts in a row are slower than the best, so that the whole baseline stays a ~25 s sample
+            if len(sweep) >= 3 and all(r["samples_per_s"] < max(x["samples_per_s"] for x in sweep) for r in sweep[-2:]):
                 break
         best = max(sweep, key=lambda r: r["samples_per_s"])
         if full_batch and time.time() - t_start < seconds_budget * 0.6:
