@@ -9,9 +9,12 @@ published algorithm:
     -> power_to_db(ref=1.0, amin=1e-10, top_db=80.0) -> scipy.fftpack.dct(type=2, norm='ortho')[:n_mfcc]
     delta(x, width=9, order=k) = scipy.signal.savgol_filter(x, 9, deriv=k, polyorder=k, axis=-1, mode='interp')
 What IS pinned: the window (scipy.signal.get_window), the DFT (numpy.fft), the DCT (scipy.fft.dct) and the delta
-filter (scipy.signal.savgol_filter) are the very library calls librosa makes.  What is restated without a check:
-the Slaney mel filterbank, the dB conversion, the reflect padding / framing, and the reference's own left-pad /
-trim arithmetic (mfcc.py:47-72, with vconv.VirtualConv's wing sizes for a 400/160 filter).
+filter (scipy.signal.savgol_filter) are the very library calls librosa makes.  What is restated without librosa to
+check against: the Slaney mel filterbank, the dB conversion, the reflect padding / framing, and the reference's own
+left-pad / trim arithmetic (mfcc.py:47-72, with vconv.VirtualConv's wing sizes for a 400/160 filter).  Round 5: the
+first three are held to a SECOND, independently written restatement of the same librosa calls that this image carries
+(transformers.audio_utils: mel_filter_bank / spectrogram / power_to_db, validated against librosa by its own project) -
+they agree to round-off (tests/test_mfcc.py) - which narrows, but does not close, the gap: still no librosa output.
 """
 import numpy as np
 import scipy.fft

@@ -33,6 +33,37 @@ def test_host_tables_against_independent_forms():
         assert np.abs(got - ref).max() < 1e-12
 
 
+def test_restated_stages_against_a_third_party_restatement_of_librosa():
+    """librosa itself is absent, so the three stages the oracle restates WITHOUT a check of its own - the Slaney mel filterbank,
+    the dB conversion with its top_db floor, the centred reflect-padded framing - are held here to an independent
+    implementation of the same librosa calls that this image does carry: `transformers.audio_utils` (mel_filter_bank with
+    norm = mel_scale = "slaney", spectrogram(center=True, pad_mode="reflect", power=2), power_to_db(db_range=80)), which its
+    own project validates against librosa.  Not a pin to librosa - the header of oracle/mfcc_ref.py keeps saying "partly
+    unpinned" - but two independently written restatements of the published algorithm that agree to round-off."""
+    AU = pytest.importorskip("transformers.audio_utils")
+    sr, win, hop, n_mels = 16000, 400, 160, 80
+    fb = AU.mel_filter_bank(num_frequency_bins=1 + win // 2, num_mel_filters=n_mels, min_frequency=0.0, max_frequency=sr / 2,
+                            sampling_rate=sr, norm="slaney", mel_scale="slaney")                 # [bins][mels]
+    ours = R.mel_filterbank(sr, win, n_mels)
+    assert fb.shape == ours.T.shape and np.abs(fb - ours.T).max() < 1e-9 * np.abs(ours).max() + 1e-12
+    rs = np.random.RandomState(3)
+    y = 128 + 60 * np.sin(2 * np.pi * np.arange(11800) * 0.01) + rs.normal(0, 12, 11800)
+    window = scipy.signal.get_window("hann", win, fftbins=True)
+    # power mel spectrogram through THEIR framing (centre, reflect pad) and filterbank, dB through THEIR conversion ...
+    theirs_db = AU.spectrogram(y, window, frame_length=win, hop_length=hop, fft_length=win, power=2.0, center=True,
+                               pad_mode="reflect", mel_filters=fb, mel_floor=1e-10, log_mel="dB", reference=1.0,
+                               min_value=1e-10, db_range=80.0, dtype=np.float64)                 # [mels][frames]
+    # ... against the oracle's own stages on the same samples (mfcc_and_deltas's body without the reference's pad / trim)
+    ypad = np.pad(y, win // 2, mode="reflect")
+    n_frames = 1 + (len(ypad) - win) // hop
+    frames = np.stack([ypad[f * hop:f * hop + win] * window for f in range(n_frames)])
+    mel = (np.abs(np.fft.rfft(frames, n=win, axis=1)) ** 2) @ ours.T
+    db = 10.0 * np.log10(np.maximum(1e-10, mel))
+    db = np.maximum(db, db.max() - 80.0)
+    assert theirs_db.shape == db.T.shape
+    assert np.abs(theirs_db - db.T).max() < 1e-8 * np.abs(db).max()
+
+
 def test_oracle_frame_arithmetic():
     """mfcc.py:47-72 for the 400 / 160 analysis window: 40 zeros of left pad, one frame trimmed on each side, and the
     frame counts SURVEY's configuration table lists (11 760 samples -> 72 frames, 6 960 -> 42)."""
