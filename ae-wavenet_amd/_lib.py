@@ -307,6 +307,7 @@ def load():
                                        C.POINTER(C.c_int), C.c_int]
     lib.aew_probe_box.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.aew_nt_chain_dep_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.aew_gemm_nt_small_split.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler), (8, Tuning),
                        (9, NtStage), (10, NtChain)):
         want = lib.aew_sizeof(which)
@@ -360,4 +361,4 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_set_lanes", "aew_set_tn_cursor", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nt_small_waves", "aew_set_nf_deep", "aew_set_nf_loaders", "aew_set_nt_rows192",
            "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_set_fn_ring3", "aew_set_nt_small_n64", "aew_tn_group_check", "aew_set_nt_mem128", "aew_set_nt_deep", "aew_tuning_default", "aew_tuning_get",
-           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned", "aew_nt_chain_build", "aew_nt_chain_dep_tiles", "aew_probe_box")
+           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned", "aew_nt_chain_build", "aew_nt_chain_dep_tiles", "aew_probe_box", "aew_gemm_nt_small_split")

@@ -1018,7 +1018,12 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wm = wave / WN;
     const int n_mt = (g.M + Cfg::BM - 1) / Cfg::BM, n_nt = g.N_pad / Cfg::BN;
-    const int L = blockIdx.x, seq = L >> 3;                  // XCD-aware order, see k_gemm_nt_bf16
+    // split-K of a small launch (aew_gemm_nt_t.k_split, the 64 x 64 shape only: see the seam below): the grid is ks copies of
+    // the tile grid, copy sp contracts K tiles [kt0, kt0 + n_tiles)
+    const int ks = (S == 5 && MT == 1 && WN == 1 && g.k_split > 1) ? g.k_split : 1;
+    const int grid1 = (int)gridDim.x / ks;
+    const int sp = (int)blockIdx.x / grid1;
+    const int L = (int)blockIdx.x - sp * grid1, seq = L >> 3;                  // XCD-aware order, see k_gemm_nt_bf16
     const int rt = (seq / n_nt) * 8 + (L & 7);
     if (rt >= n_mt * g.batch) return;
     const int b = rt / n_mt;
@@ -1027,7 +1032,7 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
         const int64_t last = (int64_t)(min(m0 + Cfg::BM, g.M) - 1) * g.out1.row_step + g.out1.row_off;
         if (last < g.out1.row_lo) return;
     }
-    const int n_tiles = g.K_total / 64;
+    const int n_tiles = g.K_total / 64 / ks, kt0 = sp * n_tiles;
     f32x4_t acc[4][MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1042,7 +1047,7 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
         const int lr = lane >> 3, pos = lane & 7;
         const int lanerow = (lr >> 2) * 8 + (lr & 3);                 // lane part of nt_wperm for 8-row pieces
         const int r0 = wave * 8 + lr;                                 // LDS row of piece j = 0 (swizzle is the same for j > 0)
-        P.w = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + lanerow) * g.K_total * 2 + ((pos ^ ((r0 >> 1) & 7)) << 4);
+        P.w = reinterpret_cast<const char*>(g.W) + ((int64_t)(n0 + lanerow) * g.K_total + (int64_t)kt0 * 64) * 2 + ((pos ^ ((r0 >> 1) & 7)) << 4);
 #pragma unroll
         for (int j = 0; j < Cfg::WP; ++j) {
             const int p = wave + Cfg::NW * j;                         // slab = p >> 3, piece in slab = p & 7
@@ -1051,7 +1056,14 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
     }
     static_assert(Cfg::NW % 2 == 0, "W pieces of a wave must share the row parity");
     int seg = 0, left = g.seg[0].k_len / 64, issued = 0;
-    p64_setup_x<Cfg::XP>(g, 0, b, m0, wave, lane, P);
+    {   // the segment and the K tile inside it where this workgroup's range starts (kt0 = 0 without split-K)
+        int skip = kt0;
+        while (skip >= left) { skip -= left; ++seg; left = g.seg[seg].k_len / 64; }
+        p64_setup_x<Cfg::XP>(g, seg, b, m0, wave, lane, P);
+#pragma unroll
+        for (int j = 0; j < Cfg::XP; ++j) P.x[j] += skip * 128;     // (masked rows stream the zero region: they advance too)
+        left -= skip;
+    }
     bool idle = false;
     auto issue_piece = [&](char* stage, int j) {                     // j < XP: X piece, else W piece
         if (j < Cfg::XP) {
@@ -1066,7 +1078,7 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
         P.w += 128;
         --left;
         ++issued;
-        if (left == 0) {                                             // wave-uniform and rare
+        if (left == 0 || issued == n_tiles) {                        // wave-uniform and rare (a split-K range may end inside a segment)
             if (issued >= n_tiles) {
                 idle = true;
 #pragma unroll
@@ -1141,6 +1153,45 @@ __global__ __launch_bounds__((P64Cfg<MT, WM, WN>::THREADS), 2) void k_gemm_nt_bf
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    if (ks > 1) {
+        // Split-K seam of a small launch (the upsampler / encoder dgrads: 16-112 workgroups of a lone block's fill latency
+        // each, on a chip of 256 CUs): per WAVE, as in k_gemm_nt_f32.  The wave's accumulators go to slab sp in a private
+        // per-lane layout (the same lane of the same wave of the same tile holds the same outputs in every copy) with
+        // write-through stores; after they have drained one lane takes a device-scope ticket; the wave that draws the last
+        // ticket of its sub-tile reads the ks partials back device-scope, adds them in ascending order of sp - a fixed
+        // order: deterministic results - and runs the epilogue.  No waiting.
+        const int64_t per_wave = 4 * MT * 64;                                   // f32x4 per wave
+        char* wsb = reinterpret_cast<char*>(g.ksplit_ws);
+        const int64_t mine = (((int64_t)sp * grid1 + L) * Cfg::NW + wave) * per_wave + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                store16_wt(wsb + (mine + (int64_t)(i * MT + j) * 64) * 16,
+                           (u32x4_t){__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]), __float_as_uint(acc[i][j][2]),
+                                     __float_as_uint(acc[i][j][3])});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* tk = g.ksplit_tickets + (int64_t)L * Cfg::NW + wave;
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t != (unsigned)(ks - 1)) return;
+        if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc(g.ksplit_ws);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < ks; ++q) {
+                    const int64_t at = ((((int64_t)q * grid1 + L) * Cfg::NW + wave) * per_wave + (int64_t)(i * MT + j) * 64 + lane) * 16;
+                    const uint4 v = ld16_sc1(rs, (uint32_t)at);
+                    const f32x4_t pq = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                    sum = q == 0 ? pq : sum + pq;
+                }
+                acc[i][j] = sum;
+            }
+    }
     nt_epilogue<EPI, false, MT>(g, acc, b, m0, n0, wm, wn, lane);
 }
 
@@ -2336,6 +2387,40 @@ static bool fn_supported(const aew_gemm_nt_t& g);
 static int launch_fn(const aew_gemm_nt_t& g, hipStream_t st);
 extern int g_fn_enable_flag();
 
+// the 64 x 64 shape of launches of very few blocks (see the p64 kernel's table): does the launcher take it for g, under
+// the calling thread's tuning record?  *blocks = its grid (one K range)
+static bool nt_small64(const aew_gemm_nt_t& g, int* blocks) {
+    if (g.dtype != AEW_BF16 || g.impl != 0 || g.N_pad % 128) return false;
+    for (int s = 0; s < g.n_segs; ++s)
+        if (g.seg[s].k_len * 2 > AEW_ZERO_SPAN) return false;
+    const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
+    const bool p64r = AEW_T().nt_wave_rows == 64 && AEW_T().nt_small_tiles > 0 && tiles256 <= AEW_T().nt_small_tiles;
+    if (!(p64r && AEW_T().nt_small_w8 && AEW_T().nt_small_n64 > 0 &&
+          ((g.M + 63) / 64) * g.batch * (g.N_pad / 128) <= AEW_T().nt_small_n64))
+        return false;
+    const int row_tiles = ((g.M + 63) / 64) * g.batch;
+    *blocks = ((row_tiles + 7) / 8) * 8 * (g.N_pad / 64);
+    return true;
+}
+
+extern "C" int aew_gemm_nt_small_split(const aew_gemm_nt_t* g, int target_blocks, int* k_split, int64_t* ws_bytes, int* n_tickets) {
+    if (!g || !k_split || !ws_bytes || !n_tickets) return AEW_E_ARG;
+    *k_split = 1;
+    *ws_bytes = 0;
+    *n_tickets = 0;
+    int blocks = 0;
+    if (!nt_small64(*g, &blocks)) return 0;
+    const int kt = g->K_total / 64;
+    int best = 1;
+    for (int S = 2; S <= 8; ++S)                             // at least four K tiles per range: the ring is five deep
+        if (kt % S == 0 && kt / S >= 4 && blocks * S <= target_blocks) best = S;
+    if (best == 1) return 0;
+    *k_split = best;
+    *ws_bytes = (int64_t)best * blocks * (P64Cfg<1, 4, 1>::NW * 4 * 64 * 16);
+    *n_tickets = blocks * P64Cfg<1, 4, 1>::NW;
+    return 0;
+}
+
 static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
     if (g.n_segs < 1 || g.n_segs > AEW_MAX_SEGS || g.M <= 0 || g.batch <= 0 || !g.W) return AEW_E_ARG;
     if (g.W2) {
@@ -2439,11 +2524,20 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             if (dwp) return launch_win(g, dwp, t192, st);
         }
         // 64 x 64 tiles for launches of very few 64 x 128 blocks (see the p64 kernel's table)
-        const bool p64n = p64r && AEW_T().nt_small_w8 && AEW_T().nt_small_n64 > 0 &&
-                          ((g.M + 63) / 64) * g.batch * (g.N_pad / 128) <= AEW_T().nt_small_n64;
+        int blocks64 = 0;
+        const bool p64n = nt_small64(g, &blocks64);
         const int bm = p64r ? 64 : ((p128 || t128) ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : ((wide || deep2) ? 256 : NT_BN));
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
+        // split-K of a small launch: honoured by the 64 x 64 shape (every other shape contracts the whole K axis; the
+        // plan's slabs then stay unused).  bf16 has no canonical order to keep: the partial sums are added in ascending order
+        if (g.k_split > 1 && p64n && !(AEW_FN_ABLATE && g.reserved)) {
+            const int64_t need = (int64_t)g.k_split * grid.x * (P64Cfg<1, 4, 1>::NW * 4 * 64 * 16);
+            if (g.k_split > 8 || g.K_total % (64 * g.k_split) || !g.ksplit_ws || !g.ksplit_tickets || ((uintptr_t)g.ksplit_ws & 15) ||
+                need > 0x7fffffff)
+                return AEW_E_ARG;
+            grid.x *= g.k_split;
+        }
 #define AEW_NT_GO(EPI, ABL)                                                                                   \
     do {                                                                                                      \
         if (!ABL && deep2)                                                                                     \

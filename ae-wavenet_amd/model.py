@@ -19,7 +19,7 @@ from . import geometry as G
 from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC, exact_split_args,
                      TAG_LOSS, TAG_MISC, TAG_PACK, TAG_VQ, bottleneck_param_specs,
                      decoder_param_specs, encoder_param_specs)
-from .plan import CopyTableBuilder, Mat, Plan, Workspace, insert_nt_chains, make_nt, make_tn, null_view, ru
+from .plan import CopyTableBuilder, Mat, Plan, Workspace, insert_nt_chains, make_nt, make_tn, null_view, ru, split_small_nt
 
 MEAN_LOSS = {"none": True, "ae": True, "vae": True, "vqvae": False, "vqvae-ema": False}
 
@@ -39,6 +39,8 @@ class TrainEngine:
     DIAG_LANE = 3             # codebook diagnostics (behind vq.ema on the same lane; read at the end of the forward)
     LANE_PACK_DEC = 1         # side lane of the decoder's forward-layout weight pack (joined by the end of fwd_a) ...
     pack_dec_late = True      # the decoder's weight pack at the head of fwd_b instead of fwd_a (see build: data-parallel overlap)
+    small_split = 0           # > 0: bf16 NT launches of few 64 x 64 blocks contract K as up to 8 ranges on separate workgroups, as
+                              # long as ranges x blocks stays at or under this (aew_gemm_nt_t.k_split hint, plan.split_small_nt)
     merge_packs = None        # True: all weight-layout packs of a step as ONE copy-table launch at the head of fwd_a (three launches
                               # fewer: 6.837 -> 6.802 ms per step interleaved, r05).  None = on unless the process is a rank of a
                               # data-parallel group: there the decoder's pack stays at the head of fwd_b (pack_dec_late), so that
@@ -449,6 +451,11 @@ class TrainEngine:
         # (mel gradient statistics: its input is the last thing the backward writes)
         moments(self.enc.dy[0] if self.enc is not None else self.dec.dlc_src, self.n_mel, 0, "mel")
         self.unpack_tbl.emit(bw, "unpack grads", join=True)        # reads the side-lane encoder wgrad slabs
+        # launches of a few dozen 64 x 64 blocks (the upsampler / encoder data gradients): split-K hint
+        self.small_split_made = []
+        if int(self.small_split) > 0 and impl == 0:
+            for pl in (fa, fb, bw):
+                self.small_split_made += split_small_nt(pl, ws, "ks." + pl.name, int(self.small_split))
         # Deferred EMA (data parallel): the EMA accumulators are not read again before the codebook
         # refresh, so the cross-rank sum of z_sum | n_sum can run asynchronously under the whole
         # decoder forward + backward; fwd_b_noema / ema_plan are fwd_b without / only its leading vq.ema op

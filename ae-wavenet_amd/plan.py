@@ -347,6 +347,26 @@ class TnGroupBuilder:
         return plan.add(L.OP_GEMM_TN_GROUP, gp, label, tag, join=join)
 
 
+def split_small_nt(plan: "Plan", ws: Workspace, name: str, target_blocks: int = 256) -> List[Tuple[str, int]]:
+    """Split-K hint for the bf16 NT ops of `plan` that launch a few dozen 64 x 64 blocks on 256 CUs (aew_gemm_nt_t.k_split;
+    aew_gemm_nt_small_split states which and how far: wavenet.py:275 / wave_encoder.py:39 backward - the upsampler and
+    encoder data gradients).  Allocates each op's partial-sum slabs and tickets.  Returns [(label, S)]."""
+    lib = L.load()
+    out = []
+    for op, lab in zip(plan.ops, plan.labels):
+        if op.kind != L.OP_GEMM_NT or op.u.nt.dtype != L.BF16 or op.u.nt.impl != 0 or op.u.nt.k_split > 1:
+            continue
+        S, nbytes, ntk = C.c_int(1), C.c_int64(0), C.c_int(0)
+        L.check(lib.aew_gemm_nt_small_split(C.byref(op.u.nt), int(target_blocks), C.byref(S), C.byref(nbytes), C.byref(ntk)), "small_split")
+        if S.value < 2:
+            continue
+        wsb = ws.alloc(f"{name}.{lab}.ws", nbytes.value // 4, torch.float32)
+        tk = ws.alloc(f"{name}.{lab}.tickets", ntk.value, torch.int32, zero=True)
+        op.u.nt.k_split, op.u.nt.ksplit_ws, op.u.nt.ksplit_tickets = S.value, wsb.data_ptr(), tk.data_ptr()
+        out.append((lab, S.value))
+    return out
+
+
 def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: int = 0, force: bool = False,
                      spin_max: int = 0, flags: int = 0, max_stage_tiles: int = 0) -> List[Tuple[int, int]]:
     """Chained NT launches (AEW_OP_NT_CHAIN, aewavenet.h): runs of consecutive main-lane bf16 NT ops of `plan` whose label

@@ -146,7 +146,17 @@ typedef struct {
      * This IS the canonical summation order of the op (oracle/exact_chain.c: aewo_conv_cl ksplit), chosen so that the
      * 180-block launches of the encoder (232-560 rows in all) become 720 blocks with a quarter of the serial K loop each.
      * ksplit_ws: device fp32 [S][rows_pad][N_pad], rows_pad = M * batch rounded up to 32; ksplit_tickets: device uint32
-     * [tiles of 16 rows x 16 channels rounded up], ZERO before the first launch (the combine resets them).  0 / 1 = off. */
+     * [tiles of 16 rows x 16 channels rounded up], ZERO before the first launch (the combine resets them).  0 / 1 = off.
+     *
+     * AEW_BF16, impl 0: a HINT for launches of very few workgroups - the upsampler / encoder data gradients,
+     * 16-112 blocks of 64 x 64 on 256 CUs, each a lone block's LDS fill latency long (wavenet.py:275, wave_encoder.py:39
+     * backward).  k_split = S in 2..8 with K_total a multiple of 64 * S: the launch becomes S copies of its tile grid, copy s
+     * contracting K tiles [s, s + 1) * K_total / 64 / S; the partial accumulators meet in ascending order of s (a fixed
+     * order: results are deterministic, but NOT those of the unsplit launch - bf16 operands, fp32 accumulation, the same
+     * tolerance class) in the workgroup that arrives last.  Honoured only where the launcher takes its 64 x 64 shape under
+     * the tuning record in force (else the whole K axis is contracted by one workgroup, the slabs stay unused);
+     * aew_gemm_nt_small_split() states the rule and the sizes: ksplit_ws = ws_bytes bytes (16-byte aligned),
+     * ksplit_tickets = n_tickets uint32, zero before the first launch.                                                   */
     int32_t k_split;
     int32_t pad2_;
     float* ksplit_ws;
@@ -555,6 +565,11 @@ int aew_nt_chain_build(const aew_gemm_nt_t* descs, int n, aew_nt_stage_t* stages
 /* Producer row tiles consumer tile (first row m0 of the 256-row tile) of `stage` waits for through dependency `dep`:
  * [*t_lo, *t_hi] (empty if *t_lo > *t_hi).  The kernel uses the same arithmetic; exported for tests. */
 int aew_nt_chain_dep_tiles(const aew_nt_stage_t* stage, int dep, int m0, int* t_lo, int* t_hi);
+
+/* Split-K hint for a small bf16 launch (aew_gemm_nt_t.k_split): *k_split = the largest S in 2..8 the launcher would honour
+ * for g under the calling thread's tuning record with S * blocks <= target_blocks and at least four 64-channel K tiles per
+ * range, or 1 (leave g alone); *ws_bytes / *n_tickets = what ksplit_ws / ksplit_tickets must then hold.  Host-only.   */
+int aew_gemm_nt_small_split(const aew_gemm_nt_t* g, int target_blocks, int* k_split, int64_t* ws_bytes, int* n_tickets);
 
 /* ---------------------------------------------------------------------------------------
  * plan

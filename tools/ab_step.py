@@ -56,7 +56,7 @@ def main():
 
     def owner(k):                                  # E.tiled: the copy-table builder's switch; everything else DecoderPlan's
         from ae_wavenet_amd import plan as PLN
-        if k.startswith("LANE_") or k in ("merge_packs", "graph_lanes", "pack_dec_late", "nt_chain", "nt_chain_bwd", "nt_chain_bwd_phase", "nt_chain_force", "nt_chain_flags"):
+        if k.startswith("LANE_") or k in ("merge_packs", "graph_lanes", "pack_dec_late", "small_split", "nt_chain", "nt_chain_bwd", "nt_chain_bwd_phase", "nt_chain_force", "nt_chain_flags"):
             from ae_wavenet_amd import model as MDL
             return MDL.TrainEngine
         if k == "k_split":                         # (timing only: the oracle's canonical order is EncoderPlan.k_split's default)
