@@ -576,16 +576,18 @@ class CopyTableBuilder:
             # slower tiled and left element-wise: B < 32 (the gate-permuted 16-wide runs: decoder pack 52 -> 67 us) and
             # the tap <-> channel (de)interleaves inside a row, whose short strides the element-wise forms already
             # cover (k x 256 tiles: decoder pack / unpack 59 -> 85 / 49 -> 76 us).
-            ta = A if A <= 8 else (16 if A <= 16 else 32)
-            tb = fit(B, pow2_le(1024 // ta))
+            cap = CopyTableBuilder.tile_cap
+            ta = A if A <= 8 else (16 if A <= 16 else (32 if (A <= 32 or cap < 4096) else 64))
+            tb = fit(B, pow2_le(min(cap // ta, (4160 if cap >= 4096 else 1600) // (ta | 1))))     # (LDS pitch ta | 1)
         else:
             return None
-        assert ta * tb <= 1024 and tb * (ta | 1) <= 1600
+        assert ta * tb <= 4096 and tb * (ta | 1) <= 4160
         outer = [i for i in range(4) if i not in (a, b)]
         outer.sort(key=lambda i: dims[i] > 1)                      # size-1 dims first
         order = outer + [b, a]
         return [dims[i] for i in order], [ss[i] for i in order], [ds[i] for i in order], ta, tb
 
+    tile_cap = 4096           # elements per LDS tile of a transposing record (1024: the round-3 tiles, 4 loads per thread in flight)
     interleave = True         # tap <-> channel (de)interleaves as register permutations (False: element-wise forms; A/B)
 
     @staticmethod

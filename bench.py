@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--n-win", dest="n_win", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box", action="store_true",
+                    help="skip the box fingerprint (profiling passes: its ~450 probe launches would sit in the kernel tables)")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--jitter-prob", dest="jitter_prob", type=float, default=0.12, help="par/train.basic.json")
     ap.add_argument("--lanes", type=int, default=0, help="1: every side-lane op on its own stream / graph branch (default 0: plan order, except the tail branch below)")
@@ -441,7 +443,7 @@ def main():
         return dt
 
     box = None
-    if rank == 0:
+    if rank == 0 and not args.no_box:
         try:
             box = box_record(lib, eng, device)
         except Exception as e:                                   # never lose the bench line

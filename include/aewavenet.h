@@ -252,8 +252,8 @@ typedef struct {
     float scale;
     int32_t first_block;         /* filled by the host: first block of this record (1024 elements per block, or one
                                     tile in the tiled form)                                                       */
-    int32_t tr_a, tr_b;          /* tr_a > 0: tiled form, tile extents along dims[3] / dims[2] (tr_a * tr_b <= 1024,
-                                    tr_b * (tr_a | 1) <= 1600); tr_a < 0: interleave forms; 0 = element-wise      */
+    int32_t tr_a, tr_b;          /* tr_a > 0: tiled form, tile extents along dims[3] / dims[2] (tr_a * tr_b <= 4096,
+                                    tr_b * (tr_a | 1) <= 4160); tr_a < 0: interleave forms; 0 = element-wise      */
 } aew_copy_rec_t;
 
 typedef struct {

@@ -61,7 +61,7 @@ def main():
             return MDL.TrainEngine
         if k == "k_split":                         # (timing only: the oracle's canonical order is EncoderPlan.k_split's default)
             return E.EncoderPlan
-        return PLN.CopyTableBuilder if k in ("tiled", "interleave") else E.DecoderPlan
+        return PLN.CopyTableBuilder if k in ("tiled", "interleave", "tile_cap") else E.DecoderPlan
 
     def engine_for(ekey):
         if ekey not in engines:

@@ -9,12 +9,12 @@ R=$GRAFT_REPO_ROOT; TAG=${1:-rXX}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 cd $R
 python bench.py --steps 30 --warmup 5 --per-op $O/per_op_ms.txt > $O/bench.json 2> $O/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 0 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-box --lanes 0 > $O/stats.log 2>&1
 # the same with every GEMM as its own launch (chained launches off): the per-kernel durations of rounds 1-4, for continuity
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_serial -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 0 --nt-chain 0 > $O/stats_serial.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --lanes 0 > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_serial -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-box --lanes 0 --nt-chain 0 > $O/stats_serial.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-box > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-box > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-box --lanes 0 > $O/pmc_sq.log 2>&1
 python - <<PY
 import csv, glob, collections, shutil
 O = "$O"
