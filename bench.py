@@ -210,7 +210,19 @@ def box_record(lib, eng, device):
     L.check(lib.aew_probe_box(scratch.data_ptr(), scratch.numel(), nbytes, C.c_void_p(st), out), "aew_probe_box")
     rec["mfma_bf16_tflops"] = round(float(out[0]), 1)
     rec["copy_90MB_TBps"] = round(float(out[1]), 3)
-    del scratch
+    # the same copy 600 times back to back (~15 ms of full memory load), the last 400 timed: the burst figure above is equal
+    # to 1 % on boxes whose step differs by 4 % (round 5: 6.63 .. 6.89 ms)
+    a, b = scratch[:nbytes], scratch[nbytes:]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(200):
+        b.copy_(a)
+    e0.record()
+    for _ in range(400):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    rec["sustained_copy_TBps"] = round(2 * nbytes * 400 / (1e-3 * e0.elapsed_time(e1)) / 1e12, 3)
+    del a, b, scratch
     for name in ("G1.2", "G2.2"):
         fb = eng.fwd_b
         if name not in fb.labels:
