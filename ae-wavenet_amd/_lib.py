@@ -77,7 +77,8 @@ class NtStage(C.Structure):
 
 class NtChain(C.Structure):
     _fields_ = [("stages", vp), ("block_stage", vp), ("counters", vp), ("n_stages", i32), ("n_blocks", i32),
-                ("n_counters", i32), ("set", i32), ("n_ops", i32), ("spin_max", i32), ("flags", i32), ("pad_", i32)]
+                ("n_counters", i32), ("set", i32), ("n_ops", i32), ("spin_max", i32), ("flags", i32), ("built_window", i32),
+                ("sticky", vp)]
 
 
 class CopyRec(C.Structure):
@@ -103,7 +104,7 @@ class VqStats(C.Structure):
 class VqEma(C.Structure):
     _fields_ = [("numer", vp), ("denom", vp), ("z_sum", vp), ("n_sum", vp), ("emb", vp),
                 ("K", i32), ("d", i32), ("update_codebook", i32), ("gamma", f32),
-                ("gamma_comp", f32)]
+                ("gamma_comp", f32), ("guard", vp)]
 
 
 class VqBwd(C.Structure):
@@ -136,13 +137,13 @@ class SpkBwd(C.Structure):
                 ("off_proj_sig", vp), ("off_proj_gate", vp), ("off_spk_w", i64),
                 ("off_spk_b", i64), ("B", i32), ("L", i32), ("D", i32), ("D_pad", i32),
                 ("C_lc", i32), ("G", i32), ("n_speakers", i32), ("colsum", vp), ("gc", vp),
-                ("grads", vp), ("colsum_running", i32), ("layer_range", i32)]
+                ("grads", vp), ("colsum_running", i32), ("layer_range", i32), ("det_scratch", vp), ("det_tickets", vp)]
 
 
 class Tuning(C.Structure):
     """aew_tuning_t: kernel-shape choices as a record (the aew_set_* switches edit the process-wide one; Plan.run(...,
     tuning=...) / aew_run_plan_tuned apply a caller's own to one call)."""
-    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("nt_chain", i32), ("reserved_", i32 * 7)]
+    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("nt_chain", i32), ("deterministic", i32), ("reserved_", i32 * 6)]
 
 
 class BaseGather(C.Structure):
@@ -161,7 +162,7 @@ class SoftmaxNll(C.Structure):
 
 class Colsum(C.Structure):
     _fields_ = [("x", Seg), ("dtype", i32), ("M", i32), ("N", i32), ("batch", i32),
-                ("out", vp), ("out_bs", i64), ("accumulate", i32)]
+                ("out", vp), ("out_bs", i64), ("accumulate", i32), ("pad_", i32), ("det_scratch", vp), ("det_tickets", vp)]
 
 
 class Reduce(C.Structure):
@@ -173,7 +174,7 @@ class Reduce(C.Structure):
 class Adam(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("lr", f32),
                 ("beta1", f32), ("beta2", f32), ("eps", f32), ("bc1", f32), ("bc2", f32),
-                ("grad_scale", f32)]
+                ("grad_scale", f32), ("pad_", i32), ("guard", vp)]
 
 
 class Zero(C.Structure):
@@ -305,16 +306,19 @@ def load():
         fn.argtypes = [C.c_void_p]
     lib.aew_nt_chain_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int), C.c_int]
+    lib.aew_nt_chain_build_tuned.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int), C.c_int, C.c_void_p]
     lib.aew_probe_box.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.aew_nt_chain_dep_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.aew_gemm_nt_small_split.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    lib.aew_colsum_det_size.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     for which, cls in ((0, Op), (1, GemmNT), (2, GemmTN), (3, Seg), (4, View), (5, CopyRec), (6, Actor), (7, Sampler), (8, Tuning),
                        (9, NtStage), (10, NtChain)):
         want = lib.aew_sizeof(which)
         if want != C.sizeof(cls):
             raise AewError(f"ABI mirror drift: sizeof({cls.__name__}) = {C.sizeof(cls)} in Python, "
                            f"{want} in the library")
-    if lib.aew_abi_version() != 19:
+    if lib.aew_abi_version() != 20:
         raise AewError("ABI version mismatch")
     _lib = lib
     return lib
@@ -361,4 +365,4 @@ EXPORTS = ("aew_abi_version", "aew_sizeof", "aew_run_plan", "aew_timing_enable",
            "aew_set_lanes", "aew_set_tn_cursor", "aew_set_nt_wave_rows", "aew_set_nt_pipe",
            "aew_set_tn_target_blocks", "aew_set_tn_small", "aew_set_nt_small_tiles", "aew_set_nt_small_deep", "aew_set_nt_small_waves", "aew_set_nf_deep", "aew_set_nf_loaders", "aew_set_nt_rows192",
            "aew_sampler_run", "aew_set_fn", "aew_nt_kernel", "aew_set_tn_big", "aew_set_nt_window", "aew_set_fn_ring3", "aew_set_nt_small_n64", "aew_tn_group_check", "aew_set_nt_mem128", "aew_set_nt_deep", "aew_tuning_default", "aew_tuning_get",
-           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned", "aew_nt_chain_build", "aew_nt_chain_dep_tiles", "aew_probe_box", "aew_gemm_nt_small_split")
+           "aew_tuning_set", "aew_run_plan_tuned", "aew_graph_capture_tuned", "aew_nt_chain_build", "aew_nt_chain_dep_tiles", "aew_probe_box", "aew_gemm_nt_small_split", "aew_colsum_det_size", "aew_nt_chain_build_tuned")

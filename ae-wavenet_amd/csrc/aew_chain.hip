@@ -46,7 +46,8 @@ __host__ __device__ __forceinline__ void chain_dep_tiles(const aew_chain_dep_t& 
 template <int SET>
 __global__ __launch_bounds__(CHAIN_THREADS, 4) void k_nt_chain(const aew_nt_stage_t* __restrict__ stages,
                                                               const uint16_t* __restrict__ block_stage,
-                                                              unsigned* counters, int n_counters, int spin_max, int flags) {
+                                                              unsigned* counters, int n_counters, int spin_max, int flags,
+                                                              unsigned* sticky) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int s = __builtin_amdgcn_readfirstlane((int)block_stage[blockIdx.x >> 3]);
     const aew_nt_stage_t& S = stages[s];
@@ -80,7 +81,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 4) void k_nt_chain(const aew_nt_stag
                     if (!ok) ok = __hip_atomic_load(counters + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
                     if (__all(ok)) break;
                     if (++spins >= spin_max) {                // a producer that never arrives: report, run on
-                        if (tid == 0) __hip_atomic_store(counters + n_counters, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (tid == 0) {
+                            __hip_atomic_store(counters + n_counters, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // ... and in the word no launch clears: the optimizer's guard (aew_adam_t.guard) - the step does
+                            // not reach the parameters, and the host finds it whenever it looks next
+                            if (sticky) __hip_atomic_fetch_max(sticky, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         break;
                     }
                     // (once any wait of the launch has given up the others do not sit out their own limit)
@@ -187,6 +193,14 @@ static int chain_desc_ok(const aew_gemm_nt_t& g, int force) {
         return AEW_E_UNSUP;
     if (g.epi == AEW_EPI_STORE && (g.flags & (AEW_EF_OUT2_COPY | AEW_EF_COUNT_ZERO))) return AEW_E_UNSUP;
     if (!g.out0.ptr) return AEW_E_ARG;
+    // a chained stage loads its epilogue operands through a raw buffer resource with a 32-bit byte offset from the view's
+    // base (ld16_sc1): a view whose extent reaches 2 GiB would read zeros (out of range) or a wrapped address
+    for (const aew_view_t* v : {&g.aux0, &g.aux1}) {
+        if (!v->ptr) continue;
+        const int64_t rows = v->row_hi > 0 ? v->row_hi : 0;
+        const int64_t extent = ((int64_t)(g.batch - 1) * v->batch_stride + rows * v->row_pitch) * (v->dtype == AEW_BF16 ? 2 : 4);
+        if (extent < 0 || extent > 0x7fffffffLL) return AEW_E_UNSUP;
+    }
     const aew_tuning_t& T = AEW_T();
     if (T.nt_wave_rows != 64 || T.nt_mem128 || T.nt_deep) return AEW_E_UNSUP;          // an A/B shape is selected
     const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
@@ -344,6 +358,18 @@ extern "C" int aew_nt_chain_build(const aew_gemm_nt_t* descs, int n, aew_nt_stag
     return 0;
 }
 
+// The same under a caller's tuning record (the record the launches will run under: it decides which stages take the one-window
+// body and which launches count as small) instead of the process-wide one.
+extern "C" int aew_nt_chain_build_tuned(const aew_gemm_nt_t* descs, int n, aew_nt_stage_t* out, uint16_t* block_stage,
+                                        int cap_blocks, int* n_blocks_out, int* n_counters_out, int* set_out, int force,
+                                        const aew_tuning_t* tuning) {
+    const aew_tuning_t* prev = t_tune;
+    if (tuning) t_tune = tuning;
+    const int rc = aew_nt_chain_build(descs, n, out, block_stage, cap_blocks, n_blocks_out, n_counters_out, set_out, force);
+    t_tune = prev;
+    return rc;
+}
+
 static int launch_nt_chain(const aew_nt_chain_t& c, hipStream_t st) {
     if (!c.stages || !c.block_stage || !c.counters || c.n_stages < 1 || c.n_blocks < 8 || (c.n_blocks & 7) || c.n_counters < 1 ||
         (c.set != 0 && c.set != 1))
@@ -358,9 +384,9 @@ static int launch_nt_chain(const aew_nt_chain_t& c, hipStream_t st) {
     const int spin = c.spin_max > 0 ? c.spin_max : (1 << 18);
     if (c.set == 0)
         hipLaunchKernelGGL((k_nt_chain<0>), dim3(c.n_blocks), dim3(CHAIN_THREADS), CHAIN_LDS_BYTES, st, c.stages, c.block_stage,
-                           c.counters, c.n_counters, spin, c.flags);
+                           c.counters, c.n_counters, spin, c.flags, c.sticky);
     else
         hipLaunchKernelGGL((k_nt_chain<1>), dim3(c.n_blocks), dim3(CHAIN_THREADS), CHAIN_LDS_BYTES, st, c.stages, c.block_stage,
-                           c.counters, c.n_counters, spin, c.flags);
+                           c.counters, c.n_counters, spin, c.flags, c.sticky);
     return (int)hipGetLastError();
 }

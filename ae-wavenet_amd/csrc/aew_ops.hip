@@ -489,6 +489,7 @@ __global__ __launch_bounds__(256) void k_vq_stats_few(const aew_vq_stats_t p) {
 __global__ void k_vq_ema(const aew_vq_ema_t p) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)p.K * p.d) return;
+    if (p.guard && *p.guard) return;
     const int k = (int)(e / p.d), j = (int)(e % p.d);
     const float nu = __fadd_rn(__fmul_rn(p.gamma, p.numer[e]), __fmul_rn(p.gamma_comp, p.z_sum[e]));
     const float de = __fadd_rn(__fmul_rn(p.gamma, p.denom[k]), __fmul_rn(p.gamma_comp, p.n_sum[k]));
@@ -502,6 +503,7 @@ __global__ void k_vq_ema(const aew_vq_ema_t p) {
 __global__ void k_vq_ema_denom(const aew_vq_ema_t p) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= p.K) return;
+    if (p.guard && *p.guard) return;
     p.denom[k] = __fadd_rn(__fmul_rn(p.gamma, p.denom[k]), __fmul_rn(p.gamma_comp, p.n_sum[k]));
 }
 
@@ -509,7 +511,7 @@ __global__ void k_vq_ema_denom(const aew_vq_ema_t p) {
 //   scaled_l2: dist = u/v, u = ||z-q||, v = ||z|| + ||q||
 //       d dist/dz = (z-q)/(u v) - u z / (v^2 ||z||)
 //   sq_l2:     d dist/dz = 2 (z-q);  VQ also gets d/d(emb) of the l2 term (vq_bn.py:78)
-__global__ __launch_bounds__(256) void k_vq_bwd(const aew_vq_bwd_t p) {
+__global__ __launch_bounds__(256) void k_vq_bwd(const aew_vq_bwd_t p, int det) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= p.Q) return;
@@ -533,9 +535,33 @@ __global__ __launch_bounds__(256) void k_vq_bwd(const aew_vq_bwd_t p) {
             if (p.metric == 0) dj = (u > 0.f ? t / (u * v) : 0.f) - (zn > 0.f ? u * z[j] / (v * v * zn) : 0.f);
             else dj = 2.0f * t;
             gr = p.dzq[(int64_t)q * p.d_pitch + j] + coef * dj;
-            if (p.demb) atomicAdd(p.demb + k * p.d + j, demb_coef * (-2.0f * t));
+            if (p.demb && !det) atomicAdd(p.demb + k * p.d + j, demb_coef * (-2.0f * t));
         }
         p.dze[(int64_t)q * p.d_pitch + j] = gr;
+    }
+    if (p.demb && det) {
+        // d/d(emb[k]) sums over the queries that chose code k.  Deterministic form: the wave of the FIRST such query adds
+        // the terms of all of them in ascending query order and is the only writer of row k (pre-zeroed by the caller).
+        bool first = true;
+        for (int c0 = 0; c0 < q && first; c0 += 64) {
+            const int i = c0 + lane;
+            if (__any(i < q && p.ind[i] == k)) first = false;
+        }
+        if (!first) return;
+        for (int j0 = 0; j0 < p.d; j0 += 64) {
+            const int j = j0 + lane;
+            float acc = 0.f;
+            for (int c0 = q & ~63; c0 < p.Q; c0 += 64) {
+                const int i = c0 + lane;
+                unsigned long long m = __ballot(i >= q && i < p.Q && p.ind[i] == k);
+                while (m) {
+                    const int qi = c0 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (j < p.d) acc += demb_coef * (-2.0f * (p.ze[(int64_t)qi * p.d_pitch + j] - c[j]));
+                }
+            }
+            if (j < p.d) p.demb[k * p.d + j] += acc;
+        }
     }
 }
 
@@ -568,6 +594,43 @@ __global__ void k_lc_gather(const aew_lc_gather_t p) {
         }
     }
     p.dst[(int64_t)b * p.dst_bs + (int64_t)t * p.dst_pitch + c] = f2bf(v);
+}
+
+// Gather form of the scatter (deterministic, no atomics, no pre-zeroed target): one thread per element of dsrc adds the
+// rows t whose jitter index points at it, t ascending.  N is the number of conditioning vectors of a window (29 at
+// w = 5000, ~210 at w = 65536), so the scan is a few hundred broadcast loads per thread.
+__global__ void k_lc_scatter_det(const aew_lc_scatter_t p) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.N * p.C;
+    if (e >= total) return;
+    const int c = (int)(e % p.C);
+    const int j = (int)((e / p.C) % p.N);
+    const int bq = (int)(e / ((int64_t)p.C * p.N));
+    float acc = 0.f;
+    if (!p.take_compat) {
+        const int64_t* jit = p.jitter + (int64_t)bq * p.jit_pitch;
+        const float* d = p.d + (int64_t)bq * p.d_bs + c;
+        for (int t = 0; t < p.N; ++t) {
+            int64_t jj = jit[t];
+            jj = jj < 0 ? 0 : (jj > p.N - 1 ? p.N - 1 : jj);
+            if (jj == j) acc += d[(int64_t)t * p.d_pitch];
+        }
+    } else {
+        // torch.take flattening (SURVEY C-1): flat = b * N + jitter lands on (flat / (C N), flat % N, (flat / N) % C) =
+        // (b / C, jitter, b % C) for every channel of row t, so element (bq, j, c) collects batch element b = bq C + c
+        const int64_t b = (int64_t)bq * p.C + c;
+        if (b < p.B) {
+            const int64_t* jit = p.jitter + b * p.jit_pitch;
+            for (int t = 0; t < p.N; ++t) {
+                int64_t jj = jit[t];
+                jj = jj < 0 ? 0 : (jj > p.N - 1 ? p.N - 1 : jj);
+                if (jj != j) continue;
+                const float* d = p.d + b * p.d_bs + (int64_t)t * p.d_pitch;
+                for (int cc = 0; cc < p.C; ++cc) acc += d[cc];
+            }
+        }
+    }
+    p.dsrc[(int64_t)bq * p.dsrc_bs + (int64_t)j * p.dsrc_pitch + c] = acc;
 }
 
 __global__ void k_lc_scatter(const aew_lc_scatter_t p) {
@@ -618,7 +681,7 @@ __global__ void k_spk_bias(const aew_spk_bias_t p) {
 
 #define AEW_SPK_MAXB 16
 #define AEW_SPK_MAXG 16
-__global__ void k_spk_bwd(const aew_spk_bwd_t p) {
+__global__ void k_spk_bwd(const aew_spk_bwd_t p, int det) {
     // grid (L, 2, ceil(B / 16)): one block per (layer, filt|gate, chunk of 16 batch elements); thread = output channel co.
     //   phase 1: everything a thread needs from global memory is fetched up front (column sums of dfg per batch
     //            element, its row of the speaker projection); it writes its bias / projection gradients and leaves
@@ -692,10 +755,40 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p) {
         }
         __syncthreads();
     }
-    // speaker embedding grads accumulate over layers -> global atomics (caller zeroes them)
-    if (pb < nb) {
-        atomicAdd(p.grads + p.off_spk_w + (int64_t)pj * p.n_speakers + p.voice[b0 + pb], dgc);
-        if (p.off_spk_b >= 0) atomicAdd(p.grads + p.off_spk_b + pj, dgc);
+    // speaker embedding grads accumulate over layers (caller zeroes them)
+    if (!det) {                                                   // fp32 atomics: the order of the 2 L terms is the schedule's
+        if (pb < nb) {
+            atomicAdd(p.grads + p.off_spk_w + (int64_t)pj * p.n_speakers + p.voice[b0 + pb], dgc);
+            if (p.off_spk_b >= 0) atomicAdd(p.grads + p.off_spk_b + pj, dgc);
+        }
+        return;
+    }
+    // Deterministic form: every block leaves its [batch element][embedding column] terms write-through, takes a ticket,
+    // and the block that draws the last one adds them - layer ascending, filt before gate, and batch elements ascending
+    // where they share a speaker row - as the only writer of the speaker-embedding gradients.
+    const int nl = gridDim.x, nz = gridDim.z;
+    float* mine = p.det_scratch + (((int64_t)blockIdx.x * 2 + half) * nz + blockIdx.z) * (AEW_SPK_MAXB * AEW_SPK_MAXG);
+    if (pb < nb) __hip_atomic_store(mine + pb * AEW_SPK_MAXG + pj, dgc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned ticket;
+    if (tid == 0) ticket = __hip_atomic_fetch_add(p.det_tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(nl * 2 * nz) - 1u) return;
+    if (tid == 0) __hip_atomic_store(p.det_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (tid < p.G) {                                              // thread = embedding column j
+        float bsum = 0.f;
+        for (int bb = 0; bb < p.B; ++bb) {
+            const int z = bb / AEW_SPK_MAXB, rb = bb - z * AEW_SPK_MAXB;
+            float t = 0.f;
+            for (int li = 0; li < nl; ++li)
+                for (int h = 0; h < 2; ++h)
+                    t += __hip_atomic_load(p.det_scratch + (((int64_t)li * 2 + h) * nz + z) * (AEW_SPK_MAXB * AEW_SPK_MAXG) +
+                                           rb * AEW_SPK_MAXG + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.grads[p.off_spk_w + (int64_t)tid * p.n_speakers + p.voice[bb]] += t;
+            bsum += t;
+        }
+        if (p.off_spk_b >= 0) p.grads[p.off_spk_b + tid] += bsum;
     }
 }
 
@@ -865,7 +958,7 @@ __global__ __launch_bounds__(256) void k_softmax_nll(const aew_softmax_nll_t p) 
 // W = columns per lane: 8 (bf16, 16-byte loads) or 4 (fp32).  A block covers 64*W columns and
 // `rows_per_chunk` rows; its 4 waves stride the rows with 4 independent loads in flight each.
 template <int W>
-__global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_per_chunk) {
+__global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_per_chunk, int det) {
     __shared__ float sh[4][64 * W];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // narrow matrices (N <= 32 W): `lpr` lanes cover a row and a wave takes G = 64 / lpr rows per load (128 bf16
@@ -913,9 +1006,41 @@ __global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_p
 #pragma unroll
     for (int r = 0; r < W; ++r) sh[wv][lane * W + r] = (lane < lpr) ? s[r] : 0.f;
     __syncthreads();
+    if (!det) {
+        for (int c = threadIdx.x; c < 64 * W; c += 256) {
+            const int cc = blockIdx.x * (64 * W) + c;
+            if (cc < p.N) atomicAdd(p.out + (int64_t)b * p.out_bs + cc, sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c]);
+        }
+        return;
+    }
+    // Deterministic form: the partial sums of this (batch element, row chunk) leave write-through, the block takes a
+    // ticket of its output - one output per column block when the batch elements share it (out_bs == 0), one per
+    // (column block, batch element) otherwise - and the last arriver adds all partials in a fixed order (batch element
+    // ascending, chunk ascending): one summation order whatever the schedule, and a single writer per output.
+    const int nchunk = gridDim.z, nb = gridDim.y, ncb = gridDim.x;
+    float* mine = p.det_scratch + (((int64_t)b * nchunk + blockIdx.z) * ncb + blockIdx.x) * (64 * W);
+    for (int c = threadIdx.x; c < 64 * W; c += 256)
+        __hip_atomic_store(mine + c, sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool shared_out = p.out_bs == 0;
+    unsigned* tk = p.det_tickets + (shared_out ? blockIdx.x : blockIdx.x * nb + b);
+    const unsigned want = (unsigned)(shared_out ? nb * nchunk : nchunk) - 1u;
+    __shared__ unsigned ticket;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != want) return;
+    if (threadIdx.x == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    const int b_lo = shared_out ? 0 : b, b_hi = shared_out ? nb : b + 1;
     for (int c = threadIdx.x; c < 64 * W; c += 256) {
         const int cc = blockIdx.x * (64 * W) + c;
-        if (cc < p.N) atomicAdd(p.out + (int64_t)b * p.out_bs + cc, sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c]);
+        if (cc >= p.N) continue;
+        float tot = 0.f;
+        for (int bb = b_lo; bb < b_hi; ++bb)
+            for (int ch = 0; ch < nchunk; ++ch)
+                tot += __hip_atomic_load(p.det_scratch + (((int64_t)bb * nchunk + ch) * ncb + blockIdx.x) * (64 * W) + c,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.out[(int64_t)b * p.out_bs + cc] += tot;
     }
 }
 
@@ -1016,6 +1141,7 @@ __global__ __launch_bounds__(1024) void k_moments(const aew_moments_t p) {
 __global__ void k_adam(const aew_adam_t a) {
     const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= a.n) return;
+    if (a.guard && *a.guard) return;                   // a chained launch of this step gave up a wait: parameters stay
     const float inv_sqrt_bc2 = rsqrtf(a.bc2);
     const float step = a.lr / a.bc1;
     if (i4 + 4 <= a.n) {
@@ -1632,14 +1758,19 @@ static int launch_vq_ema(const aew_vq_ema_t& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 static int launch_vq_bwd(const aew_vq_bwd_t& p, hipStream_t st) {
-    hipLaunchKernelGGL(k_vq_bwd, dim3(cdiv64(p.Q, 4)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_vq_bwd, dim3(cdiv64(p.Q, 4)), dim3(256), 0, st, p, AEW_T().deterministic ? 1 : 0);
     return (int)hipGetLastError();
 }
 static int launch_lc_gather(const aew_lc_gather_t& p, hipStream_t st) {
     hipLaunchKernelGGL(k_lc_gather, dim3(cdiv64((int64_t)p.B * p.N * p.C_pad, 256)), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
+#define AEW_LC_SCATTER_DET_MAXN 4096
 static int launch_lc_scatter(const aew_lc_scatter_t& p, hipStream_t st) {
+    if (p.N <= AEW_LC_SCATTER_DET_MAXN) {                      // every element of dsrc[b][j][0:C] is written: no zeroing needed
+        hipLaunchKernelGGL(k_lc_scatter_det, dim3(cdiv64((int64_t)p.B * p.N * p.C, 256)), dim3(256), 0, st, p);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_lc_scatter, dim3(cdiv64((int64_t)p.B * p.N * p.C, 256)), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
@@ -1651,8 +1782,9 @@ static int launch_spk_bwd(const aew_spk_bwd_t& p, hipStream_t st) {
     if (p.G > AEW_SPK_MAXG || p.B < 1) return AEW_E_UNSUP;     // (engine.DecoderPlan refuses such a model at build time)
     const int l0 = p.layer_range & 0xffff, ln = p.layer_range ? (p.layer_range >> 16) & 0x7fff : p.L;
     if (ln < 1 || l0 + ln > p.L) return AEW_E_ARG;
+    const int det = AEW_T().deterministic && p.det_scratch && p.det_tickets;
     hipLaunchKernelGGL(k_spk_bwd, dim3(ln, 2, (p.B + AEW_SPK_MAXB - 1) / AEW_SPK_MAXB), dim3(256),
-                       (AEW_SPK_MAXB * p.G + (AEW_SPK_MAXB + p.G) * 257) * sizeof(float), st, p);
+                       (AEW_SPK_MAXB * p.G + (AEW_SPK_MAXB + p.G) * 257) * sizeof(float), st, p, det);
     return (int)hipGetLastError();
 }
 static int launch_base_gather(const aew_base_gather_t& p, hipStream_t st) {
@@ -1696,6 +1828,15 @@ static int launch_softmax(const aew_softmax_nll_t& p, hipStream_t st) {
     hipLaunchKernelGGL(k_softmax_nll, dim3(cdiv64((int64_t)p.B * p.w, 4)), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
+static void colsum_grid(const aew_colsum_t& p, int& rpc, int& chunks, int& ncb) {
+    rpc = 64;                                                // rows per block: 16 per wave, 4 loads in flight
+    const int W = p.dtype == AEW_BF16 ? 8 : 4;
+    int lpr = 64;                                            // narrow matrices: G rows per wave-load (see k_colsum)
+    if (p.N <= 64 * W) { while (lpr > 1 && (lpr >> 1) * W >= p.N) lpr >>= 1; }
+    rpc = 64 * (64 / lpr);
+    chunks = (p.M + rpc - 1) / rpc;
+    ncb = (int)cdiv64(p.N, 64 * W);
+}
 static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
     if (!p.accumulate) {
         // contiguous or shared outputs are cleared with one memset; strided per-batch outputs one
@@ -1706,21 +1847,25 @@ static int launch_colsum(const aew_colsum_t& p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
         }
     }
-    int rpc = 64;                                            // rows per block: 16 per wave, 4 loads in flight
-    {                                                        // narrow matrices: G rows per wave-load (see k_colsum)
-        const int W = p.dtype == AEW_BF16 ? 8 : 4;
-        int lpr = 64;
-        if (p.N <= 64 * W) { while (lpr > 1 && (lpr >> 1) * W >= p.N) lpr >>= 1; }
-        rpc = 64 * (64 / lpr);
-    }
-    const int chunks = (p.M + rpc - 1) / rpc;
+    int rpc, chunks, ncb;
+    colsum_grid(p, rpc, chunks, ncb);
+    const int det = AEW_T().deterministic && p.det_scratch && p.det_tickets;
     if (p.dtype == AEW_BF16) {
         if ((p.x.row_pitch % 8) || ((uintptr_t)p.x.ptr & 15) || (p.x.batch_stride % 8)) return AEW_E_ALIGN;
-        hipLaunchKernelGGL(k_colsum<8>, dim3(cdiv64(p.N, 512), p.batch, chunks), dim3(256), 0, st, p, rpc);
+        hipLaunchKernelGGL(k_colsum<8>, dim3(ncb, p.batch, chunks), dim3(256), 0, st, p, rpc, det);
     } else {
-        hipLaunchKernelGGL(k_colsum<4>, dim3(cdiv64(p.N, 256), p.batch, chunks), dim3(256), 0, st, p, rpc);
+        hipLaunchKernelGGL(k_colsum<4>, dim3(ncb, p.batch, chunks), dim3(256), 0, st, p, rpc, det);
     }
     return (int)hipGetLastError();
+}
+extern "C" int aew_colsum_det_size(const aew_colsum_t* c, int64_t* floats, int32_t* tickets) {
+    if (!c || !floats || !tickets || c->M < 0 || c->N < 1 || c->batch < 1) return AEW_E_ARG;
+    int rpc, chunks, ncb;
+    colsum_grid(*c, rpc, chunks, ncb);
+    const int W = c->dtype == AEW_BF16 ? 8 : 4;
+    *floats = (int64_t)c->batch * (chunks > 0 ? chunks : 1) * ncb * 64 * W;
+    *tickets = ncb * c->batch;
+    return 0;
 }
 static int launch_reduce(const aew_reduce_t& p, hipStream_t st) {
     if (p.n_terms < 1 || p.n_terms > 4) return AEW_E_ARG;

@@ -168,7 +168,9 @@ static int run_ops(const aew_op_t* ops, int n, hipStream_t st, int* fail_index, 
             for (int k = 1; k <= c.n_ops && rc == 0; ++k)
                 if (ops[i + k].kind != AEW_OP_GEMM_NT || ops[i + k].lane != lane || (k > 1 && ops[i + k].join)) rc = AEW_E_ARG;
             if (rc != 0) { if (fail_index) *fail_index = i; break; }
-            if (timing != 1 && AEW_T().nt_chain && c.stages) {           // (timing 2: the chain is timed as ONE op)
+            // (a record whose one-window limit differs from the one the stage table was built under would make the chain run
+            // other kernels - another summation order - than the stage ops: those then run one by one)
+            if (timing != 1 && AEW_T().nt_chain && c.stages && c.built_window == AEW_T().nt_window) {   // (timing 2: the chain is timed as ONE op)
                 rc = ensure_big_lds();
                 if (rc == 0) rc = launch_nt_chain(c, target);
                 skip = c.n_ops;
@@ -217,7 +219,7 @@ static void tune_clamp(aew_tuning_t& t) {
     if (t.nt_wave_rows != 0 && t.nt_wave_rows != 1 && t.nt_wave_rows != 64 && t.nt_wave_rows != 128 && t.nt_wave_rows != 256)
         t.nt_wave_rows = 64;
     cl(t.nt_pipe, 0, 2); cl(t.nt_rows192, 0, 2); cl(t.nt_window, 0, 64); cl(t.nt_mem128, 0, 2); cl(t.nt_deep, 0, 3);
-    cl(t.lanes, 0, 2); if (t.tn_cursor_epoch > 0) { cl(t.tn_cursor_epoch, 3, 64); cl(t.tn_cursor_slack, 1, 8); } else if (t.tn_cursor_epoch < 0) t.tn_cursor_epoch = -1; cl(t.nt_small_w8, 0, 1); cl(t.nt_chain, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
+    cl(t.lanes, 0, 2); if (t.tn_cursor_epoch > 0) { cl(t.tn_cursor_epoch, 3, 64); cl(t.tn_cursor_slack, 1, 8); } else if (t.tn_cursor_epoch < 0) t.tn_cursor_epoch = -1; cl(t.nt_small_w8, 0, 1); cl(t.nt_chain, 0, 1); cl(t.deterministic, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
     cl(t.nt_small_tiles, 0, 1 << 30); cl(t.nt_small_n64, 0, 1 << 30); cl(t.nt_small_deep, 0, 1 << 30); cl(t.nf_deep, 0, 1 << 30);
     cl(t.fn_ring3, 0, 1 << 30); cl(t.tn_big_target, 1, 1 << 30); cl(t.tn_fold_rows, 0, 1 << 30); cl(t.tn_target_blocks, 1, 1 << 30);
     cl(t.tn_small_tiles, 0, 1 << 30); cl(t.tn_small_target, 1, 1 << 30);

@@ -92,6 +92,35 @@ class DataParallel:
             self._bufs[key] = t
         return t
 
+    # ---- the chained launches' sticky timeout word (TrainEngine.chain_guard) --------------------------------------------
+    def _guard_sync(self, eng):
+        """A hand-off wait that gave up on ONE rank poisons that rank's gradients - and through the exchange everybody's.
+        The guard word the Adam / EMA ops read is therefore MAX-reduced over the ranks in front of the first gradient
+        collective of a step (4 bytes, asynchronous, completes before the gradients do: same communicator, issue order),
+        so every rank skips the update of such a step, not only the one that saw the timeout."""
+        if self._solo() or getattr(eng, "chain_guard", None) is None or not eng._chain_flags():
+            return
+        self._guard_work = dist.all_reduce(eng.chain_guard[:1], op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+
+    def _guard_wait(self):
+        w, self._guard_work = getattr(self, "_guard_work", None), None
+        if w is not None:
+            self._wait(w, "chain.guard")
+
+    def _warn_merged_packs(self, eng):
+        """TrainEngine.merge_packs = None resolves at engine construction from the torch.distributed state; an engine built
+        BEFORE init_process_group packs every weight layout at the head of the first forward plan, and the decoder's
+        parameter all-gather can then not stay in flight under the encoder forward (_late() is False).  Results are the
+        same; the overlap is lost - say so once."""
+        if self.world > 1 and self.sharded and getattr(eng, "merge_packs", False) and getattr(eng, "merge_packs_auto", False) \
+                and not getattr(self, "_warned_packs", False):
+            import warnings
+            self._warned_packs = True
+            warnings.warn("ae_wavenet_amd.dp: the engine was built before torch.distributed was initialised, so it packs all weight "
+                          "layouts in ONE launch at the head of the forward (TrainEngine.merge_packs); the decoder's parameter "
+                          "all-gather is then not overlapped with the encoder forward.  Build the model after "
+                          "init_process_group, or set TrainEngine.merge_packs = False.")
+
     def grad_scale(self, mean_loss: bool) -> float:
         """Factor the optimizer applies to the summed gradient: 1/world reproduces the
         single-process gradient of a mean-type loss over the global batch; sum-type losses
@@ -118,6 +147,8 @@ class DataParallel:
         flat = eng.ps.grads[:eng.ps.numel]
         if self._solo():
             return
+        self._guard_sync(eng)
+        self._guard_wait()
         n = flat.numel()
         for s in range(0, n, self.bucket_elems):
             dist.all_reduce(flat[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group)
@@ -137,11 +168,13 @@ class DataParallel:
         work = []
 
         def after_decoder():
+            self._guard_sync(eng)
             work.append(dist.all_reduce(flat[lo:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
         eng.backward(after_decoder=after_decoder)
         if lo > 0:
             work.append(dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._guard_wait()
         for w in work:
             w.wait()
 
@@ -162,6 +195,7 @@ class DataParallel:
         self.finish()                       # parameter all-gathers of a preceding sharded step
 
         def after_decoder():
+            self._guard_sync(eng)
             work["dec"] = dist.all_reduce(flat[lo:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
         eng.forward(self.allreduce_ema_async)
@@ -169,6 +203,7 @@ class DataParallel:
         eng.backward(after_decoder=after_decoder)
         if lo > 0:
             work["enc"] = dist.all_reduce(flat[:lo], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._guard_wait()
         self._wait(work["dec"], "grads.decoder")
         eng.adam_step(lr, grad_scale, lo=lo, hi=n, **adam_kw)
         if lo > 0:
@@ -257,6 +292,7 @@ class DataParallel:
         """The forward of a sharded step: the encoder part starts as soon as ITS parameters are complete, the decoder's
         all-gather is waited for between the two forward plans."""
         late = self._late(eng)
+        self._warn_merged_packs(eng)
         self.finish("head" if late else None)
         return eng.forward(self.allreduce_ema_async, before_decoder=self.finish if late else None)
 
@@ -269,9 +305,12 @@ class DataParallel:
         st = {"hi": hi}
 
         def after_decoder_hi():
+            self._guard_sync(eng)
             st["dec_hi"] = self._reduce_region(flat, hi, n, bf16_grads)
 
         def after_decoder():
+            if "dec_hi" not in st:
+                self._guard_sync(eng)
             st["dec"] = self._reduce_region(flat, lo, n if "dec_hi" not in st else hi, bf16_grads)
 
         self.allreduce_kl(eng)
@@ -294,6 +333,7 @@ class DataParallel:
         # right behind it.  Otherwise the decoder's all-gather is issued at once and runs under the head's Adam.
         late = self._late(eng)
         dec_gathers = [] if late else None
+        self._guard_wait()
         if "dec_hi" in st:                               # the upper layers' region: reduced under the rest of the chain
             for w in st["dec_hi"][0]:
                 self._wait(w, "grads.decoder_hi")

@@ -622,6 +622,13 @@ class DecoderPlan:
         sb.B, sb.L, sb.D, sb.D_pad, sb.C_lc, sb.G = self.B, self.NL, self.D, self.Dp, self.Clc, self.Gc
         sb.n_speakers = self.hps.n_speakers
 
+    def _spk_det(self, sb: "L.SpkBwd", tag: str):
+        """Scratch + ticket of the deterministic speaker-embedding sums (aew_spk_bwd_t.det_scratch: one [16][16] block of terms
+        per (layer, filt | gate, chunk of 16 batch elements), added in a fixed order by the last block)."""
+        chunks = (self.B + 15) // 16
+        sb.det_scratch = self.ws.alloc(self.pre + f"det.spk_{tag}.scratch", self.NL * 2 * chunks * 256, torch.float32).data_ptr()
+        sb.det_tickets = self.ws.alloc(self.pre + f"det.spk_{tag}.tickets", 4, torch.int32, zero=True).data_ptr()
+
     def _softmax(self, backward: bool, scale: float) -> L.SoftmaxNll:
         sm = L.SoftmaxNll()
         sm.logits, sm.bs, sm.pitch = self.logits.ptr, self.logits.bs, self.logits.pitch
@@ -643,6 +650,7 @@ class DecoderPlan:
         cs.x = X.seg(128, row_off=row_off)
         cs.dtype, cs.M, cs.N, cs.batch = X.dtype, M, N, self.B
         cs.out, cs.out_bs, cs.accumulate = out_ptr, out_bs, 1      # target pre-zeroed by the plan
+        det_colsum(self.ws, cs, self.pre + "det." + label)
         with plan.side(self._next_lane()):
             plan.add(L.OP_COLSUM, cs, label, TAG_MISC)
 
@@ -856,6 +864,7 @@ class DecoderPlan:
                         sb_hi.colsum, sb_hi.gc, sb_hi.grads = self.colsum_fg.data_ptr(), self.gc.data_ptr(), ps.grads.data_ptr()
                         sb_hi.colsum_running = NL
                         sb_hi.layer_range = l | ((NL - l) << 16)
+                        self._spk_det(sb_hi, "hi")
                         self._spk_hi_from = l
                         with plan.side(1):
                             plan.add(L.OP_SPK_BWD, sb_hi, "spk_bwd (upper layers)", TAG_MISC, join=True)
@@ -926,6 +935,7 @@ class DecoderPlan:
             sbw.colsum_running = max(0, NL - self.wgrad_split_layers) if snap_ok else 0
             if getattr(self, "_spk_hi_from", None):                    # the upper layers were done after the first group
                 sbw.layer_range = 0 | (self._spk_hi_from << 16)
+            self._spk_det(sbw, "lo")
             with plan.side(tail or 1):                                 # reads the side lanes' wgrad slabs: side join
                 colsum_tbl.emit(plan, "colsum.dfg (from wgrad column R)", join=True)
                 plan.add(L.OP_SPK_BWD, sbw, "spk_bwd", TAG_MISC, join=not colsum_tbl.recs)
@@ -1002,7 +1012,8 @@ class DecoderPlan:
                                        [dlc1.seg(Cp, row_off=-t) for t in range(3)], self.WlcT.ptr,
                                        out0=self.dlcj.view(), impl=impl), "d.lc_conv", TAG_UPS)
         # ---- jitter scatter back to the LC source
-        plan.zero(self.ws, self.dlc_src.name)
+        if self.Ne > 4096:                                         # (up to 4096 conditioning vectors per window the scatter runs in
+            plan.zero(self.ws, self.dlc_src.name)                  #  its gather form, which writes every element: no atomics, no zeroing)
         sc = L.LcScatter()
         sc.d, sc.d_bs, sc.d_pitch = self.dlcj.ptr, self.dlcj.bs, self.dlcj.pitch
         sc.jitter, sc.jit_pitch = self.jitter.data_ptr(), self.jitter.shape[1]
@@ -1014,6 +1025,17 @@ class DecoderPlan:
 # ------------------------------------------------------------------------------------------
 # encoder + bottleneck (fp32 exact chain)
 # ------------------------------------------------------------------------------------------
+def det_colsum(ws: Workspace, cs: "L.Colsum", name: str):
+    """Scratch + tickets of the deterministic form of a column-sum op (aew_colsum_t.det_scratch / det_tickets: partial sums per
+    row chunk, added in a fixed order by the last arriver - no fp32 atomics).  The tickets start at zero and every launch
+    leaves them at zero."""
+    import ctypes as _C
+    nf, nt = _C.c_int64(0), _C.c_int32(0)
+    L.check(L.load().aew_colsum_det_size(_C.byref(cs), _C.byref(nf), _C.byref(nt)), "aew_colsum_det_size")
+    cs.det_scratch = ws.alloc(name + ".scratch", max(4, nf.value), torch.float32).data_ptr()
+    cs.det_tickets = ws.alloc(name + ".tickets", max(4, nt.value), torch.int32, zero=True).data_ptr()
+
+
 def exact_split_args(ws: Workspace, name: str, S: int, cin: int, k_total: int, rows: int, n_pad: int) -> dict:
     """make_nt keywords for the split-K form of an exact fp32 GEMM (aew_gemm_nt_t.k_split): S contiguous k-ranges on
     separate workgroups, combined in a fixed order - the canonical summation order of the op, oracle/exact.py ksplit_for

@@ -69,6 +69,7 @@ class TrainEngine:
                               # hand-off (write-through stores, one acquire per tile) is not free.  0 = no limit
     nt_chain_force = False    # tests: chain also the sizes the stand-alone launcher runs on its small-launch shapes
     nt_chain_flags = 0        # aew_nt_chain_t.flags (measurement aids)
+    nt_chain_spin_max = 0     # polls before a hand-off wait gives up (0: the library's 1 << 18, ~0.3 s)
     diag_early = True         # per-step diagnostics placed where their inputs become final (False: at the tail of the
                               # forward plan; A/B: 8.02 -> 7.99 ms per step)
 
@@ -91,7 +92,8 @@ class TrainEngine:
                 else DecoderPlan.wgrad_group
         self.wgrad_group = int(wgrad_group)
         self.tuning = tuning              # _lib.Tuning (aew_tuning_t) for this engine's launches, or None
-        if self.merge_packs is None:
+        self.merge_packs_auto = self.merge_packs is None          # (dp.DataParallel warns when an automatic choice went the
+        if self.merge_packs is None:                              #  wrong way: engine built before init_process_group)
             import torch.distributed as _dist
             self.merge_packs = not (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1)
         self.kind = hps.global_model
@@ -126,6 +128,9 @@ class TrainEngine:
         # without a host sync and without touching the captured graphs
         self.gmul = ws.alloc("loss.gmul", 4, torch.float32)
         self.gmul[:1].fill_(1.0)
+        # STICKY word of the chained launches (aew_nt_chain_t.sticky): no plan clears it; a hand-off wait that gave up leaves
+        # (stage + 1) here, and the optimizer / EMA ops read it as their guard - the step does not reach the parameters
+        self.chain_guard = ws.alloc("chain.guard", 4, torch.int32)
         # ---- tables
         # encoder / bottleneck tables stay on the main lane (their packed weights are needed at once and
         # their gradients come last); the decoder's are side-lane work: its weight pack overlaps the
@@ -261,6 +266,7 @@ class TrainEngine:
                     em.K, em.d, em.update_codebook = self.K, self.d, 0
                     em.gamma = float(hps.bn_vq_ema_gamma)
                     em.gamma_comp = float(1.0 - hps.bn_vq_ema_gamma)
+                    em.guard = self.chain_guard.data_ptr()
                     # EMA runs at the START of part B (after the optional cross-rank sum); the
                     # codebook refresh is deferred to after backward so that forward and backward
                     # of one step see the same emb
@@ -347,12 +353,17 @@ class TrainEngine:
         # AEW_NT_CHAIN = "f" or "f,b": stages per chained launch of the forward / backward (A/B and bisecting aid)
         env = os.environ.get("AEW_NT_CHAIN")
         n_f, n_b = int(self.nt_chain), int(self.nt_chain_bwd)
-        if env is not None:
-            v = [int(x) for x in env.split(",")]
-            n_f, n_b = v[0], (v[1] if len(v) > 1 else 0)
+        if env is not None and env.strip():
+            try:
+                v = [int(x) for x in env.split(",") if x.strip()]
+            except ValueError:
+                raise ValueError(f"AEW_NT_CHAIN={env!r}: expected 'f' or 'f,b' (stages per chained launch, forward / backward)")
+            if v:
+                n_f, n_b = v[0], (v[1] if len(v) > 1 else 0)
         self.nt_chain_used = n_f if impl == 0 else 0
         self.nt_chain_bwd_used = n_b if impl == 0 else 0
-        ckw = dict(force=bool(self.nt_chain_force), flags=int(self.nt_chain_flags), max_stage_tiles=int(self.nt_chain_max_stage_tiles))
+        ckw = dict(force=bool(self.nt_chain_force), flags=int(self.nt_chain_flags), max_stage_tiles=int(self.nt_chain_max_stage_tiles),
+                   sticky_ptr=self.chain_guard.data_ptr(), tuning=self.tuning, spin_max=int(self.nt_chain_spin_max))
         if self.nt_chain_used >= 2:
             insert_nt_chains(fb, ws, "chain.fwd", lambda lab: lab.startswith(("G1.", "G2.", "post1", "post2")), max_len=self.nt_chain_used, **ckw)
         red = L.Reduce()
@@ -517,6 +528,7 @@ class TrainEngine:
             em.z_sum, em.n_sum, em.emb = z0.data_ptr(), z0.data_ptr(), self.emb.data_ptr()
             em.K, em.d, em.update_codebook = self.K, self.d, 1
             em.gamma, em.gamma_comp = 1.0, 0.0     # numer/denom unchanged: emb = numer/denom
+            em.guard = self.chain_guard.data_ptr()
             self.cb.add(L.OP_VQ_EMA, em, "vq.codebook", TAG_VQ)
         # pack goes first in fwd_a (its table is complete only now)
         pk_plan = Plan("pack")
@@ -552,6 +564,7 @@ class TrainEngine:
         ad.p, ad.g, ad.m, ad.v = ps.params.data_ptr(), ps.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
         ad.n = ps.numel
         ad.lr, ad.beta1, ad.beta2, ad.eps, ad.bc1, ad.bc2, ad.grad_scale = 1e-4, 0.9, 0.999, 1e-8, 1.0, 1.0, 1.0
+        ad.guard = self.chain_guard.data_ptr()
         self.opt.add(L.OP_ADAM, ad, "adam", TAG_ADAM)
 
     def _vae_op(self, backward: bool, dcode: Optional[Mat] = None) -> L.Vae:
@@ -671,32 +684,74 @@ class TrainEngine:
             self._chain_flag_views = v
         return self._chain_flag_views
 
+    CHAIN_WATCH_SLOTS = 4
+
     def _chain_watch(self, after: str):
         """The bounded spin of a chained launch (csrc/aew_chain.hip) ends a wait whose producer never arrives by setting a
-        flag and letting the tile run on - with operands that may be incomplete.  The flags are copied to pinned host
-        memory asynchronously behind the plan that ran the launches (`after` = "fwd" | "bwd") and looked at before the
-        NEXT forward: no synchronisation, and a launch that gave up raises instead of training on."""
-        flags = self._chain_flags()
-        if not flags or self.device.type != "cuda":
+        flag and letting the tile run on - with operands that may be incomplete.  Two things keep such a step from
+        training on:
+        * on the DEVICE the wait also raises the engine's sticky word (`chain_guard`, aew_nt_chain_t.sticky), which no plan
+          clears and which the Adam and EMA / codebook ops read as their guard: from the poisoned step on they are no-ops,
+          however far the host has run ahead;
+        * on the HOST the sticky word is copied to pinned memory behind every plan that holds chained launches (`after` =
+          "fwd" | "bwd"; asynchronous) into a ring of CHAIN_WATCH_SLOTS slots; "check" (the head of every forward) looks at
+          every copy that has landed and raises.  A slot is reused only after its copy has been looked at - when the host is
+          a full ring ahead it waits for the oldest copy (by then several plans old) - so no timeout is ever overwritten
+          unseen, and one is reported at most CHAIN_WATCH_SLOTS plans late.  `chain_guard_check()` is the synchronous form
+          for any point where the caller synchronises anyway."""
+        if not self._chain_flags() or self.device.type != "cuda":
             return
         st = getattr(self, "_chain_host", None)
         if st is None:
-            st = self._chain_host = {"buf": torch.zeros(len(flags), dtype=torch.int32).pin_memory(), "ev": torch.cuda.Event(),
-                                     "pending": False}
+            n = self.CHAIN_WATCH_SLOTS
+            st = self._chain_host = {"buf": torch.zeros(n, dtype=torch.int32).pin_memory(),
+                                     "ev": [torch.cuda.Event() for _ in range(n)], "pending": []}
         if after == "check":
-            if st["pending"] and st["ev"].query():
-                st["pending"] = False
-                bad = [flags[i][0] for i in range(len(flags)) if int(st["buf"][i]) != 0]
-                if bad:
-                    raise L.AewError(f"chained launch(es) {bad}: a tile's wait for its producers gave up (aew_nt_chain_t spin "
-                                     "limit) - results of that step are not trustworthy; AEW_NT_CHAIN=0 runs one launch per GEMM")
+            self._chain_poll(False)
             return
-        sel = [i for i, (lab, _) in enumerate(flags) if (lab in getattr(self.bwd, "nt_chains", {})) == (after == "bwd")]
-        for i in sel:
-            st["buf"][i:i + 1].copy_(flags[i][1], non_blocking=True)
-        if sel:
-            st["ev"].record()
-            st["pending"] = True
+        if len(st["pending"]) >= self.CHAIN_WATCH_SLOTS:
+            self._chain_poll(True)
+        used = set(st["pending"])
+        slot = next(i for i in range(self.CHAIN_WATCH_SLOTS) if i not in used)
+        st["buf"][slot:slot + 1].copy_(self.chain_guard[:1], non_blocking=True)
+        st["ev"][slot].record()
+        st["pending"].append(slot)
+
+    def _chain_poll(self, wait_oldest: bool):
+        st = self._chain_host
+        while st["pending"]:
+            slot = st["pending"][0]
+            if not st["ev"][slot].query():
+                if not wait_oldest:
+                    return
+                st["ev"][slot].synchronize()
+            wait_oldest = False
+            st["pending"].pop(0)
+            if int(st["buf"][slot]) != 0:
+                self._chain_raise(int(st["buf"][slot]))
+
+    def _chain_raise(self, stage: int):
+        torch.cuda.synchronize(self.device)
+        bad = [lab for lab, f in self._chain_flags() if int(f.item()) != 0]      # (the per-launch flags of the LAST run)
+        raise L.AewError(f"chained launch: a tile's wait for its producers gave up (aew_nt_chain_t spin limit; sticky word = "
+                         f"stage {stage - 1} + 1; flagged in the last run: {bad}).  The optimizer and EMA updates have been "
+                         "no-ops since that step (device-side guard); parameters are those of the step before.  "
+                         "engine.clear_chain_guard() re-arms; AEW_NT_CHAIN=0 runs one launch per GEMM")
+
+    def chain_guard_check(self):
+        """Synchronous check of the sticky timeout word (for callers that synchronise anyway): raises like forward() would."""
+        if self.device.type == "cuda":
+            v = int(self.chain_guard[0].item())
+            if v:
+                self._chain_raise(v)
+
+    def clear_chain_guard(self):
+        """Re-arm after a reported timeout: clears the sticky word and forgets the copies in flight."""
+        self.chain_guard.zero_()
+        if getattr(self, "_chain_host", None) is not None:
+            torch.cuda.synchronize(self.device)
+            self._chain_host["pending"].clear()
+            self._chain_host["buf"].zero_()
 
     def forward(self, ema_allreduce=None, timing=False, before_decoder=None):
         """timing=True forces eager launches (the per-op event timing needs them).

@@ -368,7 +368,8 @@ def split_small_nt(plan: "Plan", ws: Workspace, name: str, target_blocks: int = 
 
 
 def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: int = 0, force: bool = False,
-                     spin_max: int = 0, flags: int = 0, max_stage_tiles: int = 0) -> List[Tuple[int, int]]:
+                     spin_max: int = 0, flags: int = 0, max_stage_tiles: int = 0, sticky_ptr: int = 0,
+                     tuning: Optional["L.Tuning"] = None) -> List[Tuple[int, int]]:
     """Chained NT launches (AEW_OP_NT_CHAIN, aewavenet.h): runs of consecutive main-lane bf16 NT ops of `plan` whose label
     passes `select` - no join except at the head of the run - get a chain op in front of them that launches the whole
     run as ONE kernel with tile-granular hand-off between the stages (wavenet.py:354-357: the layer loop; its backward).
@@ -378,8 +379,12 @@ def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: in
     - stay as they are.  The counters of all chains of one call share ONE buffer that a single zero op in front of the
     first chain clears (the chain launches then skip their own clearing: aew_nt_chain_t.flags & 2).
     max_stage_tiles > 0: runs whose stages average more 256 x 128 tiles than this stay unchained.
+    sticky_ptr: device word no launch clears; a wait that gives up leaves (stage + 1) there (aew_nt_chain_t.sticky).
+    tuning: the record the plan will RUN under (None: the process-wide one) - the stage table is built under it and a launch
+    under a record with another one-window limit falls back to the stage ops (aew_nt_chain_t.built_window).
     Returns [(index of the chain op, stages)]."""
     lib = L.load()
+    built_window = int((tuning if tuning is not None else L.current_tuning()).nt_window)
     made = []                                              # (first stage index in the ORIGINAL plan, n, stages, bmap, nb, nc, set)
     i = 0
     while i < len(plan.ops):
@@ -404,8 +409,8 @@ def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: in
             cap = sum(((-(-d.M // 256) * d.batch + 7) // 8) * 8 * (d.N_pad // 128) for d in descs)
             bmap = (C.c_uint16 * (cap // 8))()
             nb, nc, st = C.c_int(0), C.c_int(0), C.c_int(0)
-            rc = lib.aew_nt_chain_build(C.byref(descs), n, C.byref(stages), C.byref(bmap), cap, C.byref(nb), C.byref(nc),
-                                        C.byref(st), int(force))
+            rc = lib.aew_nt_chain_build_tuned(C.byref(descs), n, C.byref(stages), C.byref(bmap), cap, C.byref(nb), C.byref(nc),
+                                              C.byref(st), int(force), C.byref(tuning) if tuning is not None else None)
             if rc != L.E_UNSUP:
                 L.check(rc, f"aew_nt_chain_build ({plan.labels[i]} .. {plan.labels[j - 1]})")
                 made.append((i, n, stages, bmap, nb.value, nc.value, st.value))
@@ -438,6 +443,8 @@ def insert_nt_chains(plan: "Plan", ws: Workspace, name: str, select, max_len: in
         ch.stages, ch.block_stage, ch.counters = sd.data_ptr(), md.data_ptr(), cd.data_ptr() + 4 * off
         ch.n_stages, ch.n_blocks, ch.n_counters, ch.set, ch.n_ops, ch.spin_max = n, nb, nc, st, n, spin_max
         ch.flags = flags | 2
+        ch.built_window = built_window
+        ch.sticky = sticky_ptr or None
         first = plan.ops[i]
         cop = L.Op()
         cop.kind, cop.tag, cop.lane, cop.join = L.OP_NT_CHAIN, 0, first.lane, first.join

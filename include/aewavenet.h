@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define AEW_ABI_VERSION 19
+#define AEW_ABI_VERSION 20
 #define AEW_MAX_SEGS 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -294,6 +294,7 @@ typedef struct {                 /* EMA + optional codebook refresh (vqema_bn.py
                                     autoencoder_model.py:171-199)                              */
     int32_t K, d, update_codebook;
     float gamma, gamma_comp;
+    const uint32_t* guard;       /* ABI 20, optional: device word; non-zero = the op does nothing (see aew_adam_t.guard) */
 } aew_vq_ema_t;
 
 typedef struct {                 /* d(ze) = d(zq) + gscale*gamma * d(min_dist)/d(ze)          */
@@ -352,6 +353,11 @@ typedef struct {                 /* backward of the above from per-batch column 
                                     count) only (data parallel with two grouped wgrad launches: the upper layers' bias /
                                     projection gradients right after the first group; the speaker-embedding sums of the
                                     parts add up in `grads`)                                                       */
+    /* ABI 20, deterministic form (aew_tuning_t.deterministic != 0 and both pointers set): the speaker-embedding sums -
+     * one term per (layer, filt | gate) block - go to det_scratch ([count][2][chunks][16][16] floats, count = layers of
+     * this op) and the block that draws the last ticket (det_tickets[0]: zeroed once by the caller, left zero by every
+     * launch) adds them layer ascending, filt before gate, batch element ascending; without it they are fp32 atomics. */
+    float* det_scratch; uint32_t* det_tickets;
 } aew_spk_bwd_t;
 
 typedef struct {                 /* base layer as a column gather (wavenet.py:348-351)        */
@@ -432,6 +438,12 @@ typedef struct {                 /* first two moments of a channels-last view: t
 typedef struct {                 /* column sums over rows: out[b][n] (+)= sum_m x[b][m][n]     */
     aew_seg_t x; int32_t dtype; int32_t M, N, batch;
     float* out; int64_t out_bs; int32_t accumulate;
+    /* ABI 20, deterministic form (aew_tuning_t.deterministic != 0 and both pointers set): the row chunks write their
+     * partial sums to det_scratch (aew_colsum_det_size floats) instead of adding atomically; the block that draws the
+     * last ticket of its output (det_tickets: zeroed once by the caller, left zero by every launch) adds them in a
+     * fixed order - batch element ascending, row chunk ascending - and is the only writer of that output.          */
+    int32_t pad_;
+    float* det_scratch; uint32_t* det_tickets;
 } aew_colsum_t;
 
 typedef struct {                 /* v_i = scale_i * sum(x_i[0:n_i]);  out[1+i] = v_i;
@@ -452,6 +464,10 @@ typedef struct {                 /* fused Adam over a flat fp32 buffer (torch.op
     float lr, beta1, beta2, eps;
     float bc1, bc2;              /* 1-beta1^t, 1-beta2^t                                      */
     float grad_scale;            /* g is multiplied by this first (e.g. 1/world for a mean)   */
+    int32_t pad_;
+    const uint32_t* guard;       /* ABI 20, optional: device word read at launch time; non-zero = the update is a no-op.
+                                    The engine points it at the STICKY word of its chained launches (aew_nt_chain_t.sticky):
+                                    a step in which a hand-off wait gave up does not reach the parameters.              */
 } aew_adam_t;
 
 typedef struct { void* ptr; int64_t bytes; } aew_zero_t;
@@ -552,7 +568,12 @@ typedef struct {
     int32_t flags;                   /* 4 = consumers also issue an agent-scope acquire fence (A/B; the sc1 loads make it redundant);
                                         2 = the caller zeroes `counters` itself before the launch (a plan with several chains:
                                         one AEW_OP_ZERO for all of them) */
-    int32_t pad_;
+    int32_t built_window;            /* ABI 20: aew_tuning_t.nt_window the stage table was built under (it decides which stages
+                                        take the one-window body, i.e. their summation order).  A launch under a record that
+                                        disagrees runs the stage ops one by one instead - the chain never executes another
+                                        kernel than the serial plan would                                                */
+    uint32_t* sticky;                /* ABI 20, optional device word that NO launch clears: a wait that gives up also stores
+                                        (stage + 1) here (atomic max).  aew_adam_t.guard / aew_vq_ema_t.guard read it.    */
 } aew_nt_chain_t;
 
 /* Host logic only.  descs[0..n): the stage descriptors in execution order.  Fills stages_out[n] (host memory; `g` copied
@@ -666,13 +687,20 @@ typedef struct {
     int32_t tn_cursor_epoch;     /* ABI 18: aew_set_tn_cursor */
     int32_t tn_cursor_slack;
     int32_t nt_chain;            /* ABI 19: 1 (default) AEW_OP_NT_CHAIN ops launch their chain, 0 their stage ops run one by one */
-    int32_t reserved_[7];
+    int32_t deterministic;       /* ABI 20: 1 (default) every sum of the training step has ONE order: column sums and the
+                                    speaker-embedding gradient use their ticketed forms where the descriptor carries
+                                    det_scratch / det_tickets; 0 = fp32 atomics (A/B of the cost)                   */
+    int32_t reserved_[6];
 } aew_tuning_t;
 int aew_tuning_default(aew_tuning_t* out);
 int aew_tuning_get(aew_tuning_t* out);
 int aew_tuning_set(const aew_tuning_t* in);          /* replaces the process-wide instance (values are clamped like the setters') */
 int aew_run_plan_tuned(const aew_op_t* ops, int n, void* stream, int* fail_index, const aew_tuning_t* tuning);
 int aew_graph_capture_tuned(const aew_op_t* ops, int n, void** exec_out, int* fail_index, const aew_tuning_t* tuning);
+/* aew_nt_chain_build under `tuning` (NULL: the process-wide record) - pass the record the plan will RUN under (aew_run_plan_tuned) and
+ * store its nt_window in aew_nt_chain_t.built_window. */
+int aew_nt_chain_build_tuned(const aew_gemm_nt_t* descs, int n, aew_nt_stage_t* stages_out, uint16_t* block_stage_out,
+                             int cap_blocks, int* n_blocks, int* n_counters, int* set, int force, const aew_tuning_t* tuning);
 
 /* Box fingerprint (measurement aid): sustained rate of THIS device on a pure bf16 MFMA loop (out[0], TFLOP/s) and on a
  * device-to-device copy of copy_bytes (out[1], TB/s read + written), HIP events on `stream`.  scratch: device memory,
@@ -746,6 +774,9 @@ int aew_tn_slabs(const aew_gemm_tn_t* g);
 /* Validate one descriptor of a grouped launch (aew_gemm_tn_group_t.descs lives in device memory, so the launcher
  * cannot): 0 or AEW_E_*.  Host logic only. */
 int aew_tn_group_check(const aew_gemm_tn_t* g);
+/* What the deterministic form of a column-sum op needs (aew_colsum_t.det_scratch / det_tickets): *floats of scratch,
+ * *tickets words (zeroed once by the caller).  Host logic only; the launcher uses the same arithmetic. */
+int aew_colsum_det_size(const aew_colsum_t* c, int64_t* floats, int32_t* tickets);
 /* 1 if the op's batch loop is folded into one slab per split (short contractions). */
 int aew_tn_fold(const aew_gemm_tn_t* g);
 /* Contraction length (rows x batch) up to which TN ops fold the batch; default 4096. */

@@ -268,7 +268,13 @@ class Emu:
         if p.hist:
             self.wr(p.hist, torch.arange(p.K), self.rd(p.hist, torch.arange(p.K)) + ns)
 
+    def _guarded(self, p) -> bool:
+        """aew_adam_t.guard / aew_vq_ema_t.guard: a non-zero device word turns the op into a no-op"""
+        return bool(p.guard) and int(self.rd(p.guard, torch.arange(1))[0]) != 0
+
     def op_6(self, p):   # VQ_EMA
+        if self._guarded(p):
+            return
         kd = torch.arange(p.K * p.d)
         k = torch.arange(p.K)
         nu = p.gamma * self.rd(p.numer, kd) + p.gamma_comp * self.rd(p.z_sum, kd)
@@ -336,6 +342,11 @@ class Emu:
                + torch.arange(p.C)[None, None, :])
         gsrc = self.rd(p.d, idx)
         t, off = self.flat(p.dsrc)
+        if p.N <= 4096:
+            # gather form (k_lc_scatter_det): every element of dsrc[b][j][0:C] is WRITTEN, the plan does not zero the target
+            tgt = (torch.arange(p.B)[:, None, None] * p.dsrc_bs + torch.arange(p.N)[None, :, None] * p.dsrc_pitch
+                   + torch.arange(p.C)[None, None, :])
+            t[(off + tgt).reshape(-1)] = 0
         t.index_add_(0, (off + bb * p.dsrc_bs + nn * p.dsrc_pitch + cc).reshape(-1), gsrc.reshape(-1).to(t.dtype))
 
     def _spk_common(self, p):
@@ -462,6 +473,8 @@ class Emu:
         t[off] = tot
 
     def op_16(self, a):  # ADAM
+        if self._guarded(a):
+            return
         n = torch.arange(a.n)
         p, g, m, v = (self.rd(x, n) for x in (a.p, a.g, a.m, a.v))
         g = g * a.grad_scale

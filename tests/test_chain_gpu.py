@@ -70,8 +70,8 @@ def test_chained_stack_is_bit_identical_to_one_launch_per_op(monkeypatch, n_chai
         assert l == l_ref, (rep, l, l_ref)
         assert torch.equal(lg, lg_ref), rep
         assert torch.equal(g[mask], g_ref[mask]), rep
-        d = (g[~mask] - g_ref[~mask]).abs().max().item()
-        assert d <= 2e-6 * g_ref[~mask].abs().max().item(), (rep, d)
+        # (ABI 20: the bias-type sums have one order as well - nothing is masked any more)
+        assert torch.equal(g, g_ref), (rep, (g - g_ref).abs().max().item())
     eng.use_graphs = False
     l, lg, g = _step(eng)
     _no_timeouts(eng)
@@ -81,15 +81,15 @@ def test_chained_stack_is_bit_identical_to_one_launch_per_op(monkeypatch, n_chai
     eng.tuning = t
     l, lg, g = _step(eng)
     assert l == l_ref and torch.equal(lg, lg_ref) and torch.equal(g[mask], g_ref[mask])
-    # the engine watches the launches' timeout flags (copied to pinned host memory behind each plan, looked at before the
-    # next forward): a wait that gave up raises instead of training on
+    # the engine watches the launches' STICKY timeout word (copied to pinned host memory behind each plan, looked at before
+    # the next forward): a wait that gave up raises instead of training on (tests/test_trust_gpu.py: with the host ahead)
     eng._chain_watch("check")                                   # nothing pending / nothing set: silent
-    lab, flag = eng._chain_flags()[0]
-    flag.fill_(7)
+    eng.chain_guard[:1].fill_(7)
     eng._chain_watch("fwd")
     torch.cuda.synchronize()
     with pytest.raises(L.AewError, match="gave up"):
         eng._chain_watch("check")
+    eng.clear_chain_guard()
 
 
 @pytest.mark.parametrize("B,w", [(3, 700), (2, 100)])

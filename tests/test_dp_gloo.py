@@ -172,6 +172,15 @@ def _real_worker(rank, world, port, bn, q, wg=None):
             assert len(eng.bwd_a1.ops) + len(eng.bwd_a2.ops) == len(eng.bwd_a.ops)
         d = dp.DataParallel()
         d.prepare_vae(eng)
+        if world == 8:
+            # every region splits into 8 shards of a multiple of 4 elements PLUS a replicated remainder (all-reduced, updated
+            # by every rank): the tiny model's regions are not multiples of 32
+            rems = []
+            for a, b in d._regions(eng):
+                s_, rem = d._split(a, b)
+                assert s_ > 0 and s_ % 4 == 0 and 0 <= b - rem < 32, (a, b, s_, rem)
+                rems.append(b - rem)
+            assert any(r > 0 for r in rems), rems                  # (at least one region is not a multiple of 32)
         batch = _global_batch(eng.geom, 5, world)
         mine = [t[rank:rank + 1] for t in batch]
         eps_all = None
@@ -225,7 +234,11 @@ def _real_worker(rank, world, port, bn, q, wg=None):
 
 
 @pytest.mark.parametrize("bn,world,wg", [("vqvae-ema", 2, None), ("ae", 2, None), ("vqvae-ema", 3, None), ("vae", 2, None),
-                                         ("vqvae-ema", 2, 1), ("vqvae-ema", 3, 1)])
+                                         ("vqvae-ema", 2, 1), ("vqvae-ema", 3, 1),
+                                         # the world size of the target machine (BASELINE configs[2]: 8 x MI355X): shards of
+                                         # 1/8 with a replicated remainder in every region, the three-region exchange, the
+                                         # deferred all-gather order and the EMA sum over 8 ranks
+                                         ("vqvae-ema", 8, None), ("vqvae-ema", 8, 1)])
 def test_dp_real_steps_match_single_process_global_batch(bn, world, wg):
     """Sum-type loss (VQ-VAE-EMA: summed gradients, one codebook from summed EMA statistics) and mean-type loss (AE:
     the optimizer scales the summed gradient by 1 / world): N ranks with one window each == one process with all N.
@@ -241,11 +254,14 @@ def test_dp_real_steps_match_single_process_global_batch(bn, world, wg):
     procs = [ctx.Process(target=_real_worker, args=(r, world, port, bn, q, wg)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, o0, ref), (_, o1, _) = res[0], res[-1]
+    for _, ok, _ in res[1:-1]:                                    # every rank in between holds the same replica
+        for name in ok:
+            assert (ok[name][0] == o0[name][0]).all() and (ok[name][1] == o0[name][1]).all(), name
     T = lambda a: None if a is None else torch.from_numpy(a)
     o0 = {k: tuple(T(a) for a in v) for k, v in o0.items()}
     o1 = {k: tuple(T(a) for a in v) for k, v in o1.items()}
@@ -258,7 +274,10 @@ def test_dp_real_steps_match_single_process_global_batch(bn, world, wg):
         pb, mb, eb = o1[name]
         assert torch.equal(pa, pb), name                                   # the replicas stay identical
         assert torch.equal(ma, mb), name                                   # gathered moments too
-        assert float((pa - p_ref).abs().max()) <= tol * scale, (name, float((pa - p_ref).abs().max()), scale)
+        # (bf16 transport: a summed gradient near zero may change SIGN in the rounding, and Adam's first step is lr * sign(g):
+        # 2 lr on such a parameter - seen at world 8, where seven more hops round)
+        bound = max(tol * scale, 2.05e-2) if name.endswith("bf16") else tol * scale
+        assert float((pa - p_ref).abs().max()) <= bound, (name, float((pa - p_ref).abs().max()), scale)
         # (bf16 transport rounds every summed gradient to 8 bits of mantissa; Adam's normalised update then moves
         # near-zero-gradient parameters differently in step 1, which step 2's moments see: looser bound)
         mtol = 1e-2 if name.endswith("bf16") else tol             # one step: m = (1 - beta1) g, g rounded to bf16
@@ -333,8 +352,8 @@ def _state_worker(rank, world, port, tmpdir, q):
         dist.destroy_process_group()
 
 
-def test_sharded_optimizer_state_sync_and_collective_checkpoint(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_optimizer_state_sync_and_collective_checkpoint(tmp_path, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -345,7 +364,9 @@ def test_sharded_optimizer_state_sync_and_collective_checkpoint(tmp_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, r0, m0, s0, c0, a0, p0), (_, r1, m1, s1, c1, a1, p1) = res
+    for rk in res[1:-1]:                                          # (world 8: the ranks in between agree with rank 0)
+        assert rk[1] and (rk[2] == res[0][2]).all() and (rk[6] == res[0][6]).all() and rk[4] > 0 and rk[5]
+    (_, r0, m0, s0, c0, a0, p0), (_, r1, m1, s1, c1, a1, p1) = res[0], res[-1]
     assert r0 and r1                                              # FusedAdam.state_dict() refused the sharded moments
     assert (m0 == m1).all() and (p0 == p1).all()                  # after the sync both ranks hold the same, complete state
     assert s0 == s1 == {2.0}

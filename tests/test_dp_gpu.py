@@ -79,6 +79,9 @@ def test_rccl_carries_every_product_collective_on_one_rank():
     lr, steps = 1e-4, 3
     for name, rec in out["cases"].items():
         if name.endswith("plain_again"):
+            # the plain run against itself over three steps: the whole state bit for bit - no masked elements since the
+            # bias-type sums have one order (aew_tuning_t.deterministic, ABI 20)
+            assert rec["bit_equal"] and rec["losses"] == rec["ref_losses"], (name, rec["max_abs_diff"], rec.get("params_differing"))
             continue
         assert all(abs(a / b - 1) < 1e-6 for a, b in zip(rec["losses"][:1], rec["ref_losses"][:1])), (name, rec["losses"])
         if name.endswith("bf16_grads"):
@@ -89,11 +92,8 @@ def test_rccl_carries_every_product_collective_on_one_rank():
             # after the first step: bit for bit - parameters and both Adam moments - on everything one process reproduces at
             # all (bias-type gradients are fp32-atomic column sums: round-off)
             assert rec["bit_equal_after_first_step"], (name, rec["first_step_max_abs_diff_deterministic"])
-            # later steps: that atomic noise (1e-11 in a few parameters) can tip a bf16 rounding in the decoder - also in the
-            # plain run against itself - so: the same losses, parameters within Adam's per-step bound
-            assert all(abs(a / b - 1) < 1e-5 for a, b in zip(rec["losses"], rec["ref_losses"])), (name, rec["losses"])
-            assert rec["max_abs_diff"]["params"] < 2.05 * steps * lr, (name, rec["max_abs_diff"])
-            assert all(v < 1e-3 for v in rec["max_rel_diff_atomic_sums"].values()), (name, rec["max_rel_diff_atomic_sums"])
+            # ... and after all three: every parameter, both moments, codebook, EMA numerator, every element
+            assert rec["bit_equal"] and rec["losses"] == rec["ref_losses"], (name, rec["max_abs_diff"], rec.get("params_differing"))
         if "sharded" in name:                                       # async collectives: their waits were really taken
             ex = rec["exposed_collective_ms_per_step"]
             assert {"grads.decoder", "grads.encoder", "params.all_gather"} <= set(ex), (name, ex)
