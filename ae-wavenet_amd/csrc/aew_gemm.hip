@@ -2336,6 +2336,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS((k_gemm_nt_bf16_pipe<EPI, 2>), (NtCfg<8, 2>::LDS_BYTES))      \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8>), NT_LDS_BYTES)           \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 8, 2>), (NtCfg<8, 2>::LDS_BYTES)) \
+    AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4, 2>), (NtCfg<4, 2>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4>), NT_LDS_BYTES)          \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 3, 1, 192>), (NtCfg<3, 1, 192>::LDS_BYTES)) \
     AEW_SET_LDS((k_gemm_nt_bf16<EPI, false, 4, 1, 128>), (NtCfg<4, 1, 128>::LDS_BYTES)) \
@@ -2495,6 +2496,9 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         for (int s = 0; s < g.n_segs; ++s) zspan = zspan && g.seg[s].k_len * 2 <= AEW_ZERO_SPAN;
         const bool wide = AEW_T().nt_wave_rows == 256 && g.N_pad % 256 == 0 && !(g.epi == AEW_EPI_RES_SKIP && g.n_split % 256);
         const bool p64 = wide && AEW_T().nt_pipe == 2 && zspan;    // 256 x 256 tiles, K tiles of 64
+        // 256 x 256 tiles as SIXTEEN waves of 64 x 64 (A/B, round 6: the A operand staged once per two N tiles, with the wave
+        // count of two 8-wave blocks - what the 8-fat-wave form of this tile lacks); one block per CU, 3 x 32 KiB ring
+        const bool wide16 = AEW_T().nt_wave_rows == 512 && g.N_pad % 256 == 0 && g.epi != AEW_EPI_RES_SKIP;
         // launches that would be a small fraction of one tile wave use 64-row tiles (default shape only)
         const int tiles256 = ((g.M + NT_BM - 1) / NT_BM) * g.batch * (g.N_pad / NT_BN);
         const bool p64r = AEW_T().nt_wave_rows == 64 && AEW_T().nt_small_tiles > 0 && tiles256 <= AEW_T().nt_small_tiles && zspan;
@@ -2526,7 +2530,7 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
         // 64 x 64 tiles for launches of very few 64 x 128 blocks (see the p64 kernel's table)
         int blocks64 = 0;
         const bool p64n = nt_small64(g, &blocks64);
-        const int bm = p64r ? 64 : ((p128 || t128) ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : ((wide || deep2) ? 256 : NT_BN));
+        const int bm = p64r ? 64 : ((p128 || t128) ? 128 : (t192 ? 192 : NT_BM)), bn = p64n ? 64 : ((p128 || p64r) ? 128 : ((wide || deep2 || wide16) ? 256 : NT_BN));
         const int row_tiles = ((g.M + bm - 1) / bm) * g.batch;
         dim3 grid(((row_tiles + 7) / 8) * 8 * (g.N_pad / bn));
         // split-K of a small launch: honoured by the 64 x 64 shape (every other shape contracts the whole K axis; the
@@ -2562,6 +2566,8 @@ static int launch_gemm_nt(const aew_gemm_nt_t& g, hipStream_t st) {
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 4, 2, 2>), grid, dim3(256), (P64Cfg<4, 2, 2>::LDS_BYTES), st, g); \
         else if (!ABL && p64)                                                                                  \
             hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI, 8, 2, 4>), grid, dim3(512), (P64Cfg<8, 2, 4>::LDS_BYTES), st, g); \
+        else if (!ABL && wide16)                                                                               \
+            hipLaunchKernelGGL((k_gemm_nt_bf16<EPI, false, 4, 2>), grid, dim3((NtCfg<4, 2>::THREADS)), (NtCfg<4, 2>::LDS_BYTES), st, g); \
         else if (!ABL && AEW_T().nt_pipe && wide)                                                                   \
             hipLaunchKernelGGL((k_gemm_nt_bf16_pipe<EPI, 2>), grid, dim3((NtCfg<8, 2>::THREADS)), (NtCfg<8, 2>::LDS_BYTES), st, g); \
         else if (!ABL && AEW_T().nt_pipe && AEW_T().nt_wave_rows == 128)                                                  \

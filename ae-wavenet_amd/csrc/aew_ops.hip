@@ -776,20 +776,49 @@ __global__ void k_spk_bwd(const aew_spk_bwd_t p, int det) {
     __syncthreads();
     if (ticket != (unsigned)(nl * 2 * nz) - 1u) return;
     if (tid == 0) __hip_atomic_store(p.det_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    if (tid < p.G) {                                              // thread = embedding column j
-        float bsum = 0.f;
-        for (int bb = 0; bb < p.B; ++bb) {
-            const int z = bb / AEW_SPK_MAXB, rb = bb - z * AEW_SPK_MAXB;
+    // thread (batch element bb, column j): its 2 L terms in order (loads 8 at a time), result to LDS; then thread j walks
+    // the batch elements in order and adds into the speaker rows (batch elements that share a speaker: ascending)
+    float* tot = sh;                                              // [B][G] (B <= 16 per chunk; nz chunks handled in turn)
+    float bsum = 0.f;
+    for (int z = 0; z < nz; ++z) {
+        const int nbz = min(AEW_SPK_MAXB, p.B - z * AEW_SPK_MAXB);
+        __syncthreads();
+        if (tid < nbz * p.G) {
+            const int rb = tid / p.G, j = tid - rb * p.G;
+            const float* base = p.det_scratch + (int64_t)z * (AEW_SPK_MAXB * AEW_SPK_MAXG) + rb * AEW_SPK_MAXG + j;
+            const int64_t stride = (int64_t)nz * (AEW_SPK_MAXB * AEW_SPK_MAXG);     // term (li, h) sits (li * 2 + h) strides further
             float t = 0.f;
-            for (int li = 0; li < nl; ++li)
-                for (int h = 0; h < 2; ++h)
-                    t += __hip_atomic_load(p.det_scratch + (((int64_t)li * 2 + h) * nz + z) * (AEW_SPK_MAXB * AEW_SPK_MAXG) +
-                                           rb * AEW_SPK_MAXG + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p.grads[p.off_spk_w + (int64_t)tid * p.n_speakers + p.voice[bb]] += t;
-            bsum += t;
+            for (int q = 0; q < 2 * nl; q += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = q + u < 2 * nl ? __hip_atomic_load(base + (int64_t)(q + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += v[u];
+            }
+            tot[rb * p.G + j] = t;
         }
-        if (p.off_spk_b >= 0) p.grads[p.off_spk_b + tid] += bsum;
+        __syncthreads();
+        if (tid < p.G) {
+            // speaker rows: a batch element adds into the running value of the FIRST batch element of its chunk with the same
+            // speaker (LDS), and that one writes the row - no dependent global read-modify-write chain
+            for (int rb = 0; rb < nbz; ++rb) {
+                const int64_t v = p.voice[z * AEW_SPK_MAXB + rb];
+                int first = rb;
+                for (int r2 = 0; r2 < rb; ++r2)
+                    if (p.voice[z * AEW_SPK_MAXB + r2] == v) { first = r2; break; }
+                bsum += tot[rb * p.G + tid];
+                if (first != rb) tot[first * p.G + tid] += tot[rb * p.G + tid];
+            }
+            for (int rb = 0; rb < nbz; ++rb) {
+                const int64_t v = p.voice[z * AEW_SPK_MAXB + rb];
+                bool is_first = true;
+                for (int r2 = 0; r2 < rb; ++r2) is_first = is_first && p.voice[z * AEW_SPK_MAXB + r2] != v;
+                if (is_first) p.grads[p.off_spk_w + (int64_t)tid * p.n_speakers + v] += tot[rb * p.G + tid];
+            }
+        }
     }
+    if (tid < p.G && p.off_spk_b >= 0) p.grads[p.off_spk_b + tid] += bsum;
 }
 
 // =============================================================================================
@@ -1015,11 +1044,15 @@ __global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_p
     }
     // Deterministic form: the partial sums of this (batch element, row chunk) leave write-through, the block takes a
     // ticket of its output - one output per column block when the batch elements share it (out_bs == 0), one per
-    // (column block, batch element) otherwise - and the last arriver adds all partials in a fixed order (batch element
-    // ascending, chunk ascending): one summation order whatever the schedule, and a single writer per output.
+    // (column block, batch element) otherwise - and the last arriver adds all partials in a FIXED order: the list of
+    // partials (batch element ascending, chunk ascending) is cut into NG contiguous ranges, one per thread group, each
+    // summed in order (loads 8 at a time), and the NG range sums are added in range order.  One association whatever the
+    // schedule, and a single writer per output.
     const int nchunk = gridDim.z, nb = gridDim.y, ncb = gridDim.x;
+    const int col0 = blockIdx.x * (64 * W);
+    const int ncol = min(64 * W, p.N - col0);                         // valid columns of this column block
     float* mine = p.det_scratch + (((int64_t)b * nchunk + blockIdx.z) * ncb + blockIdx.x) * (64 * W);
-    for (int c = threadIdx.x; c < 64 * W; c += 256)
+    for (int c = threadIdx.x; c < ncol; c += 256)
         __hip_atomic_store(mine + c, sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1031,16 +1064,37 @@ __global__ __launch_bounds__(256) void k_colsum(const aew_colsum_t p, int rows_p
     __syncthreads();
     if (ticket != want) return;
     if (threadIdx.x == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    const int b_lo = shared_out ? 0 : b, b_hi = shared_out ? nb : b + 1;
-    for (int c = threadIdx.x; c < 64 * W; c += 256) {
-        const int cc = blockIdx.x * (64 * W) + c;
-        if (cc >= p.N) continue;
+    const int b_lo = shared_out ? 0 : b;
+    const int npart = shared_out ? nb * nchunk : nchunk;              // partial q: batch element b_lo + q / nchunk, chunk q % nchunk
+    int cpad = 1;
+    while (cpad < ncol) cpad <<= 1;                                   // columns rounded up to a power of two <= 64 W <= 512
+    const int NG = cpad >= 256 ? 1 : 256 / cpad;                       // thread groups
+    const int per = (npart + NG - 1) / NG;
+    float* red = &sh[0][0];                                           // [NG][cpad] <= 256 floats ... 4 * 64 W available
+    for (int c0 = 0; c0 < cpad; c0 += 256 / NG) {                      // (one pass unless cpad > 256)
+        const int c = c0 + (int)(threadIdx.x % (256 / NG)), gq = threadIdx.x / (256 / NG);
         float tot = 0.f;
-        for (int bb = b_lo; bb < b_hi; ++bb)
-            for (int ch = 0; ch < nchunk; ++ch)
-                tot += __hip_atomic_load(p.det_scratch + (((int64_t)bb * nchunk + ch) * ncb + blockIdx.x) * (64 * W) + c,
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        p.out[(int64_t)b * p.out_bs + cc] += tot;
+        if (c < ncol) {
+            const int q0 = gq * per, q1 = min(npart, q0 + per);
+            const float* base = p.det_scratch + ((int64_t)b_lo * nchunk * ncb + blockIdx.x) * (64 * W) + c;
+            const int64_t stride = (int64_t)ncb * (64 * W);           // partial q sits q strides further (b-major, chunk-minor)
+            for (int q = q0; q < q1; q += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = q + u < q1 ? __hip_atomic_load(base + (int64_t)(q + u) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tot += v[u];
+            }
+        }
+        __syncthreads();
+        red[gq * (256 / NG) + (threadIdx.x % (256 / NG))] = tot;
+        __syncthreads();
+        if (gq == 0 && c < ncol) {
+            float t2 = 0.f;
+            for (int k = 0; k < NG; ++k) t2 += red[k * (256 / NG) + (threadIdx.x % (256 / NG))];
+            p.out[(int64_t)b * p.out_bs + col0 + c] += t2;
+        }
     }
 }
 

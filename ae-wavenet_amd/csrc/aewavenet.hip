@@ -216,7 +216,8 @@ struct TuneScope {
 };
 static void tune_clamp(aew_tuning_t& t) {
     auto cl = [](int32_t& v, int lo, int hi) { v = v < lo ? lo : (v > hi ? hi : v); };
-    if (t.nt_wave_rows != 0 && t.nt_wave_rows != 1 && t.nt_wave_rows != 64 && t.nt_wave_rows != 128 && t.nt_wave_rows != 256)
+    if (t.nt_wave_rows != 0 && t.nt_wave_rows != 1 && t.nt_wave_rows != 64 && t.nt_wave_rows != 128 && t.nt_wave_rows != 256 &&
+        t.nt_wave_rows != 512)
         t.nt_wave_rows = 64;
     cl(t.nt_pipe, 0, 2); cl(t.nt_rows192, 0, 2); cl(t.nt_window, 0, 64); cl(t.nt_mem128, 0, 2); cl(t.nt_deep, 0, 3);
     cl(t.lanes, 0, 2); if (t.tn_cursor_epoch > 0) { cl(t.tn_cursor_epoch, 3, 64); cl(t.tn_cursor_slack, 1, 8); } else if (t.tn_cursor_epoch < 0) t.tn_cursor_epoch = -1; cl(t.nt_small_w8, 0, 1); cl(t.nt_chain, 0, 1); cl(t.deterministic, 0, 1); cl(t.nf_loaders, 0, 1); cl(t.fn_enable, 0, 1); cl(t.tn_safe, 0, 1); cl(t.tn_big, 0, 1);
@@ -361,7 +362,7 @@ extern "C" int aew_set_nt_small_n64(int max_blocks) { g_tune.nt_small_n64 = max_
 extern "C" int aew_set_nt_small_deep(int max_blocks) { g_tune.nt_small_deep = max_blocks < 0 ? 0 : max_blocks; return 0; }
 extern "C" int aew_set_nt_pipe(int mode) { g_tune.nt_pipe = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 extern "C" int aew_set_nt_wave_rows(int rows) {
-    if (rows != 0 && rows != 1 && rows != 64 && rows != 128 && rows != 256) return AEW_E_ARG;
+    if (rows != 0 && rows != 1 && rows != 64 && rows != 128 && rows != 256 && rows != 512) return AEW_E_ARG;
     g_tune.nt_wave_rows = rows;
     return 0;
 }

@@ -1156,6 +1156,7 @@ class EncoderPlan:
                 cs.x = dpre.seg(128)
                 cs.dtype, cs.M, cs.N, cs.batch = BF, Lo, E, B
                 cs.out, cs.out_bs, cs.accumulate = ps.ptr(f"encoder.net.{i}.conv.bias", True), 0, 1
+                det_colsum(self.ws, cs, f"det.db.enc{i}")
                 with plan.side(1 + (2 * i) % DecoderPlan.n_side_lanes):
                     plan.add(L.OP_COLSUM, cs, f"db.enc{i}", TAG_ENC)
             slabs = L.tn_slabs(t) if grp is None else 1

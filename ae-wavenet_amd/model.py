@@ -16,7 +16,7 @@ import torch
 
 from . import _lib as L
 from . import geometry as G
-from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC, exact_split_args,
+from .engine import (BF, F3, DecoderPlan, EncoderPlan, Packer, ParamStore, TAG_ADAM, TAG_ENC, det_colsum, exact_split_args,
                      TAG_LOSS, TAG_MISC, TAG_PACK, TAG_VQ, bottleneck_param_specs,
                      decoder_param_specs, encoder_param_specs)
 from .plan import CopyTableBuilder, Mat, Plan, Workspace, insert_nt_chains, make_nt, make_tn, null_view, ru, split_small_nt
@@ -443,6 +443,7 @@ class TrainEngine:
                 cs.x = self.dlin.seg(64)
                 cs.dtype, cs.M, cs.N, cs.batch = F3, g.embed_len, self.d, B
                 cs.out, cs.out_bs, cs.accumulate = ps.ptr("bottleneck.linear.bias", True), 0, 1
+                det_colsum(ws, cs, "det.db.bn")
                 with bw.side():
                     bw.add(L.OP_COLSUM, cs, "db.bn", TAG_VQ)
             # linear wgrad / dgrad

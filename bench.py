@@ -123,46 +123,63 @@ def host_batches(model, B, rank, n_pool=8):
     return it()
 
 
-CPU_BASELINE_METHOD = "r05: thread sweep on one window, then one full-batch step at the fastest thread count; fastest reported"
+CPU_BASELINE_METHOD = ("r06: thread sweep on one window (with the reference's diagnostic backward), the same step without it at the "
+                       "fastest count, then ONE full-batch step at that count on the weights and batch the GPU has just run "
+                       "(the parity record); value = fastest one-window rate, value_full_batch beside it")
 
 
 def cpu_baseline(hps, eng, seconds_budget=75.0, full_batch=True):
     """The oracle (torch fp32 CPU restatement of the reference) as the best the CPU path does on this host, on a bounded
-    sample of the same workload.  One training step = forward, the reference's diagnostic autograd.grad over (mel,
-    encoding) (autoencoder_model.py:252-257: what its run() does), backward, Adam over all parameters
-    (chassis.py:151-171).  (1) one window of the batch, one timed step at each of {4, 8, 16, 32, 64, all} threads (after an
-    untimed warm-up step; the sweep stops once two counts in a row are slower than the best); (2) one step on the FULL batch of 8 windows at the fastest thread count of (1) - batched
-    convolutions use the cores better than one window does (the unmodified reference, 8 cores, B = 8: 1 570
-    samples/s).  `value` is the fastest samples/s seen, `cores` the thread count that produced it; everything measured is
-    listed in `sweep`.  Round 4's method (one window, all threads, median of three) is entry `all threads` of the sweep."""
+    sample of the same workload - and, in the same pass, the PARITY RECORD of the as-benchmarked configuration.
+    One training step = forward, the reference's diagnostic autograd.grad over (mel, encoding)
+    (autoencoder_model.py:252-257: what its run() does), backward, Adam over all parameters (chassis.py:151-171).
+    (1) one window of the batch, one timed step at each of {4, 8, 16, 32, 64, all} threads (after an untimed warm-up
+        step; the sweep stops once two counts in a row are slower than the best);
+    (2) the same one-window step WITHOUT the diagnostic backward at the fastest count (BASELINE.md 3: the pair);
+    (3) one step on the FULL batch at that count, on a fresh copy of the engine's current weights and codebook and on a
+        batch the GPU engine runs first (forward + backward, chained launch and all, B = 8, w = 5000): the oracle's loss,
+        code indices and gradients against the GPU's = `parity` (chassis.py:151-157).
+    `value` is the fastest one-window samples/s, `value_full_batch` the full-batch rate (the GPU number's own batch);
+    both are soft numbers - torch's CPU convolutions at these sizes move by 10x with the thread count alone (128 threads:
+    0.6 k samples/s, 16 threads: 8 k) - `sweep` lists everything measured."""
     import torch
     from oracle import ref_model as R
     g = eng.geom
     n_all = torch.get_num_threads()
-    sd = {k: eng.ps.view(k).detach().cpu().clone().requires_grad_(True) for k in eng.ps.names()}
-    emb = eng.emb.detach().cpu().clone()
-    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+
+    def fresh():
+        sd_ = {k: eng.ps.view(k).detach().cpu().clone().requires_grad_(True) for k in eng.ps.names()}
+        return sd_, torch.optim.Adam(list(sd_.values()), lr=1e-4)
+    sd, opt = fresh()
+    emb = eng.emb.detach().cpu().clone() if hasattr(eng, "emb") else None
 
     def batch(nb):
         gen = torch.Generator().manual_seed(5)
         return (torch.randint(0, 256, (nb, g.enc_in_len), generator=gen).float(), torch.randn(nb, 39, g.mel_len, generator=gen),
                 torch.randint(0, 40, (nb,), generator=gen), torch.arange(g.embed_len).repeat(nb, 1))
 
-    def step(data, diag):
+    def step(data, diag, sd_=None, opt_=None, keep=None):
+        sd_, opt_ = (sd, opt) if sd_ is None else (sd_, opt_)
         wav, mel, voice, jitter = data
         t0 = time.time()
-        opt.zero_grad()
+        opt_.zero_grad()
         m = mel.clone().requires_grad_(True)
-        out = R.ae_run(sd, {"emb": emb}, hps, g, wav, m, voice, jitter, loss_mode="intended", take_compat=False)
+        out = R.ae_run(sd_, {"emb": emb}, hps, g, wav, m, voice, jitter, loss_mode="intended", take_compat=False)
         if diag:
             torch.autograd.grad(out["loss"], (m, out["encoding_bn"]), retain_graph=True, allow_unused=True)
         out["loss"].backward()
-        opt.step()
+        if keep is not None:                                   # (before Adam moves the weights: the gradients of THIS step)
+            keep["loss"] = float(out["loss"].detach())
+            keep["ind"] = out["min_ind"].reshape(-1).clone() if "min_ind" in out else None
+            keep["grads"] = {k: v.grad.detach().clone() for k, v in sd_.items() if v.grad is not None}
+        opt_.step()
         return time.time() - t0
     t_start = time.time()
     one = batch(1)
     step(one, False)                                       # warm-up (allocator, thread pool, first touch of 95 MB of moments)
     sweep = []
+    parity = None
+    without_diag = None
     cands = sorted({t for t in (4, 8, 16, 32, 64, n_all) if 1 <= t <= n_all})
     try:
         for t in cands:
@@ -176,23 +193,60 @@ def cpu_baseline(hps, eng, seconds_budget=75.0, full_batch=True):
             if len(sweep) >= 3 and all(r["samples_per_s"] < max(x["samples_per_s"] for x in sweep) for r in sweep[-2:]):
                 break
         best = max(sweep, key=lambda r: r["samples_per_s"])
+        torch.set_num_threads(best["threads"])
+        dt = step(one, False)
+        without_diag = {"threads": best["threads"], "windows": 1, "seconds": round(dt, 3), "samples_per_s": round(g.n_win / dt, 1)}
         if full_batch and time.time() - t_start < seconds_budget * 0.6:
-            torch.set_num_threads(best["threads"])
             nb = eng.B
-            dt = step(batch(nb), True)
+            data = batch(nb)
+            # ---- the GPU's step on this batch, from the engine's current state (no optimizer step: the oracle below starts
+            # from the same weights).  vq.ema of this extra forward advances the EMA accumulators once more; the bench is over.
+            dev = eng.device
+            sd2, opt2 = fresh()                                # the weights and the codebook this forward reads (the backward
+            if hasattr(eng, "emb"):                            # below refreshes the codebook from the EMA statistics)
+                emb = eng.emb.detach().cpu().clone()
+            eng.set_inputs(*[t_.to(dev) for t_ in data])
+            gl = float(eng.forward())
+            eng.backward()
+            torch.cuda.synchronize()
+            g_ind = eng.ind[:eng.Q].cpu() if hasattr(eng, "ind") else None
+            g_grads = {k: eng.ps.view(k, True).detach().cpu().clone() for k in eng.ps.names()}
+            keep = {}
+            dt = step(data, True, sd2, opt2, keep)
             sweep.append({"threads": best["threads"], "windows": nb, "seconds": round(dt, 3),
                           "samples_per_s": round(nb * g.n_win / dt, 1)})
+            rl2, cos = [], []
+            for k, gr in keep["grads"].items():
+                a, b = g_grads[k].double().reshape(-1), gr.double().reshape(-1)
+                nb_ = float(b.norm())
+                if nb_ > 0:
+                    rl2.append(float((a - b).norm()) / nb_)
+                    cos.append(float(torch.dot(a, b)) / (float(a.norm()) * nb_ + 1e-300))
+            rl2.sort()
+            parity = {"config": f"B = {nb}, w = {g.n_win}, the engine as benchmarked (chained forward: "
+                                f"{bool(getattr(eng.fwd_b, 'nt_chains', None))}) vs oracle/ref_model.ae_run on the same weights, codebook and batch",
+                      "loss_gpu": gl, "loss_oracle": keep["loss"], "loss_rel": abs(gl / keep["loss"] - 1.0),
+                      "n_queries": int(g_ind.numel()) if g_ind is not None else 0,
+                      "indices_equal": bool(torch.equal(g_ind, keep["ind"])) if g_ind is not None and keep["ind"] is not None else None,
+                      "n_indices_differ": int((g_ind != keep["ind"]).sum()) if g_ind is not None and keep["ind"] is not None else None,
+                      "grad_tensors": len(rl2), "grad_rel_l2_median": round(rl2[len(rl2) // 2], 5) if rl2 else None,
+                      "grad_rel_l2_worst": round(rl2[-1], 5) if rl2 else None, "grad_cosine_min": round(min(cos), 5) if cos else None}
     finally:
         torch.set_num_threads(n_all)
-    best = max(sweep, key=lambda r: r["samples_per_s"])
+    best = max((r for r in sweep if r["windows"] == 1), key=lambda r: r["samples_per_s"])
+    fullb = next((r for r in sweep if r["windows"] > 1), None)
     return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+            "value_full_batch": fullb["samples_per_s"] if fullb else None,
+            "with_diagnostic_backward": best["samples_per_s"],
+            "without_diagnostic_backward": without_diag["samples_per_s"] if without_diag else None,
+            "soft_number": "torch CPU convolutions at these sizes: 10x by thread count alone (see sweep); a reported baseline, not a target",
             "host_threads_available": n_all, "method": CPU_BASELINE_METHOD, "sweep": sweep,
             "sample": f"oracle forward + the reference's diagnostic backward + backward + Adam: one step each at "
                       f"{[r['threads'] for r in sweep if r['windows'] == 1]} threads on 1 of the batch's {eng.B} windows "
-                      f"({g.n_win} samples), then one step on "
-                      + (f"all {eng.B} windows at {sweep[-1]['threads']} threads" if sweep[-1]["windows"] > 1 else "no full batch (time budget)")
-                      + f"; fastest: {best['windows']} window(s) at {best['threads']} threads, {best['seconds']} s; "
-                        f"{time.time() - t_start:.0f} s of host time in total"}
+                      f"({g.n_win} samples), the same without the diagnostic backward, then one step on "
+                      + (f"all {eng.B} windows at {fullb['threads']} threads" if fullb else "no full batch (time budget)")
+                      + f"; fastest one-window step: {best['threads']} threads, {best['seconds']} s; "
+                        f"{time.time() - t_start:.0f} s of host time in total"}, parity
 
 
 def box_record(lib, eng, device):
@@ -671,13 +725,13 @@ def main():
             import traceback
             roof = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-600:]}
 
-    cpu = None
+    cpu, parity = None, None
     if world > 1:
         cpu = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
                "sample": "measured at --gpus 1 only (rank 0 would hold the other ranks for ~30 s)"}
     elif rank == 0 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(hps, eng)
+            cpu, parity = cpu_baseline(hps, eng)
         except Exception as e:                                   # never lose the GPU line
             cpu = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": f"failed: {type(e).__name__}: {e}"}
@@ -707,7 +761,7 @@ def main():
             "host_fed": {"ms_per_step": 1e3 * dt_host / args.steps, "value": samples / dt_host, "unit": "samples/s",
                          "path": "pinned host batch -> DevicePrefetcher (H2D on a copy stream, jitter generated on the device) -> the "
                                  "same step: PCIe-inclusive, reported beside `value`, never as it"},
-            "roofline": roof, "cpu_baseline": cpu, "box": box, "data_parallel": dp_info,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "box": box, "data_parallel": dp_info,
             "kernel_ms_by_tag": {str(k): round(v, 4) for k, v in sorted(kern.items())},
         }
         print(json.dumps(out))

@@ -21,12 +21,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(backend, share, sharded, timeout=420):
+def _bench(backend, share, sharded, timeout=420, gpus=2, n_win=1000, extra_env=None):
     env = dict(os.environ, AEW_BENCH_BACKEND=backend, AEW_DP_SHARDED="1" if sharded else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env["AEW_BENCH_SHARE_GPU"] = "1" if share else "0"
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--check-replicas", "--n-win", "1000"]
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--check-replicas", "--n-win", str(n_win)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
@@ -57,6 +58,28 @@ def test_two_ranks_train_identically_through_bench():
     assert "all-reduce" in ref["config"]["parallelism"] and ref["data_parallel"]["replica_param_max_diff"] == 0.0
     # same data, same seeds, same number of optimizer steps: the two schedules differ by fp32 summation order only
     assert abs(loss_sharded / ref["config"]["loss"] - 1) < 2e-3, (loss_sharded, ref["config"]["loss"])
+
+
+def test_eight_ranks_spawn_and_report_through_bench():
+    """The driver's first 8-GPU run (BASELINE configs[2]) must not be the first time `bench.py --gpus 8` exists: the spawn
+    path, eight ranks in one process group, the three-wait-point sharded step and the JSON line (`n_gpus: 8`,
+    `data_parallel.by_wait_ms_per_step`) - here with all eight ranks on the test box's device over gloo (a functional check,
+    small windows), or one per device over RCCL where the box has eight.  train.py:58-60, chassis.py:168-169."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        backend, share = "nccl", False
+    else:
+        backend, share = "gloo", True
+    out, err = _bench(backend, share, True, timeout=900, gpus=8, n_win=100)
+    assert out is not None, err
+    dp = out["data_parallel"]
+    print(f"eight ranks over {backend}: {out['ms_per_step']:.2f} ms/step ({'one shared device: not a measurement' if share else '8 devices'}), "
+          f"waits {dp['by_wait_ms_per_step']}")
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
+    assert dp["backend"] == backend and dp["ranks_share_one_gpu"] == share
+    assert dp["replica_param_max_diff"] == 0.0 and dp["replica_codebook_max_diff"] == 0.0
+    assert {"grads.decoder", "grads.encoder", "params.all_gather"} <= set(dp["by_wait_ms_per_step"]), dp
+    assert out["cpu_baseline"]["value"] is None and out["value"] > 0
 
 
 def test_rccl_carries_every_product_collective_on_one_rank():

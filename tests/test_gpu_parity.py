@@ -835,7 +835,7 @@ def diff_workspaces(ec, eg, skip_prefix=("tbl.", "in.", "adam.", "scratch.")):
     bad = []
     for n, tc in ec.ws.bufs.items():
         if n.startswith(skip_prefix) or ".wg." in n or n.startswith("enc.wg") or n.startswith("bn.wg") or "tbl." in n \
-                or n == "bn.vq_part" or ".tng" in n or n.startswith("tng"):
+                or n == "bn.vq_part" or ".tng" in n or n.startswith("tng") or "det." in n:
             continue                     # wgrad slabs / search scratch: implementation detail; tables hold pointers
         tg = eg.ws.get(n).cpu()
         if tc.dtype in (torch.int64, torch.int32):
@@ -1112,7 +1112,9 @@ def test_full_width_step_vs_oracle():
     err = (lg - out["quant"].detach()).abs().max().item()
     print(f"logit max abs err {err:.4f} (scale {out['quant'].abs().max().item():.2f})")
     assert err <= 0.06
-    assert abs(float(loss) / float(out["loss"]) - 1) < 1e-2
+    rel = abs(float(loss) / float(out["loss"]) - 1)
+    print(f"loss {float(loss):.5f} vs oracle {float(out['loss']):.5f}: rel {rel:.2e}")
+    assert rel < 1e-4            # (measured <= 1e-5: the logit errors of the bf16 decoder average out over the positions)
     worst = (0.0, "")
     rl2 = []
     for k in eng.ps.names():
@@ -1233,7 +1235,9 @@ def test_deep_decoder_step_vs_oracle():
     err = (lg - out["quant"].detach()).abs().max().item()
     print(f"DEEP: logit max abs err {err:.4f} (scale {out['quant'].abs().max().item():.2f})")
     assert err <= 0.08
-    assert abs(float(loss) / float(out["loss"].detach()) - 1) < 1e-2
+    rel = abs(float(loss) / float(out["loss"].detach()) - 1)
+    print(f"DEEP: loss {float(loss):.5f} vs oracle {float(out['loss'].detach()):.5f}: rel {rel:.2e}")
+    assert rel < 1e-3
     worst = (0.0, "")
     rl2 = []
     for k in eng.ps.names():
@@ -1271,7 +1275,9 @@ def test_full_window_forward_vs_oracle():
     rms = ((lg - ref) ** 2).mean().sqrt().item() / (ref ** 2).mean().sqrt().item()
     print(f"w=5000 logit max abs err {err:.4f} (scale {ref.abs().max().item():.2f}), relative rms {rms:.2e}")
     assert err <= 0.06 and rms < 2e-2          # measured 0.019 / 0.93e-2 (bf16 activations through 20 layers)
-    assert abs(loss / float(out["loss"]) - 1) < 1e-2
+    rel = abs(loss / float(out["loss"]) - 1)
+    print(f"w=5000 loss {loss:.5f} vs oracle {float(out['loss']):.5f}: rel {rel:.2e}")
+    assert rel < 1e-4
 
 
 @pytest.mark.parametrize("fixture", ["mi_full.npz", "mi_full_real.npz"])
@@ -1480,7 +1486,7 @@ def test_multi_step_trajectory_vs_oracle(width, steps, lr):
         n_mismatch += int((got_ind != ref_ind).sum())
         print(f"step {it}: ze rel err {ze_err:.1e}; loss {float(loss.detach()):.4f} oracle {float(out['loss'].detach()):.4f} rel {rel:.2e}; indices: {bad} of "
               f"{int(clear.sum())} clear-margin differ, {int((got_ind != ref_ind).sum())} of {len(ref_ind)} overall")
-        assert rel < 1e-2, (it, float(loss.detach()), float(out["loss"].detach()))
+        assert rel < 1e-3, (it, float(loss.detach()), float(out["loss"].detach()))     # (measured <= 3.5e-4 over the 13 steps)
         assert bad == 0, (it, bad)
         # EMA accumulators and refreshed codebook, on every code that both sides assigned identically (a query that
         # sits on a near-tie may go either way; the two codes it chose between are left out): they differ only by what the

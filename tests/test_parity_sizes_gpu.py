@@ -49,7 +49,9 @@ def test_full_window_step_vs_oracle():
     finally:
         torch.set_num_threads(n_thr)
     assert np.array_equal(eng.ind[:eng.Q].cpu().numpy(), out["min_ind"].reshape(-1).numpy())
-    assert abs(loss / float(out["loss"]) - 1) < 1e-2
+    rel = abs(loss / float(out["loss"]) - 1)
+    print(f"loss {loss:.5f} vs oracle {float(out['loss']):.5f}: rel {rel:.2e}")
+    assert rel < 1e-4
     rows = _grad_table(eng, sd)
     med, worst = rows[len(rows) // 2], rows[-1]
     cos_min = min(r[1] for r in rows)
@@ -99,7 +101,7 @@ def test_full_width_vae_step_vs_oracle():
           f"loss {loss:.5f} vs {float(out['loss']):.5f}")
     assert e_mu < 1e-5 and e_ls < 1e-4                       # exact fp32 chain against torch's summation order
     assert abs(kl_dev / kl_ref - 1) < 1e-4
-    assert abs(loss / float(out["loss"]) - 1) < 1e-2         # the NLL comes through the bf16 decoder
+    assert abs(loss / float(out["loss"]) - 1) < 1e-4         # the NLL comes through the bf16 decoder (measured 5e-7)
     rows = _grad_table(eng, sd)
     med, worst = rows[len(rows) // 2], rows[-1]
     cos_min = min(r[1] for r in rows)
@@ -167,4 +169,5 @@ def test_free_running_index_agreement_rate():
         print(f"free-running step {it}: index agreement {rates[-1]:.3f} ({int((got == ref).sum())} / {len(ref)}), loss rel dev {rel:.2e}")
     print("free-running index agreement rate per step:", [round(r, 3) for r in rates])
     assert rates[0] >= 0.95
+    assert min(rates[1:4]) >= 0.9, rates                      # steps 1-3: before a near-tie has separated the codebooks
     assert min(rates) > 0.25                                  # chance is 1 / 128

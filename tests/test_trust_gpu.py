@@ -44,7 +44,9 @@ def test_timeout_with_the_host_running_ahead_raises_and_leaves_the_parameters(mo
     CHAIN_WATCH_SLOTS plans."""
     monkeypatch.setattr(M.TrainEngine, "nt_chain", 64)
     monkeypatch.setattr(M.TrainEngine, "nt_chain_force", True)
-    monkeypatch.setattr(M.TrainEngine, "nt_chain_spin_max", 300)
+    # (forced chains at this size: most stages are resident at once and consumers really wait, ~1e3 polls; a broken stage
+    # costs its first waiter 20 000 polls = ~20 ms, the others give up with it)
+    monkeypatch.setattr(M.TrainEngine, "nt_chain_spin_max", 20000)
     monkeypatch.delenv("AEW_NT_CHAIN", raising=False)
     lib = L.load()
     lib.aew_set_nt_window(0)                                  # (forced small chains run the plain bodies)
