@@ -2195,6 +2195,194 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void k_gemm_tn_bf16_big_grp(const a
 }
 
 // =============================================================================================
+// TN kernel, bf16, EIGHT waves on a rectangular tile ("tn8", aew_gemm_tn_group_t.tile = 384; round 6).
+// The 128 x 128 kernel above stages (128 + 128) columns per 64 MFMAs and runs three 4-wave blocks per CU; the NT bodies -
+// 256 x 128 tiles, 8 waves of 64 x 64, two blocks per CU on a 3 x 24 KiB ring: (256 + 128) columns per 128 MFMAs, four
+// waves per SIMD - move 1.6x the MFMAs per CU and K step in their K loop.  This is that shape for the weight gradients:
+//   orientation 0  128 (k) x 256 (n): LDS blocks [G n-half 0 | G n-half 1 | A k tile], waves as 2 (k) x 4 (n)
+//   orientation 1  256 (k) x 128 (n): LDS blocks [G | A k tile 2 kt | A k tile 2 kt + 1], waves as 4 (k) x 2 (n)
+// (tn8_ori: the one that tiles the matrix without a half-empty tile where one does; a half that lies beyond N_pad /
+// K_total is staged from the zero page and not stored).  A block is [32 rows][128 columns] bf16 = 8 KiB in the 128-tile
+// kernel's layout (same swizzle, same ds_read_b64_tr_b16 fragments); every wave stages one 4-row piece of each block per
+// step.  Every output element accumulates the same 32-row products in the same order (rows ascending, batch elements
+// ascending) as in tn_bf16_tile: results are BIT-IDENTICAL to the 128-tile grouped launch, by-products included.
+// =============================================================================================
+#define TN8_THREADS 512
+#define TN8_BLK_BYTES (TN_RC * 256)                  // 8 KiB
+#define TN8_STAGE_BYTES (3 * TN8_BLK_BYTES)          // 24 KiB
+#define TN8_STAGES 3
+#define TN8_LDS_BYTES (TN8_STAGES * TN8_STAGE_BYTES) // 72 KiB: two blocks per CU
+
+__host__ __device__ __forceinline__ int tn8_ori(int N_pad, int K_total) { return (K_total % 256 == 0 && N_pad % 256 != 0) ? 1 : 0; }
+
+struct Tn8Src {                                       // per-lane source of one LDS block's piece
+    const char* p;
+    int64_t inc;
+    int row, step, lo, hi;
+    bool live;                                        // (wave-uniform) the block exists
+};
+
+__device__ __forceinline__ void tn8_src(Tn8Src& S, const aew_seg_t s, int col, int b, int m, int chunk, bool live) {
+    S.step = TN_RC * s.row_step;
+    S.inc = (int64_t)S.step * s.row_pitch * 2;
+    S.lo = (int)s.row_lo; S.hi = (int)s.row_hi;
+    S.row = m * s.row_step + s.row_off;
+    S.p = reinterpret_cast<const char*>(s.ptr) + ((int64_t)b * s.batch_stride + (int64_t)S.row * s.row_pitch + col + chunk * 8) * 2;
+    S.live = live;
+}
+
+template <bool SNAP>
+__device__ __forceinline__ void tn8_tile(const aew_gemm_tn_t& g, char* smem, int kt, int nt, float* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ori = tn8_ori(g.N_pad, g.K_total);
+    const int wk = ori ? (wave & 3) : (wave & 1), wn = ori ? (wave >> 2) : (wave >> 1);
+    const int n0 = nt * (ori ? 128 : 256), kfirst = ori ? 2 * kt : kt;
+    const int gblk = ori ? 0 : (wn >> 1), gcol = ori ? wn * 64 : (wn & 1) * 64;
+    const int ablk = ori ? 1 + (wk >> 1) : 2, acol = ori ? (wk & 1) * 64 : wk * 64;
+    const bool half1 = ori ? (kfirst + 1) * 128 < g.K_total : n0 + 128 < g.N_pad;     // the tile's second 128-column half exists
+    const TnTile t0 = tn_locate(g, kfirst, TN_BT);
+    const TnTile t1 = (ori && half1) ? tn_locate(g, kfirst + 1, TN_BT) : t0;
+    const bool mine = ori ? (wk < 2 || half1) : (wn < 2 || half1);                     // this wave's 64 x 64 lies inside the matrix
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nst = (g.Mc + TN_RC - 1) / TN_RC;
+    const int total = nst * g.batch;
+    const int lr = lane >> 4, pc = lane & 15;
+    const int prow = wave * 4 + lr;                                                    // this lane's row of every 32-row block
+    const int chunk = tn_swz_bf16(prow, pc);
+    Tn8Src S[3];
+    bool fast = false;
+    int st_in_b = 0, bcur = 0, issued = 0, slot = 0, m_next = 0;
+    auto setup = [&](int b) {
+        const aew_seg_t sg = g.g;
+        if (ori == 0) {
+            tn8_src(S[0], sg, n0, b, prow, chunk, true);
+            tn8_src(S[1], sg, n0 + 128, b, prow, chunk, half1);
+            tn8_src(S[2], g.seg[t0.seg], t0.kin, b, prow, chunk, true);
+        } else {
+            tn8_src(S[0], sg, n0, b, prow, chunk, true);
+            tn8_src(S[1], g.seg[t0.seg], t0.kin, b, prow, chunk, true);
+            tn8_src(S[2], g.seg[t1.seg], t1.kin, b, prow, chunk, half1);
+        }
+        m_next = prow;
+        // interior (the common case): every row this lane stages for this batch element is valid
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r0 = S[q].row, r1 = r0 + (nst - 1) * S[q].step;
+            ok = ok && (!S[q].live || (min(r0, r1) >= S[q].lo && max(r0, r1) < S[q].hi));
+        }
+        ok = ok && prow + (nst - 1) * TN_RC < g.Mc;
+        fast = __all(ok);
+    };
+    auto issue_next = [&]() {
+        if (issued == 0) setup(0);
+        else if (++st_in_b == nst) { st_in_b = 0; ++bcur; setup(bcur); }
+        const uint32_t l0 = (uint32_t)(uintptr_t)AEW_LDS_PTR(smem + slot * TN8_STAGE_BYTES) + wave * 1024;
+        const char* zp = reinterpret_cast<const char*>(aew_zero_page);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const bool ok = S[q].live && (fast || (m_next < g.Mc && S[q].row >= S[q].lo && S[q].row < S[q].hi));
+            glds16_raw(ok ? S[q].p : zp, l0 + q * TN8_BLK_BYTES);
+            S[q].p += S[q].inc; S[q].row += S[q].step;
+        }
+        m_next += TN_RC;
+        slot = (slot + 1 == TN8_STAGES) ? 0 : slot + 1;
+        ++issued;
+    };
+    if (total > 0) issue_next();
+    if (total > 1) issue_next();
+    int stage = 0;
+    const int koff0 = kfirst * TN_BT;                                                  // first column of the tile on the K axis
+    const int ktile_w = ori ? 256 : 128;
+    const int srel = SNAP ? g.snap_k - koff0 : -1;
+    const bool snap_here = SNAP && g.snap_out && srel >= 0 && srel < ktile_w && (ori == 0 || srel < 128 || half1);
+    int c_in_b = 0, bdone = 0;
+    const bool snap_cs = SNAP && g.snap_out && g.snap_k < 0;
+    const bool do_cs = SNAP && (g.colsum_out != nullptr || snap_cs) && kfirst == 0 && wk == 0 && mine;
+    f32x4_t cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (s16x8_t){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                          // the 3 pieces of stage t + 1 stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < total) issue_next();
+        const char* sb = smem + stage * TN8_STAGE_BYTES;
+        const char* gs = sb + gblk * TN8_BLK_BYTES;
+        const char* as = sb + ablk * TN8_BLK_BYTES;
+        stage = (stage + 1 == TN8_STAGES) ? 0 : stage + 1;
+        bf16x8_t af[4], gf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = tn_frag_bf16<0>(as, 0, acol + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gf[j] = tn_frag_bf16<0>(gs, 0, gcol + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+        if (do_cs) {                                   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[j], cs[j], 0, 0, 0);
+        }
+        if (SNAP && ++c_in_b == nst) {                 // wave-uniform, once per batch element
+            c_in_b = 0;
+            if (snap_here && mine && wk == (srel >> 6) && (lane >> 4) == ((srel >> 2) & 3)) {
+                const int si = (srel >> 4) & 3, sr = srel & 3;
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n0 + wn * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v = (i == si && r == sr) ? acc[i][j][r] : v;
+                    so[j * 16] = v;
+                }
+            }
+            if (snap_cs && do_cs && (lane >> 4) == 0) {
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n0 + wn * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) so[j * 16] = cs[j][0];
+            }
+            ++bdone;
+        }
+    }
+    if (!mine) return;
+    const int q = lane & 15, gq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = koff0 + wk * 64 + i * 16 + 4 * gq;
+            *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        if (do_cs && g.colsum_out && gq == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
+    }
+}
+
+// Grouped launch on the 8-wave tiles (aew_gemm_tn_group_t.tile = 384): tile = nt * nkt + kt in the descriptor's own
+// orientation (tn8_ori): nkt = K_total / 128 (orientation 0) or ceil(K_total / 256) (orientation 1).
+__global__ __launch_bounds__(TN8_THREADS, 4) void k_gemm_tn_bf16_grp8(const aew_gemm_tn_t* __restrict__ descs,
+                                                                      const int32_t* __restrict__ tile_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rec = __builtin_amdgcn_readfirstlane(tile_map[blockIdx.x]);
+    if (rec < 0) return;
+    const aew_gemm_tn_t& g = descs[rec >> 22];
+    const int tile = rec & 0xfff;
+    const int nkt = tn8_ori(g.N_pad, g.K_total) ? (g.K_total / 128 + 1) / 2 : g.K_total / 128;
+    tn8_tile<true>(g, smem, tile % nkt, tile / nkt, g.out);
+}
+
+// =============================================================================================
 // TN kernel, fp32: out tile 64 (k) x 64 (n), contraction staged 32 rows at a time, operands by
 // ds_read_b32 (v_mfma_f32_16x16x4_f32 takes one row of the contraction per 16-lane group).
 // =============================================================================================
@@ -2368,6 +2556,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16_grp, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_grp_cur, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_big_grp, TNB_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16_grp8, TN8_LDS_BYTES)
     AEW_SET_LDS((k_nt_chain<0>), CHAIN_LDS_BYTES)
     AEW_SET_LDS((k_nt_chain<1>), CHAIN_LDS_BYTES)
 #undef AEW_SET_LDS
@@ -2721,6 +2910,8 @@ static int launch_gemm_tn_group(const aew_gemm_tn_group_t& p, hipStream_t st) {
     if (rc) return rc;
     if (p.tile == 256)
         hipLaunchKernelGGL(k_gemm_tn_bf16_big_grp, dim3(p.n_blocks), dim3(TNB_THREADS), TNB_LDS_BYTES, st, p.descs, p.tile_map);
+    else if (p.tile == 384)
+        hipLaunchKernelGGL(k_gemm_tn_bf16_grp8, dim3(p.n_blocks), dim3(TN8_THREADS), TN8_LDS_BYTES, st, p.descs, p.tile_map);
     else if (p.tile == 128) {
         // row cursor: the caller provides one zeroed progress word per tile (64 per descriptor) when it wants the launch
         // paced; the tuning record picks epoch / slack (0: the defaults 4 / 2) or vetoes it (-1).  Its own kernel: the

@@ -265,7 +265,7 @@ class TnGroupBuilder:
     CURSOR_AUTO_TILES = 1024              # (the 256 CUs hold 768 of the 128-tile blocks at a time)
 
     def __init__(self, ws: Workspace, name: str, tile: int = 128):
-        assert tile in (128, 256)
+        assert tile in (128, 256, 384)    # 384: the 8-wave 128 x 256 / 256 x 128 tiles (k_gemm_tn_bf16_grp8; aewavenet.h)
         self.ws, self.name, self.tile = ws, name, tile
         self.descs: List[L.GemmTN] = []
         self.labels: List[str] = []
@@ -275,6 +275,9 @@ class TnGroupBuilder:
     def _grid(self, t: L.GemmTN) -> Tuple[int, int]:
         """(k tiles, n tiles) of a descriptor's output in this builder's tile size."""
         k128, n128 = t.K_total // 128, t.N_pad // 128
+        if self.tile == 384:              # orientation per descriptor (tn8_ori in csrc/aew_gemm.hip: the same rule)
+            ori = 1 if (t.K_total % 256 == 0 and t.N_pad % 256 != 0) else 0
+            return ((k128 + 1) // 2, n128) if ori else (k128, (n128 + 1) // 2)
         return (k128, n128) if self.tile == 128 else ((k128 + 1) // 2, (n128 + 1) // 2)
 
     def set_split(self, t: L.GemmTN, chunk_rows: int) -> int:

@@ -216,7 +216,12 @@ typedef struct {
     int32_t tile;                /* 128: 128 x 128 output tiles, 4 waves, three blocks per CU
                                     256: 256 x 256 tiles (half the operand bytes staged per FLOP), 8 waves, one block
                                          per CU; tile = nt * ((K_total / 128 + 1) / 2) + kt in 256-column units, halves
-                                         beyond N_pad / K_total are skipped                                  */
+                                         beyond N_pad / K_total are skipped
+                                    384 (ABI 20): EIGHT waves of 64 x 64 on a 128 (k) x 256 (n) tile - or 256 (k) x 128 (n)
+                                         where K_total is a multiple of 256 and N_pad is not - two blocks per CU on a
+                                         3 x 24 KiB ring (the NT kernels' shape: 1.5 x the MFMAs per staged byte of the
+                                         128-tile, four waves per SIMD); tile = nt * nkt + kt in that grid; no split
+                                         descriptors (grp_splits = 0), no cursor; results bit-identical to tile = 128 */
     int32_t cursor_stride;       /* words per descriptor in `cursors` (>= 64)                                          */
     /* Optional row cursor (ABI 18; tile = 128 only; non-NULL = pace this launch): device
      * [n_descs][cursor_stride] uint32, ZERO before every launch (epoch / slack: aew_set_tn_cursor); word i of a descriptor's row = the epoch tile i is

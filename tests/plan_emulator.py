@@ -186,7 +186,11 @@ class Emu:
         for d, t in enumerate(descs):
             # the tile map must name every (chunk, output tile) of every descriptor exactly once
             k128, n128 = t.K_total // 128, t.N_pad // 128
-            n_tiles = k128 * n128 if p.tile == 128 else ((k128 + 1) // 2) * ((n128 + 1) // 2)
+            if p.tile == 384:                                  # 8-wave tiles: 128 x 256 or 256 x 128 by the descriptor's shape
+                ori = 1 if (t.K_total % 256 == 0 and t.N_pad % 256 != 0) else 0
+                n_tiles = ((k128 + 1) // 2) * n128 if ori else k128 * ((n128 + 1) // 2)
+            else:
+                n_tiles = k128 * n128 if p.tile == 128 else ((k128 + 1) // 2) * ((n128 + 1) // 2)
             n_chunks = t.grp_splits * t.batch if t.grp_splits > 0 else 1
             assert sorted(covered.get(d, [])) == [(c, tl) for c in range(n_chunks) for tl in range(n_tiles)], f"tile map of descriptor {d}"
             out, ooff = self.flat(t.out)

@@ -505,7 +505,7 @@ def test_tuned_record_cannot_change_a_built_split_k_plan():
         assert torch.equal(r, res[0])
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 384])
 def test_gemm_tn_group(tile):
     """AEW_OP_GEMM_TN_GROUP: several weight-gradient descriptors in one launch, each output tile contracted over all
     rows of all batch elements in one block (one result, no slabs), plus the running per-batch snapshots of the
@@ -563,7 +563,8 @@ def test_gemm_tn_group(tile):
         gb.emit(p, "group")
         if ws is ws_g:
             tm = gb.tile_map()
-            counts = (14, 6, 4) if tile == 128 else (4, 2, 1)
+            # (384: the 8-wave tiles - 128 x 256 for descriptors 0 and 2, 256 x 128 for descriptor 1 whose N_pad = 384)
+            counts = {128: (14, 6, 4), 256: (4, 2, 1), 384: (7, 3, 2)}[tile]
             want = [(d << 22) | tl for d, n in enumerate(counts) for tl in range(n)]
             if tile == 128:
                 want += [(3 << 22) | (c << 12) | tl for c in range(9) for tl in range(4)]
@@ -598,6 +599,21 @@ def test_gemm_tn_group(tile):
     g2 = ws_c.get("G2")[:B * 650 * 384].view(B, 650, 384).float()
     run_sum2 = torch.cumsum(g2[:, :640].sum(1), 0)
     assert (ws_g.get("snap2")[:B * 384].view(B, 384).cpu() - run_sum2).abs().max().item() <= 2e-3 * run_sum2.abs().max().item()
+    if tile == 384:
+        # the 8-wave tiles accumulate every output element over the same 32-row products in the same order as the 128-tile
+        # launch: bit-identical, by-products included
+        ws_1 = _mirror(ws_c, DEV)
+        for n in ("o1", "o2", "o3", "snap", "snap2", "cs1"):
+            ws_1.get(n).zero_()
+        gb = TnGroupBuilder(ws_1, "tng128", 128)
+        for i, t in enumerate(build(ws_1)):
+            gb.add(t, f"d{i}")
+        p = Plan("g128")
+        gb.emit(p, "group")
+        p.run(stream())
+        torch.cuda.synchronize()
+        for n in ("o1", "o2", "o3", "snap", "snap2", "cs1", "cs2"):
+            assert torch.equal(ws_1.get(n), ws_g.get(n)), n
     if tile == 128:
         # the same launch paced by the row cursor (aew_gemm_tn_group_t.cursors, aew_set_tn_cursor): the tiles of a matrix
         # wait for each other every few stages, which changes when a row is read and nothing about what is summed
