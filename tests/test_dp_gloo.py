@@ -386,3 +386,65 @@ def test_sharded_optimizer_state_sync_and_collective_checkpoint(tmp_path, world)
     got = torch.cat([adam.state[p]["exp_avg"].reshape(-1) for p in params]).numpy()
     assert (got == m0).all() and float(abs(got).max()) > 0
     assert all(float(adam.state[p]["step"]) == 2.0 for p in params)
+
+
+# ----------------------------------------------------------------------------------------------
+# the chained launches' sticky timeout word under data parallel: a wait that gave up on ONE rank poisons, through the
+# gradient exchange, every rank's gradients - so the guard is MAX-reduced in front of the first gradient collective
+# and every rank's optimizer step becomes a no-op (dp.DataParallel._guard_sync; aew_adam_t.guard)
+# ----------------------------------------------------------------------------------------------
+def _guard_worker(rank, world, port, q):
+    from tests.plan_emulator import emulate
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hps = _tiny("vqvae-ema")
+        eng = emulate(M.TrainEngine(hps, B=1, device="cpu", n_mel=5))
+        # (the CPU engine chains nothing - small launches are refused - so the predicate that says "this engine has chained
+        # launches to watch" is forced; the guard word and the ops that read it are the engine's own)
+        eng._chain_flag_views = [("chain[forced]", eng.chain_guard[:1])]
+        d = dp.DataParallel()
+        batch = _global_batch(eng.geom, 5, world)
+        mine = [t[rank:rank + 1] for t in batch]
+        n = eng.ps.numel
+        res = {}
+        for name in ("allreduce", "sharded"):
+            _seed_engine(eng)
+            eng.set_inputs(*mine)
+            eng.chain_guard.zero_()
+            step = (lambda: d.train_step(eng, 1e-2, 1.0)) if name == "allreduce" else (lambda: d.train_step_sharded(eng, 1e-2, 1.0))
+            before = eng.ps.params[:n].clone()
+            emb0 = eng.emb.clone()
+            if rank == 1:
+                eng.chain_guard[0] = 7                             # "stage 6 gave up" - on this rank only
+            step()
+            d.finish()
+            poisoned_same = bool(torch.equal(eng.ps.params[:n], before)) and bool(torch.equal(eng.emb, emb0))
+            guard_seen = int(eng.chain_guard[0])
+            eng.chain_guard.zero_()                                # re-armed everywhere: the next step trains
+            step()
+            d.finish()
+            res[name] = (poisoned_same, guard_seen, float((eng.ps.params[:n] - before).abs().max()))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_timeout_guard_is_shared_by_all_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        for name, (same, guard, moved) in r.items():
+            assert same, (rank, name, "a step poisoned on rank 1 reached the parameters / codebook")
+            assert guard == 7, (rank, name, guard)                 # both ranks hold the MAX
+            assert moved > 0, (rank, name)                         # and the re-armed step trains again

@@ -1,0 +1,116 @@
+"""The reference harness's loop body, statement for statement, against the drop-in (VERDICT r05 "missing" 6).
+
+`Chassis.train` (chassis.py:109-237) is what calls the hot path in production; the surface tests elsewhere are
+hand-written equivalents of it.  Here the statements of its loop body are executed as the reference writes them -
+`ss.update_learning_rate` (checkpoint.py:132-134), the anneal update (chassis.py:148-149, vae_bn.py:72-73),
+`ss.optim.zero_grad()`, `model.run(wav, mel, voice, jitter)` (:152), `Softmax(1)(quant)` (:153), `loss.backward()`
+(:157), the parameter clone of a progress step (:163), `ss.optim.step()` (:171), `avg_prob_target` (:266-270), the
+update / weight ratio loop (:180-185), `current_stats.update(model.objective.metrics)` / `model.encoder.metrics`
+(:214-222) - on the drop-in model + FusedAdam, and the same statements on the oracle (oracle/ref_model.ae_run +
+torch.optim.Adam), with a learning rate and an anneal weight that change every step as the schedules of
+par/train.*.json make them.
+"""
+import numpy as np
+import pytest
+import torch
+
+from ae_wavenet_amd import autoencoder_model as ae, config, optim
+from tests.test_gpu_parity import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bn", ["vqvae-ema", "vae"])
+def test_chassis_train_loop_body_statement_for_statement(bn):
+    from oracle import ref_model as R
+    kw = dict(n_res=64, n_dil=64, n_skp=64, n_post=64, n_lc_out=32, enc_n_out=64, bn_n_out=16, n_win_batch=256, n_blocks=2,
+              n_block_layers=5)
+    if bn == "vqvae-ema":
+        kw["bn_vq_n_embed"] = 128
+    hps = config.make_hps(bn, **kw)
+    B = 4
+    torch.manual_seed(31)
+    model = ae.AutoEncoder(hps, n_mel=39)
+    names = [n for n, _ in model.named_parameters()]
+    sd = {n: p.detach().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    emb = model._buffers["bn_emb"].clone() if bn == "vqvae-ema" else None
+    model = model.to(DEV)
+    ss_optim = optim.FusedAdam(model, lr=1e-3)
+    adam = torch.optim.Adam([sd[n] for n in names], lr=1e-3)
+    g = model.geom
+    gen = torch.Generator().manual_seed(32)
+    softmax = torch.nn.Softmax(1)                                    # chassis.py:96
+    learning_rates = {0: 4e-4, 1: 2e-4, 2: 1e-4}                     # par/train.*.json: "learning_rates" by step
+    anneal_schedule = {0: 0.0, 1: 0.3, 2: 0.6}
+    for step in range(3):
+        wav = torch.randint(0, 256, (B, g.enc_in_len), generator=gen).float()
+        mel = torch.randn(B, 39, g.mel_len, generator=gen)
+        voice = torch.randint(0, 40, (B,), generator=gen)
+        jitter = (torch.arange(g.embed_len).repeat(B, 1) + torch.randint(-1, 2, (B, g.embed_len), generator=gen)).clamp_(0, g.embed_len - 1)
+        # ================= the drop-in, chassis.py:143-185 as written =================
+        for pg in ss_optim.param_groups:                             # ss.update_learning_rate(...)
+            pg["lr"] = learning_rates[step]
+        if model.bn_type == "vae":
+            model.objective.update_anneal_weight(anneal_schedule[step])
+        ss_optim.zero_grad()
+        if bn == "vae":
+            torch.manual_seed(1000 + step)                           # (the reparameterisation noise: drawn inside run(), read back below)
+        quant, target, loss = model.run(wav.to(DEV), mel.to(DEV), voice.to(DEV), jitter.to(DEV))
+        eps_used = model._engine.eps.detach().cpu().permute(0, 2, 1).clone() if bn == "vae" else None
+        probs = softmax(quant)
+        loss.backward()
+        pars_copy = [p.data.clone() for p in model.parameters()]
+        ss_optim.step()
+        target_probs = torch.gather(probs, 1, target.long().unsqueeze(1))      # avg_prob_target
+        tprb_m = torch.mean(target_probs)
+        uw_ratio = {np_[0]: torch.norm(c - np_[1].data) / c.norm() for c, np_ in zip(pars_copy, model.named_parameters())}
+        current_stats = {"lrate": ss_optim.param_groups[0]["lr"]}
+        current_stats.update(model.objective.metrics)
+        current_stats.update(model.encoder.metrics)
+        torch.cuda.synchronize()
+        # ================= the oracle, the same statements =================
+        for pg in adam.param_groups:
+            pg["lr"] = learning_rates[step]
+        adam.zero_grad()
+        okw = dict(loss_mode="intended", take_compat=False)
+        if bn == "vae":
+            okw.update(eps=eps_used, anneal=anneal_schedule[step])
+        out = R.ae_run(sd, {"emb": emb} if emb is not None else {}, hps, g, wav, mel, voice, jitter, **okw)
+        o_quant, o_target = out["pred"], out["target"]           # (quant[..., :-1], wav_out[..., 1:]: autoencoder_model.py:249)
+        o_probs = softmax(o_quant.detach())
+        out["loss"].backward()
+        o_copy = [sd[n].data.clone() for n in names]
+        adam.step()
+        o_tprb = torch.mean(torch.gather(o_probs, 1, o_target.long().unsqueeze(1)))
+        o_ratio = {n: torch.norm(c - sd[n].data) / c.norm() for c, n in zip(o_copy, names)}
+        # ================= compare =================
+        assert tuple(quant.shape) == tuple(o_quant.shape) and tuple(target.shape) == tuple(o_target.shape)
+        assert torch.equal(target.cpu().long(), o_target.long())
+        rel = abs(float(loss.detach()) / float(out["loss"].detach()) - 1)
+        perr = float((probs.cpu() - o_probs).abs().max())
+        print(f"{bn} step {step}: loss {float(loss.detach()):.5f} oracle {float(out['loss'].detach()):.5f} rel {rel:.1e}; max |dp| {perr:.2e}; "
+              f"tprb_m {float(tprb_m):.6f} vs {float(o_tprb):.6f}")
+        assert rel < (1e-4 if step == 0 else 2e-3), (step, rel)
+        assert perr < 2e-2, (step, perr)
+        assert abs(float(tprb_m) / float(o_tprb) - 1) < 2e-2
+        assert current_stats["lrate"] == learning_rates[step]
+        # update / weight ratios: Adam's first step moves every element by lr (the sign of its gradient), later ones by the
+        # ratio of the moments - the drop-in's ratios follow the oracle's per tensor
+        rr = []
+        for n in names:
+            a, b = float(uw_ratio[n]), float(o_ratio[n])
+            if np.isfinite(b) and b > 0:
+                assert np.isfinite(a), n
+                rr.append(abs(a / b - 1))
+            else:                                                    # zero-initialised biases: ||c|| = 0 on both sides (inf / nan,
+                assert not np.isfinite(a) or a == 0, n               # as in the reference's own loop)
+        rr.sort()
+        assert rr[len(rr) // 2] < (5e-3 if step == 0 else 5e-2) and rr[-1] < (5e-2 if step == 0 else 0.5), (step, rr[len(rr) // 2], rr[-1])
+        # the per-step statistics the harness prints exist, are finite scalars, and carry what run() measured
+        for k, v in current_stats.items():
+            if torch.is_tensor(v):
+                assert v.numel() == 1 and bool(torch.isfinite(v.float()).all()), k
+        for k in ("mel_grad_sd", "bn_grad_sd"):
+            assert k in current_stats, (k, sorted(current_stats))
+        if bn == "vqvae-ema":
+            emb = model._engine.emb.detach().cpu().clone()           # (the next step quantises against the device's codebook)
