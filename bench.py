@@ -322,7 +322,7 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
-def pmc_traffic(kernel_prefix, tag="r05"):
+def pmc_traffic(kernel_prefix, tag="r06"):
     """HBM bytes per launch (a number, as the bench contract asks) of the dominant kernel from the committed PMC passes
     (profiles/<tag>_pmc_hbm_traffic.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
     FETCH doubled per MI355X_MICROARCH.md; written by tools/measure_round.sh together with <tag>_pmc_hbm_traffic.sha =

@@ -63,6 +63,39 @@ def test_full_window_step_vs_oracle():
     assert cos_min > 0.99 and emax[2] < 0.17, (cos_min, emax)       # measured 0.9932 / 0.1285
 
 
+def test_as_benchmarked_batch_chained_step_vs_oracle():
+    """BASELINE configs[1] AS BENCHMARKED: B = 8 windows of w = 5000, the forward's gated stack as ONE chained launch of
+    27 856 tiles (the B = 1 test above runs 112-tile launches on the unchained small-tile shapes; until round 6 the chained
+    configuration reached the oracle only through bit-identity to the serial plan).  Loss, all 232 code indices, every
+    gradient (chassis.py:151-157).  ~40 s of oracle on the host."""
+    from oracle import ref_model as R
+    hps, eng, wts, emb, inp = seeded_full_engine(B=8, w=5000, seed=17)
+    assert eng.nt_chain_used >= 2 and getattr(eng.fwd_b, "nt_chains", None), "the forward stack is expected to run chained"
+    eng.set_inputs(*[t.to(DEV) for t in inp])
+    loss = float(eng.forward())
+    eng.backward()
+    torch.cuda.synchronize()
+    eng.chain_guard_check()
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(min(16, n_thr))
+    try:
+        sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in wts.items()}
+        out = R.ae_run(sd, {"emb": torch.from_numpy(emb)}, hps, eng.geom, *inp, loss_mode="intended", take_compat=False)
+        out["loss"].backward()
+    finally:
+        torch.set_num_threads(n_thr)
+    assert eng.Q == 232 and np.array_equal(eng.ind[:eng.Q].cpu().numpy(), out["min_ind"].reshape(-1).numpy())
+    rel = abs(loss / float(out["loss"]) - 1)
+    rows = _grad_table(eng, sd)
+    med, worst = rows[len(rows) // 2], rows[-1]
+    cos_min = min(r[1] for r in rows)
+    print(f"B=8 w=5000 chained vs oracle: loss {loss:.4f} vs {float(out['loss']):.4f} (rel {rel:.1e}); {len(rows)} gradient tensors: "
+          f"relative L2 median {med[0]:.4f}, worst {worst[0]:.4f} ({worst[3]}); lowest cosine {cos_min:.5f}")
+    assert rel < 1e-4
+    assert len(rows) >= 190
+    assert med[0] < 0.10 and worst[0] < 0.15 and cos_min > 0.99, (med, worst, cos_min)    # (bench.py's parity record: 0.080 / 0.102 / 0.9948)
+
+
 def test_full_width_vae_step_vs_oracle():
     """BASELINE configs[3] at full width on the GPU (768-wide encoder, 64-d latent, 20 x 368 / 256 decoder; B = 2,
     w = 100, jitter on, eps injected, anneal 0.3): mu and log sigma^2 (fp32 exact-chain encoder: round-off), KL, loss,
