@@ -143,7 +143,7 @@ class SpkBwd(C.Structure):
 class Tuning(C.Structure):
     """aew_tuning_t: kernel-shape choices as a record (the aew_set_* switches edit the process-wide one; Plan.run(...,
     tuning=...) / aew_run_plan_tuned apply a caller's own to one call)."""
-    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("nt_chain", i32), ("deterministic", i32), ("reserved_", i32 * 6)]
+    _fields_ = [("nt_wave_rows", i32), ("nt_pipe", i32), ("nt_rows192", i32), ("nt_small_tiles", i32), ("nt_small_n64", i32), ("nt_small_w8", i32), ("nt_small_deep", i32), ("nt_window", i32), ("nt_mem128", i32), ("nt_deep", i32), ("nf_loaders", i32), ("nf_deep", i32), ("fn_enable", i32), ("fn_ring3", i32), ("tn_safe", i32), ("tn_big", i32), ("tn_big_target", i32), ("tn_fold_rows", i32), ("tn_target_blocks", i32), ("tn_small_tiles", i32), ("tn_small_target", i32), ("lanes", i32), ("tn_cursor_epoch", i32), ("tn_cursor_slack", i32), ("nt_chain", i32), ("deterministic", i32), ("tn_mfma32", i32), ("reserved_", i32 * 5)]
 
 
 class BaseGather(C.Structure):

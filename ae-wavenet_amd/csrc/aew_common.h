@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define AEW_WAVE 64
 #define AEW_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
@@ -23,7 +24,7 @@ __device__ __attribute__((aligned(128))) unsigned int aew_zero_region[2 * AEW_ZE
 // ---- tuning context (aew_tuning_t, aewavenet.h): the process-wide record the aew_set_* switches edit, and the record of
 // the call in progress when a caller passed its own (aew_run_plan_tuned): launchers read AEW_T().field
 // (field order of aew_tuning_t; the ONE place the library's defaults are written down: aew_tuning_default returns the same)
-#define AEW_TUNING_DEFAULTS {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, 0, 0, 1, 1, {0, 0, 0, 0, 0, 0}}
+#define AEW_TUNING_DEFAULTS {64, 1, 1, 128, 256, 1, 256, 64, 0, 0, 1, 256, 1, 16, 0, 0, 256, 4096, 512, 8, 128, 0, 0, 0, 1, 1, 0, {0, 0, 0, 0, 0}}
 static aew_tuning_t g_tune = AEW_TUNING_DEFAULTS;
 static thread_local const aew_tuning_t* t_tune = nullptr;
 static inline const aew_tuning_t& AEW_T() { return t_tune ? *t_tune : g_tune; }

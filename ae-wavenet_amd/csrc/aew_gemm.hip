@@ -1644,7 +1644,11 @@ struct TnPtrs {
     bool fast;                   // wave-uniform: every row this wave will stage (all stages) is valid
 };
 
-template <int NP, int ESIZE, int RC>
+// swizzle of the 32 x 32 x 16 fragment pattern (tn32_tile): a 16-lane group of ds_read_b64_tr_b16 covers 4 rows x 16 columns
+// and lanes 0-31 are served together - 4 rows x 4 chunks: row r & 3 selects one of four 64-byte quarters of the 256-byte row
+__device__ __forceinline__ int tn_swz32(int row, int chunk) { return chunk ^ ((row & 3) << 2); }
+
+template <int NP, int ESIZE, int RC, int SWZ = 0>
 __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& tt, int b, int r_lo, int n0,
                                          int wave, int lane, TnPtrs<NP>& P, int nst = 0, int r_end = 0) {
     const aew_seg_t sa = g.seg[tt.seg], sg = g.g;             // one batch of scalar loads
@@ -1657,7 +1661,7 @@ __device__ __forceinline__ void tn_setup(const aew_gemm_tn_t& g, const TnTile& t
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int r = (wave * NP + j) * 4 + lr;
-        const int c = ESIZE == 2 ? tn_swz_bf16(r, pc) : tn_swz_f32(r, pc);
+        const int c = ESIZE == 2 ? (SWZ ? tn_swz32(r, pc) : tn_swz_bf16(r, pc)) : tn_swz_f32(r, pc);
         const int m = r_lo + r;
         P.m[j] = m;
         P.grow[j] = m * sg.row_step + sg.row_off;
@@ -1936,6 +1940,158 @@ __global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16(const aew_gemm_t
     const int slab = fold_batch ? sp : (bz * splits + sp);
     tn_bf16_tile<SAFE, false>(g, smem, tile % nkt, tile / nkt, fold_batch ? 0 : bz, fold_batch ? g.batch : bz + 1,
                               r_lo, r_hi, g.out + (int64_t)slab * g.out_batch_stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same 128 x 128 tile on v_mfma_f32_32x32x16_bf16 (round 6, aew_tuning_t.tn_mfma32): HALF the MFMA instructions per
+// stage (8 instead of 16 per wave: 2 x 2 tiles of 32 x 32, two 16-row k steps) for the same fragment bytes - the K loops
+// are issue-bound (DESIGN 5 "Round 6") - and the instruction the bf16 peak is quoted on.  A wave still owns 64 (k) x 64
+// (n); fragments: lane l holds 8 consecutive contraction rows 16 s + 8 (l / 32) .. + 7 of column l % 32 - two
+// ds_read_b64_tr_b16, whose 16-lane groups each cover 4 rows x 16 columns (rows Rb + (q >> 2), columns Cb + 4 (q & 3) in,
+// rows Rb .. Rb + 3 of column Cb + q out); accumulator register r of lane l = dW[n = .. + l % 32][k = .. + 8 (r / 4) +
+// 4 (l / 32) + r % 4].  Same products, summed in 16-row instead of 32-row groups: equal to fp32 rounding, not bit for bit,
+// to the 16 x 16 x 32 form; one fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t tn_frag32(const char* tile, int s, int c0, int lane) {
+    const int q = lane & 15, ch = (lane >> 4) & 1, kh = lane >> 5;
+    s16x8_t out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * s + 8 * kh + 4 * h + (q >> 2);
+        const int col = c0 + 16 * ch + 4 * (q & 3);
+        const int chunk = tn_swz32(row, col >> 3);
+        const char* p = tile + row * 256 + (chunk << 4) + ((col & 7) << 1);
+        const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)AEW_LDS_PTR(p));
+        out[4 * h + 0] = v[0]; out[4 * h + 1] = v[1]; out[4 * h + 2] = v[2]; out[4 * h + 3] = v[3];
+    }
+    return __builtin_bit_cast(bf16x8_t, out);
+}
+
+template <bool SNAP>
+__device__ __forceinline__ void tn32_tile(const aew_gemm_tn_t& g, char* smem, int kt, int nt, int b_lo, int b_hi,
+                                          int r_lo, int r_hi, float* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    const int n0 = nt * TN_BT;
+    const TnTile tt = tn_locate(g, kt, TN_BT);
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nst = (r_hi - r_lo + TN_RC - 1) / TN_RC;
+    const int total = nst * (b_hi - b_lo);
+    TnPtrs<2> P;
+    int st_in_b = 0, bcur = b_lo, issued = 0, slot = 0;
+    auto issue_next = [&]() {
+        if (issued == 0) {
+            tn_setup<2, 2, TN_RC, 1>(g, tt, bcur, r_lo, n0, wave, lane, P, nst, r_hi);
+        } else if (++st_in_b == nst) {
+            st_in_b = 0; ++bcur;
+            tn_setup<2, 2, TN_RC, 1>(g, tt, bcur, r_lo, n0, wave, lane, P, nst, r_hi);
+        }
+        tn_issue<2, TN_RC, true>(g, tt, smem + slot * TN_STAGE_BYTES, r_hi, wave, P);
+        slot = (slot + 1 == TN_STAGES) ? 0 : slot + 1;
+        ++issued;
+    };
+    if (total > 0) issue_next();
+    if (total > 1) issue_next();
+    int stage = 0;
+    const int srel = SNAP ? g.snap_k - tt.koff : -1;
+    const bool snap_here = SNAP && g.snap_out && srel >= 0 && srel < TN_BT;
+    int c_in_b = 0, bdone = b_lo;
+    const bool snap_cs = SNAP && g.snap_out && g.snap_k < 0;
+    const bool do_cs = SNAP && (g.colsum_out != nullptr || snap_cs) && kt == 0 && wk == 0;
+    f32x16_t cs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[j][r] = 0.f;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (s16x8_t){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < total) issue_next();
+        const char* gs = smem + stage * TN_STAGE_BYTES;
+        const char* as = gs + TN_RC * 256;
+        stage = (stage + 1 == TN_STAGES) ? 0 : stage + 1;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8_t af[2], gf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = tn_frag32(as, s2, wk * 64 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gf[j] = tn_frag32(gs, s2, wn * 64 + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+            if (do_cs) {                                   // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, gf[j], cs[j], 0, 0, 0);
+            }
+        }
+        if (SNAP && ++c_in_b == nst) {                 // wave-uniform, once per batch element
+            c_in_b = 0;
+            // column srel of the tile: wave half srel >> 6, 32-tile (srel >> 5) & 1, register 4 ((srel >> 3) & 3) + (srel & 3)
+            // of the lanes with lane / 32 == (srel >> 2) & 1
+            if (snap_here && wk == (srel >> 6) && (lane >> 5) == ((srel >> 2) & 1)) {
+                const int si = (srel >> 5) & 1, sr = 4 * ((srel >> 3) & 3) + (srel & 3);
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v = (i == si && r == sr) ? acc[i][j][r] : v;
+                    so[j * 32] = v;
+                }
+            }
+            if (snap_cs && do_cs && (lane >> 5) == 0) {          // every row of cs[j] is sum_m G[m][n] so far
+                float* so = g.snap_out + (int64_t)bdone * g.snap_bs + n0 + wn * 64 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) so[j * 32] = cs[j][0];
+            }
+            ++bdone;
+        }
+    }
+    const int q = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int k = tt.koff + wk * 64 + i * 32 + 8 * rq + 4 * kh;
+                *reinterpret_cast<float4*>(out + (int64_t)n * g.K_total + k) =
+                    make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
+            }
+        if (do_cs && g.colsum_out && kh == 0 && n < g.N) g.colsum_out[n] = cs[j][0];
+    }
+}
+
+__global__ __launch_bounds__(TN_THREADS, 2) void k_gemm_tn_bf16_grp32(const aew_gemm_tn_t* __restrict__ descs,
+                                                                      const int32_t* __restrict__ tile_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rec = __builtin_amdgcn_readfirstlane(tile_map[blockIdx.x]);
+    if (rec < 0) return;
+    const aew_gemm_tn_t& g = descs[rec >> 22];
+    const int tile = rec & 0xfff, chunk = (rec >> 12) & 0x3ff, nkt = g.K_total / TN_BT;
+    if (g.grp_splits > 0) {
+        const int bz = chunk / g.grp_splits, sp = chunk - bz * g.grp_splits;
+        const int r_lo = sp * g.grp_rows;
+        tn32_tile<false>(g, smem, tile % nkt, tile / nkt, bz, bz + 1, r_lo, min(g.Mc, r_lo + g.grp_rows),
+                         g.out + (int64_t)chunk * g.out_batch_stride);
+        return;
+    }
+    tn32_tile<true>(g, smem, tile % nkt, tile / nkt, 0, g.batch, 0, g.Mc, g.out);
 }
 
 // Grouped form (aew_gemm_tn_group_t): block p takes tile tile_map[p] of descriptor table `descs` (device memory,
@@ -2557,6 +2713,7 @@ static int ensure_big_lds() {
     AEW_SET_LDS(k_gemm_tn_bf16_grp_cur, TN_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_big_grp, TNB_LDS_BYTES)
     AEW_SET_LDS(k_gemm_tn_bf16_grp8, TN8_LDS_BYTES)
+    AEW_SET_LDS(k_gemm_tn_bf16_grp32, TN_LDS_BYTES)
     AEW_SET_LDS((k_nt_chain<0>), CHAIN_LDS_BYTES)
     AEW_SET_LDS((k_nt_chain<1>), CHAIN_LDS_BYTES)
 #undef AEW_SET_LDS
@@ -2922,6 +3079,8 @@ static int launch_gemm_tn_group(const aew_gemm_tn_group_t& p, hipStream_t st) {
         if (on)
             hipLaunchKernelGGL(k_gemm_tn_bf16_grp_cur, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map,
                                p.cursors, p.cursor_stride, e, d);
+        else if (AEW_T().tn_mfma32)
+            hipLaunchKernelGGL(k_gemm_tn_bf16_grp32, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
         else
             hipLaunchKernelGGL(k_gemm_tn_bf16_grp, dim3(p.n_blocks), dim3(TN_THREADS), TN_LDS_BYTES, st, p.descs, p.tile_map);
     }

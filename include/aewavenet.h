@@ -695,7 +695,10 @@ typedef struct {
     int32_t deterministic;       /* ABI 20: 1 (default) every sum of the training step has ONE order: column sums and the
                                     speaker-embedding gradient use their ticketed forms where the descriptor carries
                                     det_scratch / det_tickets; 0 = fp32 atomics (A/B of the cost)                   */
-    int32_t reserved_[6];
+    int32_t tn_mfma32;           /* ABI 20: 1 = the grouped weight-gradient launch (tile = 128, no cursor) on v_mfma_f32_32x32x16_bf16:
+                                    half the MFMA instructions per stage; same products, 16-row instead of 32-row partial sums
+                                    (equal to fp32 rounding, not bit for bit, to the 16 x 16 x 32 form).  0 (default)            */
+    int32_t reserved_[5];
 } aew_tuning_t;
 int aew_tuning_default(aew_tuning_t* out);
 int aew_tuning_get(aew_tuning_t* out);

@@ -578,6 +578,20 @@ def test_gemm_tn_group(tile):
         ref, got = ws_c.get(n).float(), ws_g.get(n).float().cpu()
         err = (got - ref).abs().max().item()
         assert err <= 2e-3 * max(1.0, ref.abs().max().item()), (n, err)
+    if tile == 128:
+        # the same launch on v_mfma_f32_32x32x16_bf16 (aew_tuning_t.tn_mfma32): half the MFMA instructions, the same products in
+        # 16-row instead of 32-row partial sums - equal to fp32 rounding, by-products and the split descriptor included
+        keep = {n: ws_g.get(n).clone() for n in ("o1", "o2", "o3", "o4", "snap", "snap2", "cs1", "cs2")}
+        for n in ("o1", "o2", "o3", "o4", "snap", "snap2", "cs1"):
+            ws_g.get(n).zero_()
+        p.run(stream(), tuning=L.current_tuning(tn_mfma32=1))
+        torch.cuda.synchronize()
+        for n, ref in keep.items():
+            got = ws_g.get(n)
+            err = (got - ref).abs().max().item()
+            assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (n, err)
+            assert n in ("cs2",) or not torch.equal(got, torch.zeros_like(got)), n
+        assert torch.all(ws_g.get("cs2")[368:384].cpu() == -7.0)
     # the per-matrix ops (split-K slabs summed afterwards) give the same matrices
     for i, (t, n) in enumerate(zip(build(ws_g), ("o1", "o2", "o3"))):
         slabs = L.tn_slabs(t)

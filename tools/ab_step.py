@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0, "tn_cursor": 0, "deterministic": 1}
+DEFAULTS = {"nt_window": 64, "nt_small_deep": 256, "nt_rows192": 1, "nt_small_tiles": 128, "lanes": 0, "fn": 1, "fn_ring3": 16, "graphs": 1, "nt_small_n64": 256, "nt_mem128": 0, "nt_deep": 0, "tn_cursor": 0, "deterministic": 1, "tn_mfma32": 0}
 
 
 def main():
@@ -93,9 +93,9 @@ def main():
             if k == "graphs":                      # 0: plans run eagerly (real streams + events) instead of as hipGraphs
                 eng.use_graphs = bool(v)
                 continue
-            if k == "deterministic":               # aew_tuning_t.deterministic (no setter: through the record)
+            if k in ("deterministic", "tn_mfma32"):   # aew_tuning_t fields without a setter: through the record
                 import ctypes as _C
-                t = L.current_tuning(deterministic=v)
+                t = L.current_tuning(**{k: v})
                 L.check(lib.aew_tuning_set(_C.byref(t)), "aew_tuning_set")
                 continue
             if k == "tn_cursor":                   # epoch * 10 + slack (0 = the defaults 4 / 2 where the plan paces a launch)
