@@ -172,3 +172,53 @@ def test_deterministic_sums_equal_the_atomic_ones_to_roundoff():
             assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-12, n
         else:
             assert torch.equal(x, y), n
+
+
+@pytest.mark.parametrize("dtype,N,M,B,per_batch", [("bf16", 128, 7046, 8, False), ("bf16", 600, 900, 3, True), ("f32", 64, 29, 8, False),
+                                                     ("f32", 300, 2500, 2, True)])
+def test_colsum_deterministic_form(dtype, N, M, B, per_batch):
+    """AEW_OP_COLSUM in its ticketed form (aew_colsum_t.det_scratch / det_tickets) over the shapes the plans use and some they do
+    not - narrow and multi-column-block matrices, shared and per-batch outputs, bf16 and fp32, a row range that masks rows:
+    equal to the fp64 column sums to fp32 round-off, bit-equal between repeats (the tickets re-arm themselves), bit-equal
+    between two launches on different streams of work (order independence), and accumulating into what `out` held."""
+    from ae_wavenet_amd.engine import det_colsum
+    from ae_wavenet_amd.plan import Mat, Plan, Workspace
+    ws = Workspace(DEV)
+    dt = L.BF16 if dtype == "bf16" else L.F32
+    pitch = (N + 127) // 128 * 128
+    X = Mat.new(ws, "x", B, M, pitch, dt)
+    gen = torch.Generator().manual_seed(N + M)
+    X.tensor().copy_(torch.randn(B, M, pitch, generator=gen).to(ws.get("x").dtype))      # (the buffer is padded past B M pitch)
+    out = ws.alloc("out", B * N if per_batch else N, torch.float32)
+    cs = L.Colsum()
+    cs.x = X.seg(128, row_off=3, hi=M - 5)                       # rows 3 .. M - 6 of every batch element
+    Mv = M - 8
+    cs.dtype, cs.M, cs.N, cs.batch = dt, Mv, N, B
+    cs.out, cs.out_bs, cs.accumulate = out.data_ptr(), (N if per_batch else 0), 1
+    det_colsum(ws, cs, "det.t")
+    p = Plan("cs")
+    p.add(L.OP_COLSUM, cs, "colsum")
+    x = X.tensor()[:, 3:3 + Mv, :N].double()
+    ref = x.sum(1) if per_batch else x.sum((0, 1))
+    res = []
+    for rep in range(3):
+        out.fill_(0.5)                                           # accumulate = 1: the sums are ADDED to what is there
+        if rep == 2:                                             # other work in flight beside it
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                a = torch.randn(2048, 2048, device=DEV)
+                for _ in range(10):
+                    a = (a @ a).clamp_(-1, 1)
+        p.run(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res.append(out[:ref.numel()].clone())
+    got = res[0].double().reshape(ref.shape) - 0.5
+    scale = float(x.abs().sum(1).max()) if per_batch else float(x.abs().sum((0, 1)).max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale, float((got - ref).abs().max()) / scale
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert int(ws.get("det.t.tickets").abs().max()) == 0        # every ticket word back at zero
+    # ... and the atomic form gives the same sums to round-off
+    out.fill_(0.5)
+    p.run(torch.cuda.current_stream().cuda_stream, tuning=L.current_tuning(deterministic=0))
+    torch.cuda.synchronize()
+    assert float((out[:ref.numel()].double().reshape(ref.shape) - 0.5 - ref).abs().max()) <= 2e-6 * scale
